@@ -1,0 +1,168 @@
+/*
+ * spasm_amd.h -- C ABI of the MI355X-native sparse GF(p) echelonization engine.
+ *
+ * This is the drop-in boundary: every `spasm_*` symbol below has the name, argument
+ * order and struct layout that SpaSM.jl binds with `@ccall spasm_lib.<sym>` (reference
+ * file `src/SpaSM.jl`; the line of each binding is cited next to the declaration).
+ * Pointing `spasm_lib` at `libspasm_amd.so` re-routes the echelonize / kernel hot path
+ * to the HIP engine without touching the Julia side.
+ *
+ * Conventions (all from the reference wrapper):
+ *   - indices are 0-based on this side of the boundary      (src/SpaSM.jl:486,597,961)
+ *   - values are balanced residues in [mhalfp, halfp], i32  (src/SpaSM.jl:79-88)
+ *   - rows of a CSR need not be sorted by column            (src/SpaSM.jl:1017-1020)
+ *   - returned objects are owned by the caller and released with spasm_csr_free /
+ *     spasm_lu_free from an arbitrary thread                (src/SpaSM.jl:146-150,273-277)
+ *
+ * The `spasm_amd_*` symbols are engine extensions (device-resident handles for
+ * benchmarking and multi-GPU sharding); the reference has no counterpart for them.
+ */
+#ifndef SPASM_AMD_H
+#define SPASM_AMD_H
+
+#include <stdint.h>
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t i64;
+typedef int32_t spasm_ZZp; /* balanced representative, src/SpaSM.jl:79-81 */
+
+/* struct Field, src/SpaSM.jl:51-56 (32 bytes, embedded by value) */
+struct spasm_field_struct {
+    i64 p;
+    i64 halfp;
+    i64 mhalfp;
+    double dinvp;
+};
+typedef struct spasm_field_struct spasm_field[1];
+
+/* struct _CSR, src/SpaSM.jl:126-134 (72 bytes) */
+struct spasm_csr {
+    i64 nzmax;
+    int n;          /* rows */
+    int m;          /* columns */
+    i64 *p;         /* n+1 row starts */
+    int *j;         /* column indices */
+    spasm_ZZp *x;   /* values (may be NULL when allocated with_values = false) */
+    spasm_field field;
+};
+
+/* struct _Triplet, src/SpaSM.jl:234-243 (only named so that spasm_lu can point at it) */
+struct spasm_triplet;
+
+/* struct _LU, src/SpaSM.jl:262-270 (48 bytes) */
+struct spasm_lu {
+    int r;                    /* rank */
+    bool complete;            /* L present and complete */
+    struct spasm_csr *L;      /* NULL unless opts->L */
+    struct spasm_csr *U;      /* r x m, unit pivots, pivot not necessarily first in row */
+    int *qinv;                /* m entries: row of U holding the pivot of column j, or -1 */
+    int *p;                   /* >= m entries (Julia views it with length U->m, :300) */
+    struct spasm_triplet *Ltmp;
+};
+
+/* struct EchelonizeOpts, src/SpaSM.jl:325-343 (64 bytes) */
+struct echelonize_opts {
+    bool enable_greedy_pivot_search;
+    bool enable_tall_and_skinny;
+    bool enable_dense;
+    bool enable_GPLU;
+    bool L;
+    bool complete;
+    double min_pivot_proportion;
+    int max_round;
+    double sparsity_threshold;
+    int dense_block_size;     /* Julia declares Int (8 bytes) at :339; low 32 bits are read */
+    double low_rank_ratio;
+    double tall_and_skinny_ratio;
+    double low_rank_start_weight;
+};
+
+/* ---- data symbol: SpaSM.log() stores a C callback here, src/SpaSM.jl:34-46 ---- */
+extern int (*logcallback)(char *);
+
+/* ---- spasm_util.c surface ---- */
+double spasm_wtime(void);                                            /* src/SpaSM.jl:430 */
+i64 spasm_nnz(const struct spasm_csr *A);                            /* src/SpaSM.jl:432 */
+struct spasm_csr *spasm_csr_alloc(int n, int m, i64 nzmax, i64 prime, bool with_values); /* :441 */
+void spasm_csr_realloc(struct spasm_csr *A, i64 nzmax);              /* src/SpaSM.jl:447 */
+void spasm_csr_resize(struct spasm_csr *A, int n, int m);            /* src/SpaSM.jl:449 */
+void spasm_csr_free(struct spasm_csr *A);                            /* src/SpaSM.jl:451 */
+void spasm_lu_free(struct spasm_lu *N);                              /* src/SpaSM.jl:463 */
+int spasm_get_num_threads(void);                                     /* src/SpaSM.jl:470 */
+int spasm_get_thread_num(void);                                      /* src/SpaSM.jl:475 */
+
+/* ---- spasm_ZZp.c surface (commented-out binding at src/SpaSM.jl:65; arithmetic restated :73-88,:383-390) ---- */
+void spasm_field_init(i64 p, spasm_field F);
+
+/* ---- spasm_transpose.c ---- */
+struct spasm_csr *spasm_transpose(const struct spasm_csr *A);        /* src/SpaSM.jl:589 (one-argument form) */
+
+/* ---- spasm_echelonize.c / spasm_kernel.c : THE hot path ---- */
+void spasm_echelonize_init_opts(struct echelonize_opts *opts);       /* src/SpaSM.jl:817 */
+struct spasm_lu *spasm_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts); /* :863 */
+struct spasm_csr *spasm_kernel(const struct spasm_lu *fact);         /* src/SpaSM.jl:879 */
+
+/* ====================================================================================
+ * Engine extensions (no reference counterpart): device-resident handles.
+ * ==================================================================================== */
+
+/* Per-round record written by the engine (what libspasm prints per round, README.md:19-38). */
+struct spasm_amd_round_stats {
+    int round;
+    int rows_in;          /* rows of the matrix entering the round */
+    i64 nnz_in;
+    int npiv;             /* structural pivots elected this round */
+    int rows_out;         /* non-empty rows of the Schur complement */
+    i64 nnz_out;
+    i64 nnz_reduced;      /* reference scatter trip count: sum nnz(A_i) + sum over applications nnz(U_r) */
+    i64 applications;     /* (row, pivot-row) eliminations performed */
+    i64 read_bytes;       /* algorithmic read bytes: 8*nnz_reduced + 16*segments + 4*m */
+    double ms_pivots;     /* device time, pivot election + U build */
+    double ms_solve;      /* device time, triangular-solve kernel (multipliers) */
+    double ms_scatter;    /* device time, scatter/accumulate kernel (Schur rows) */
+    double ms_total;
+};
+
+typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;
+
+/* Last error text of the calling thread ("" if none). Engine calls return NULL / nonzero on failure. */
+const char *spasm_amd_last_error(void);
+
+/* Number of HIP devices visible; <= 0 when there is none (the hot path then fails loudly). */
+int spasm_amd_device_count(void);
+int spasm_amd_set_device(int dev);
+
+/* Deterministic synthetic CSR (host memory, caller frees with spasm_csr_free):
+ *   kind 0: every entry present with probability `density` (BASELINE config 2)
+ *   kind 1: exactly `row_nnz` distinct uniform columns per row (BASELINE configs 3/4)
+ * values uniform on the nonzero balanced residues; columns unsorted. */
+struct spasm_csr *spasm_amd_synth_csr(int kind, int n, int m, double density, int row_nnz,
+                                      i64 prime, uint64_t seed);
+
+/* Build a device-resident plan for ONE Schur round of A (BASELINE config 3):
+ * uploads rows [row_lo,row_hi) of A as this device's shard, elects the Faugere-Lachartre
+ * pivots of the WHOLE matrix (so that every shard sees the same U), builds U on the device.
+ * Returns NULL on failure. */
+spasm_amd_schur_plan *spasm_amd_schur_plan_create(const struct spasm_csr *A, int row_lo, int row_hi);
+/* Run the round once on `stream` (a hipStream_t, NULL = default): solve + scatter kernels.
+ * Returns 0 on success. Safe to call repeatedly (outputs are overwritten). */
+int spasm_amd_schur_plan_run(spasm_amd_schur_plan *plan, void *stream);
+/* Block until the plan's last run has finished and fill `stats` (counters + event timings). */
+int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spasm_amd_round_stats *stats);
+/* Copy the Schur complement of the last run back to host CSR (n_shard_nonpivot x m). p_out (may be
+ * NULL) receives, per output row, the index of the originating row of A. */
+struct spasm_csr *spasm_amd_schur_plan_fetch(spasm_amd_schur_plan *plan, int *p_out);
+void spasm_amd_schur_plan_free(spasm_amd_schur_plan *plan);
+
+/* Per-round records of the most recent spasm_echelonize call on this thread. */
+int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPASM_AMD_H */

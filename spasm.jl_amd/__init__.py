@@ -1,0 +1,29 @@
+"""spasm.jl_amd -- MI355X-native sparse GF(p) echelonization behind SpaSM.jl's CSR / echelonize / kernel surface.
+
+The directory name carries a dot, so import it as `spasm_jl_amd` (the loader module of that name
+at the repository root registers this package).
+"""
+from . import _abi
+from .api import (
+    CSR,
+    LU,
+    EchelonizeOpts,
+    Field,
+    SpasmError,
+    ZZp,
+    balanced,
+    echelonize,
+    kernel,
+    last_rounds,
+    nnz,
+    prime0,
+    rank,
+    sparse,
+    synth_csr,
+    transpose,
+)
+
+__all__ = [
+    "CSR", "LU", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "kernel",
+    "last_rounds", "nnz", "prime0", "rank", "sparse", "synth_csr", "transpose",
+]

@@ -1,0 +1,374 @@
+"""Host-side mirror of SpaSM.jl's CSR / echelonize / kernel surface over the C ABI.
+
+Julia is absent from this image, so the host side above the C ABI is written in Python with the
+reference's names, argument meaning and error behaviour (reference src/SpaSM.jl, lines cited per
+item).  Everything that computes goes through libspasm_amd.so; nothing here falls back to Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+prime0 = 42013  # reference src/SpaSM.jl:16
+
+
+class SpasmError(RuntimeError):
+    pass
+
+
+# ---------------------------------------------------------------------------------------------
+# Field / ZZp  (reference src/SpaSM.jl:51-121)
+# ---------------------------------------------------------------------------------------------
+class Field:
+    """Field(p): the finite field Z/pZ, 2 < p <= 0xfffffffb (reference src/SpaSM.jl:73-76)."""
+
+    def __init__(self, p=prime0):
+        p = int(p)
+        if not (2 < p <= 0xFFFFFFFB):
+            raise AssertionError("2 < p <= 0xfffffffb")  # the @assert at :74
+        self.p = p
+        self.halfp = p // 2
+        self.mhalfp = p // 2 - p + 1
+        self.dinvp = 1.0 / p
+
+    def __call__(self, x):
+        """Balanced representative of x (reference src/SpaSM.jl:83-88, :96)."""
+        x = int(x) % self.p
+        return x - self.p if x > self.halfp else x
+
+    def __eq__(self, other):
+        return isinstance(other, Field) and other.p == self.p
+
+    def __hash__(self):
+        return hash(self.p)
+
+    def __repr__(self):
+        return f"Field({self.p})"
+
+
+def ZZp(F, x=None):
+    """ZZp(F, x) / ZZp(p, x) / ZZp(x): balanced representative (reference src/SpaSM.jl:96-98)."""
+    if x is None:
+        return Field(prime0)(F)
+    if not isinstance(F, Field):
+        F = Field(F)
+    return F(x)
+
+
+def balanced(values, p):
+    """Vectorised ZZp: integers -> balanced residues (reference src/SpaSM.jl:955-958)."""
+    v = np.mod(np.asarray(values, dtype=np.int64), p)
+    return np.where(2 * v > p, v - p, v).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+# CSR  (reference src/SpaSM.jl:126-167, :941-1023)
+# ---------------------------------------------------------------------------------------------
+class CSR:
+    """Spasm matrix in Compressed Sparse Row format, owned through the C ABI.
+
+    CSR(m, prime) with a scipy sparse matrix or a 2-D array stores the TRANSPOSE: every column of
+    `m` becomes a row (reference src/SpaSM.jl:941-968, README.md:7).  `transpose=False` stores `m`
+    itself (one extra spasm_transpose, :967).
+    """
+
+    def __init__(self, src, prime=prime0, transpose=True, own=True):
+        self._own = own
+        if isinstance(src, C.POINTER(_abi.CsrStruct)):
+            if not src:
+                raise SpasmError("NULL spasm_csr: " + _abi.last_error())
+            self.data = src
+            return
+        import scipy.sparse as sp
+
+        A = sp.csc_matrix(src)
+        if A.dtype.kind not in "iu":
+            raise TypeError("integer entries expected")
+        A.sum_duplicates()
+        nrow_j, ncol_j = A.shape
+        vals = balanced(A.data, prime)
+        keep = vals != 0  # zeros are dropped (:959)
+        col_of = np.repeat(np.arange(ncol_j), np.diff(A.indptr))
+        counts = np.bincount(col_of[keep], minlength=ncol_j).astype(np.int64)
+        nnz_ = int(keep.sum())
+        ptr = _abi.lib().spasm_csr_alloc(ncol_j, nrow_j, nnz_, int(prime), True)  # csr_alloc(n,m,nzmax,prime) :944
+        if not ptr:
+            raise SpasmError("spasm_csr_alloc failed: " + _abi.last_error())
+        self.data = ptr
+        st = ptr.contents
+        p = np.ctypeslib.as_array(st.p, (ncol_j + 1,))
+        p[0] = 0
+        np.cumsum(counts, out=p[1:])
+        if nnz_:
+            np.ctypeslib.as_array(st.j, (nnz_,))[:] = A.indices[keep]
+            np.ctypeslib.as_array(st.x, (nnz_,))[:] = vals[keep]
+        if not transpose:
+            t = _abi.lib().spasm_transpose(self.data)
+            if not t:
+                raise SpasmError("spasm_transpose failed: " + _abi.last_error())
+            _abi.lib().spasm_csr_free(self.data)
+            self.data = t
+
+    @classmethod
+    def from_rows(cls, rows, m, prime=prime0):
+        """Build directly from libspasm-side rows: rows[i] = list of (column, value)."""
+        n = len(rows)
+        nnz_ = sum(len(r) for r in rows)
+        ptr = _abi.lib().spasm_csr_alloc(n, m, nnz_, int(prime), True)
+        if not ptr:
+            raise SpasmError("spasm_csr_alloc failed: " + _abi.last_error())
+        self = cls(ptr)
+        p, j, x = self.p, self.j, self.x
+        k = 0
+        F = Field(prime)
+        for i, r in enumerate(rows):
+            p[i] = k
+            for (c, v) in r:
+                j[k] = c
+                x[k] = F(v)
+                k += 1
+        p[n] = k
+        return self
+
+    @classmethod
+    def from_arrays(cls, n, m, p, j, x, prime=prime0):
+        """Copy host CSR arrays (0-based, values already balanced) into an owned spasm_csr."""
+        nnz_ = int(p[n])
+        ptr = _abi.lib().spasm_csr_alloc(int(n), int(m), nnz_, int(prime), True)
+        if not ptr:
+            raise SpasmError("spasm_csr_alloc failed: " + _abi.last_error())
+        self = cls(ptr)
+        self.p[:] = np.asarray(p, dtype=np.int64)[: n + 1]
+        if nnz_:
+            self.j[:nnz_] = np.asarray(j, dtype=np.int32)[:nnz_]
+            self.x[:nnz_] = np.asarray(x, dtype=np.int32)[:nnz_]
+        return self
+
+    def __del__(self):  # finalizer(csr_free, x), reference src/SpaSM.jl:146-150
+        if getattr(self, "_own", False) and getattr(self, "data", None):
+            try:
+                _abi.lib().spasm_csr_free(self.data)
+            except Exception:
+                pass
+            self.data = None
+
+    # getproperty, reference src/SpaSM.jl:154-167: views, no copies
+    @property
+    def _st(self):
+        return self.data.contents
+
+    @property
+    def n(self):
+        return int(self._st.n)
+
+    @property
+    def m(self):
+        return int(self._st.m)
+
+    @property
+    def nzmax(self):
+        return int(self._st.nzmax)
+
+    @property
+    def prime(self):
+        return int(self._st.field.p)
+
+    @property
+    def field(self):
+        return Field(self.prime)
+
+    @property
+    def p(self):
+        return np.ctypeslib.as_array(self._st.p, (self.n + 1,))
+
+    @property
+    def j(self):
+        return np.ctypeslib.as_array(self._st.j, (max(self.nzmax, 1),))
+
+    @property
+    def x(self):
+        return np.ctypeslib.as_array(self._st.x, (max(self.nzmax, 1),))
+
+    @property
+    def shape(self):  # Base.size, :229
+        return (self.n, self.m)
+
+    def __repr__(self):  # Base.show, :195
+        return f"{self.n}×{self.m} CSR matrix % {self.prime} with {nnz(self)} (maximum {self.nzmax}) non-zeros"
+
+    def rows(self):
+        """libspasm-side rows as sorted lists of (column, balanced value)."""
+        p, j, x = self.p, self.j, self.x
+        out = []
+        for i in range(self.n):
+            lo, hi = int(p[i]), int(p[i + 1])
+            out.append(sorted(zip(j[lo:hi].tolist(), x[lo:hi].tolist())))
+        return out
+
+    def todense(self):
+        """Dense libspasm-side matrix (n x m) of balanced residues."""
+        D = np.zeros((self.n, self.m), dtype=np.int64)
+        p, j, x = self.p, self.j, self.x
+        for i in range(self.n):
+            lo, hi = int(p[i]), int(p[i + 1])
+            D[i, j[lo:hi]] = x[lo:hi]
+        return D
+
+
+def nnz(A):
+    """SparseArrays.nnz (reference src/SpaSM.jl:432)."""
+    return int(_abi.lib().spasm_nnz(A.data))
+
+
+def sparse(A, transpose=True):
+    """SparseMatrixCSC view of a CSR: column i = row i of the CSR, sorted (reference src/SpaSM.jl:1011-1023)."""
+    import scipy.sparse as sp
+
+    n, m = A.shape
+    k = nnz(A)
+    mat = sp.csc_matrix((A.x[:k].astype(np.int64), A.j[:k].astype(np.int64), A.p.astype(np.int64)), shape=(m, n))
+    mat.sort_indices()
+    return mat if transpose else mat.T.tocsc()
+
+
+def transpose(A):
+    """Base.transpose(::CSR) (reference src/SpaSM.jl:589)."""
+    t = _abi.lib().spasm_transpose(A.data)
+    if not t:
+        raise SpasmError("spasm_transpose failed: " + _abi.last_error())
+    return CSR(t)
+
+
+# ---------------------------------------------------------------------------------------------
+# LU / echelonize / kernel / rank  (reference src/SpaSM.jl:262-305, :814-884, :1147-1149)
+# ---------------------------------------------------------------------------------------------
+class EchelonizeOpts:
+    """EchelonizeOpts() filled by spasm_echelonize_init_opts (reference src/SpaSM.jl:817)."""
+
+    def __init__(self, **kwargs):
+        self.struct = _abi.EchelonizeOptsStruct()
+        _abi.lib().spasm_echelonize_init_opts(C.byref(self.struct))
+        for k, v in kwargs.items():  # parse_echelonize_opts, :819-824
+            if not hasattr(self.struct, k):
+                raise AttributeError(f"type EchelonizeOpts has no field {k}")
+            setattr(self.struct, k, v)
+
+    def __getattr__(self, k):
+        return getattr(self.__dict__["struct"], k)
+
+
+class LU:
+    def __init__(self, ptr):
+        if not ptr:
+            raise SpasmError("spasm_echelonize failed: " + _abi.last_error())
+        self.data = ptr
+
+    def __del__(self):  # finalizer(lu_free, x), reference src/SpaSM.jl:273-277
+        if getattr(self, "data", None):
+            try:
+                _abi.lib().spasm_lu_free(self.data)
+            except Exception:
+                pass
+            self.data = None
+
+    @property
+    def r(self):
+        return int(self.data.contents.r)
+
+    @property
+    def complete(self):
+        return bool(self.data.contents.complete)
+
+    @property
+    def U(self):
+        st = self.data.contents
+        if not st.U:
+            raise SpasmError("M.U is null")  # :291
+        return CSR(st.U, own=False)
+
+    @property
+    def L(self):
+        st = self.data.contents
+        if not st.L:
+            raise SpasmError("M.L is null")  # :288
+        return CSR(st.L, own=False)
+
+    @property
+    def qinv(self):
+        st = self.data.contents
+        if not st.qinv:
+            raise SpasmError("M.qinv is null")
+        return np.ctypeslib.as_array(st.qinv, (max(int(st.U.contents.m), 1),))[: int(st.U.contents.m)]
+
+    @property
+    def p(self):
+        st = self.data.contents
+        if not st.p:
+            raise SpasmError("M.p is null")
+        return np.ctypeslib.as_array(st.p, (max(int(st.U.contents.m), 1),))[: int(st.U.contents.m)]
+
+
+def echelonize(A, opts=None, verbose=False, **kwargs):
+    """echelonize(A; kwargs...) -> LU (reference src/SpaSM.jl:860-866)."""
+    if opts is None:
+        opts = EchelonizeOpts()
+    for k, v in kwargs.items():
+        if not hasattr(opts.struct, k):
+            raise AttributeError(f"type EchelonizeOpts has no field {k}")
+        setattr(opts.struct, k, v)
+    with _quiet(not verbose):
+        ptr = _abi.lib().spasm_echelonize(A.data, C.byref(opts.struct))
+    return LU(ptr)
+
+
+def kernel(A, verbose=False, **kwargs):
+    """kernel(fact::LU) / kernel(A::CSR) (reference src/SpaSM.jl:876-882, :1147)."""
+    fact = A if isinstance(A, LU) else echelonize(A, verbose=verbose, **kwargs)
+    with _quiet(not verbose):
+        ptr = _abi.lib().spasm_kernel(fact.data)
+    if not ptr:
+        raise SpasmError("spasm_kernel failed: " + _abi.last_error())
+    return CSR(ptr)
+
+
+def rank(A, **kwargs):
+    """rank(N::LU) = N.r; rank(A::CSR) = rank(echelonize(A)) (reference src/SpaSM.jl:305, :1149)."""
+    return A.r if isinstance(A, LU) else echelonize(A, **kwargs).r
+
+
+def last_rounds(max_rounds=4096):
+    """Per-round records of the most recent echelonize call on this thread (engine extension)."""
+    buf = (_abi.RoundStats * max_rounds)()
+    n = _abi.lib().spasm_amd_last_rounds(buf, max_rounds)
+    return [buf[i].as_dict() for i in range(min(n, max_rounds))]
+
+
+# The engine's progress text goes to stderr / logcallback like libspasm's; the reference hides it
+# by redirecting the process's stderr around the ccall unless verbose (src/SpaSM.jl:838-858).
+_LOGFUNC = C.CFUNCTYPE(C.c_int, C.c_char_p)
+_swallow = _LOGFUNC(lambda s: 0)
+
+
+class _quiet:
+    def __init__(self, active):
+        self.active = active
+
+    def __enter__(self):
+        if self.active:
+            self.slot = C.c_void_p.in_dll(_abi.lib(), "logcallback")
+            self.prev = self.slot.value
+            self.slot.value = C.cast(_swallow, C.c_void_p).value
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.slot.value = self.prev
+        return False
+
+
+def synth_csr(kind, n, m, density=0.0, row_nnz=0, prime=prime0, seed=0):
+    """Deterministic synthetic CSR: kind 0 = Bernoulli(density), kind 1 = row_nnz per row."""
+    ptr = _abi.lib().spasm_amd_synth_csr(int(kind), int(n), int(m), float(density), int(row_nnz), int(prime), int(seed))
+    if not ptr:
+        raise SpasmError("spasm_amd_synth_csr failed: " + _abi.last_error())
+    return CSR(ptr)

@@ -1,0 +1,1003 @@
+// engine.hip -- round driver of the MI355X echelonization engine and its C ABI entry points.
+//
+// spasm_echelonize / spasm_kernel / spasm_transpose keep the signatures SpaSM.jl binds (reference
+// src/SpaSM.jl:863, :879, :589): host CSR in, host LU / CSR out, caller owns the result.  Inside,
+// the matrix is uploaded once, every round runs on the device (kernels.hpp), and only U, qinv and
+// the rank come back.  There is NO CPU fallback: without a HIP device these entry points fail.
+#include "common.hpp"
+#include "kernels.hpp"
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+#include <vector>
+#include <memory>
+#include <stdexcept>
+#include <algorithm>
+#include <cstring>
+#include <cstdlib>
+
+namespace {
+
+struct EngineError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            char _b[512];                                                                             \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            throw EngineError(_b);                                                                    \
+        }                                                                                             \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    void alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void zero(hipStream_t s) { if (p) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+inline int cdiv(i64 a, i64 b) { return (int)((a + b - 1) / b); }
+
+// device matrix: rows are slices (start,len) of ent; lead = leftmost column; orig = row of the input matrix
+struct DevMat {
+    int n = 0, m = 0;
+    DevBuf<i64d> start;
+    DevBuf<int> len, lead, orig;
+    DevBuf<int2> ent;
+};
+
+struct Scanner {
+    DevBuf<unsigned char> tmp;
+    template <class T> void exclusive(const T *in, T *out, size_t n, hipStream_t s)
+    {
+        size_t bytes = 0;
+        HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), s));
+        tmp.ensure(bytes);
+        HIPCHK(rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), s));
+    }
+};
+
+// hash-table classes of the scatter kernel: log2(slots), threads per workgroup, largest row bound
+struct ScatterClass { int logt, tpb; i64 cap; };
+const ScatterClass kClasses[6] = {{8, 64, 160}, {10, 64, 640}, {11, 128, 1280}, {12, 256, 2560}, {13, 256, 5120}, {14, 256, 10240}};
+const int kNumHashClasses = 6;
+
+template <int LOGT, int TPB, bool SMALL> void launch_scatter(const ScatterArgs &a, int grid, hipStream_t s)
+{
+    typedef typename ZpAcc<SMALL>::type Acc;
+    const size_t lds = ((size_t)1 << LOGT) * (sizeof(Acc) + sizeof(int)) + 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_scatter<LOGT, TPB, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_scatter<LOGT, TPB, SMALL>), dim3(grid), dim3(TPB), lds, s, a);
+    HIPCHK(hipGetLastError());
+}
+
+template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, int grid, hipStream_t s)
+{
+    switch (cls) {
+    case 0: launch_scatter<8, 64, SMALL>(a, grid, s); break;
+    case 1: launch_scatter<10, 64, SMALL>(a, grid, s); break;
+    case 2: launch_scatter<11, 128, SMALL>(a, grid, s); break;
+    case 3: launch_scatter<12, 256, SMALL>(a, grid, s); break;
+    case 4: launch_scatter<13, 256, SMALL>(a, grid, s); break;
+    case 5: if (SMALL) launch_scatter<14, 256, true>(a, grid, s); break;
+    default: break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One echelonization round on one device.
+// ------------------------------------------------------------------------------------------------
+struct Round {
+    ZpField F;
+    int m = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    Scanner scan;
+
+    // election
+    DevBuf<u64d> best;
+    DevBuf<int> colflag, colscan, qinv_r, pivrow, pivcol, is_piv, rowflag, rowscan, np_rows;
+    int npiv = 0, nnp = 0;
+    // U of this round
+    DevBuf<i64d> ulen, uoff;
+    i64 utotal = 0;
+    DevBuf<int2> Ufull, UPP, UPN;
+    DevBuf<UHdr> uhdr;
+    // solve
+    DevBuf<int2> Lpool;
+    DevBuf<i64d> Lstart, bound, sstart;
+    DevBuf<int> Llen, overflow_list;
+    DevBuf<RoundCounters> ctr;
+    RoundCounters hctr;
+    // scatter
+    DevBuf<int> class_count, class_list;
+    DevMat S;
+    i64 s_capacity = 0;      // entries S.ent can hold (sum of bounds at the time it was sized)
+    i64 s_total_bound = 0;
+    int free_cols = 0;
+    // timing
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    Round()
+    {
+        memset(&hctr, 0, sizeof hctr);
+        for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+    }
+    ~Round()
+    {
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    }
+
+    // ---- (1a) local candidates: best[j] = min over local rows with leftmost column j of (len, global row)
+    void elect_local(const DevMat &A, int row_base)
+    {
+        m = A.m;
+        best.ensure((size_t)m + 1);
+        HIPCHK(hipMemsetAsync(best.p, 0xff, ((size_t)m + 1) * sizeof(u64d), stream));
+        if (A.n > 0) {
+            hipLaunchKernelGGL(k_elect, dim3(cdiv(A.n, 256)), dim3(256), 0, stream, A.n, row_base, A.len.p, A.lead.p, best.p);
+            HIPCHK(hipGetLastError());
+        }
+    }
+
+    // ---- (1b) number the pivots by ascending column; pivrow holds GLOBAL row ids
+    void assign_pivots()
+    {
+        colflag.ensure((size_t)m + 1);
+        colscan.ensure((size_t)m + 1);
+        qinv_r.ensure((size_t)m + 1);
+        hipLaunchKernelGGL(k_col_flags, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, m, best.p, colflag.p);
+        HIPCHK(hipGetLastError());
+        scan.exclusive(colflag.p, colscan.p, (size_t)m + 1, stream);
+        HIPCHK(hipMemcpyAsync(&npiv, colscan.p + m, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        pivrow.ensure((size_t)npiv + 1);
+        pivcol.ensure((size_t)npiv + 1);
+        if (m > 0) {
+            hipLaunchKernelGGL(k_col_assign, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, best.p, colscan.p, qinv_r.p, pivrow.p, pivcol.p);
+            HIPCHK(hipGetLastError());
+        }
+    }
+
+    // ---- (1c) local non-pivot, non-empty rows
+    void mark_local(const DevMat &A, int row_base, int lo = 0, int hi = INT_MAX)
+    {
+        is_piv.ensure((size_t)A.n + 1);
+        rowflag.ensure((size_t)A.n + 1);
+        rowscan.ensure((size_t)A.n + 1);
+        np_rows.ensure((size_t)A.n + 1);
+        HIPCHK(hipMemsetAsync(is_piv.p, 0, ((size_t)A.n + 1) * sizeof(int), stream));
+        if (npiv > 0) {
+            hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, row_base, A.n, pivrow.p, is_piv.p);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_row_flags, dim3(cdiv((i64)A.n + 1, 256)), dim3(256), 0, stream, A.n, lo, hi, is_piv.p, A.len.p, rowflag.p);
+        HIPCHK(hipGetLastError());
+        scan.exclusive(rowflag.p, rowscan.p, (size_t)A.n + 1, stream);
+        HIPCHK(hipMemcpyAsync(&nnp, rowscan.p + A.n, sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (A.n > 0) {
+            hipLaunchKernelGGL(k_compact, dim3(cdiv(A.n, 256)), dim3(256), 0, stream, A.n, rowflag.p, rowscan.p, np_rows.p);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+
+    // ---- (2) U from the pivot rows; PM holds them, rowsrc[idx] = row of PM (device array)
+    void build_U(const DevMat &PM, const int *rowsrc)
+    {
+        ulen.ensure((size_t)npiv + 1);
+        uoff.ensure((size_t)npiv + 1);
+        uhdr.ensure((size_t)npiv + 1);
+        hipLaunchKernelGGL(k_gather_len, dim3(cdiv((i64)npiv + 1, 256)), dim3(256), 0, stream, npiv, rowsrc, PM.len.p, ulen.p);
+        HIPCHK(hipGetLastError());
+        scan.exclusive(ulen.p, uoff.p, (size_t)npiv + 1, stream);
+        i64d tot = 0;
+        HIPCHK(hipMemcpyAsync(&tot, uoff.p + npiv, sizeof(i64d), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        utotal = tot;
+        if (utotal >= (i64)0xffffffffLL) throw EngineError("pivot rows of one round exceed 2^32 entries");
+        Ufull.ensure((size_t)utotal + 1);
+        UPP.ensure((size_t)utotal + 1);
+        UPN.ensure((size_t)utotal + 1);
+        if (npiv > 0) {
+            constexpr int TEAM = 16;
+            hipLaunchKernelGGL((k_build_U<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, stream, npiv, F, rowsrc, pivcol.p,
+                               PM.start.p, PM.len.p, PM.ent.p, qinv_r.p, uoff.p, Ufull.p, UPP.p, UPN.p, uhdr.p);
+            HIPCHK(hipGetLastError());
+        }
+        free_cols = m - npiv;
+    }
+
+    // ---- (3) SOLVE for `nrows` rows of M (rows = list of local rows or NULL)
+    void alloc_solve(int nrows, i64 lpool_entries)
+    {
+        Lstart.ensure((size_t)nrows + 1);
+        Llen.ensure((size_t)nrows + 1);
+        bound.ensure((size_t)nrows + 1);
+        sstart.ensure((size_t)nrows + 1);
+        overflow_list.ensure((size_t)nrows + 1);
+        Lpool.ensure((size_t)lpool_entries + 1);
+        ctr.ensure(1);
+        class_count.ensure(NCLASS);
+        class_list.ensure((size_t)NCLASS * (size_t)(nrows > 0 ? nrows : 1));
+        S.start.ensure((size_t)nrows + 1);
+        S.len.ensure((size_t)nrows + 1);
+        S.lead.ensure((size_t)nrows + 1);
+        S.orig.ensure((size_t)nrows + 1);
+    }
+
+    void run_solve(const DevMat &M, const int *rows, const int *self_idx, int nrows)
+    {
+        HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(RoundCounters), stream));
+        HIPCHK(hipMemsetAsync(bound.p + nrows, 0, sizeof(i64d), stream));
+        if (nrows == 0) return;
+        SolveArgs a;
+        a.nrows = nrows;
+        a.rows = rows;
+        a.self_idx = self_idx;
+        a.retry = nullptr;
+        a.retry_count = nullptr;
+        a.start = M.start.p;
+        a.len = M.len.p;
+        a.ent = M.ent.p;
+        a.qinv_r = qinv_r.p;
+        a.uhdr = uhdr.p;
+        a.UPP = UPP.p;
+        a.Lpool = Lpool.p;
+        a.lpool_cap = (u64d)Lpool.n - 1;
+        a.Lstart = Lstart.p;
+        a.Llen = Llen.p;
+        a.bound = bound.p;
+        a.free_cols = free_cols;
+        a.overflow_list = overflow_list.p;
+        a.overflow_count = &ctr.p->solve_overflow;
+        a.ctr = ctr.p;
+        a.F = F;
+        {
+            constexpr int TEAM = 8, CAP = 128, TPB = 256;
+            hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(cdiv((i64)nrows * TEAM, TPB)), dim3(TPB), 0, stream, a);
+            HIPCHK(hipGetLastError());
+        }
+        // rows whose reach overflowed the small list: one wave per row, 4096-entry list
+        a.retry = overflow_list.p;
+        a.retry_count = &ctr.p->solve_overflow;
+        a.overflow_list = nullptr;
+        a.overflow_count = &ctr.p->solve_failed;
+        {
+            constexpr int TEAM = 64, CAP = 4096, TPB = 64;
+            hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(std::min(nrows, 2 * num_cu)), dim3(TPB), 0, stream, a);
+            HIPCHK(hipGetLastError());
+        }
+    }
+
+    // solve + bounds with automatic growth of the multiplier pool; returns the total bound of S
+    i64 solve_phase(const DevMat &M, const int *rows, const int *self_idx, int nrows, i64 lpool_guess)
+    {
+        i64 pool = std::max<i64>(lpool_guess, 1 << 16);
+        for (;;) {
+            alloc_solve(nrows, pool);
+            run_solve(M, rows, self_idx, nrows);
+            run_bounds(nrows);
+            RoundCounters c;
+            HIPCHK(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, stream));
+            const i64 tot = fetch_total_bound(nrows); // synchronises
+            if (c.lpool_overflow) { pool = std::max<i64>(pool * 4, (i64)c.lpool_used + 1024); continue; }
+            if (c.solve_failed) throw EngineError("a row reaches more than 4096 pivot rows of one round: beyond this build's solve classes");
+            return tot;
+        }
+    }
+
+    // ---- (4) SCATTER.  S.ent must hold s_total_bound entries (size_S() after a solve).
+    void run_bounds(int nrows)
+    {
+        scan.exclusive(bound.p, sstart.p, (size_t)nrows + 1, stream);
+    }
+
+    i64 fetch_total_bound(int nrows)
+    {
+        i64d tot = 0;
+        HIPCHK(hipMemcpyAsync(&tot, sstart.p + nrows, sizeof(i64d), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        s_total_bound = tot;
+        return tot;
+    }
+
+    void run_scatter(const DevMat &M, const int *rows, int nrows)
+    {
+        S.n = nrows;
+        S.m = m;
+        if (nrows == 0) return;
+        HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
+        BinArgs b;
+        b.nrows = nrows;
+        b.bound = bound.p;
+        b.Llen = Llen.p;
+        for (int c = 0; c < NCLASS; c++) b.cap[c] = -1;
+        int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1; // 12-byte slots: the 2^14 table exceeds LDS
+        for (int c = 0; c < nhash; c++) b.cap[c] = kClasses[c].cap;
+        // classes nhash..NCLASS-2 are unused (cap -1 never matches); the last class collects what fits nowhere
+        b.class_count = class_count.p;
+        b.class_list = class_list.p;
+        hipLaunchKernelGGL(k_bin, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, b);
+        HIPCHK(hipGetLastError());
+
+        ScatterArgs a;
+        a.rows = rows;
+        a.start = M.start.p;
+        a.len = M.len.p;
+        a.orig = M.orig.p;
+        a.ent = M.ent.p;
+        a.qinv_r = qinv_r.p;
+        a.uhdr = uhdr.p;
+        a.UPN = UPN.p;
+        a.Lpool = Lpool.p;
+        a.Lstart = Lstart.p;
+        a.Llen = Llen.p;
+        a.sstart = sstart.p;
+        a.Sent = S.ent.p;
+        a.Slen = S.len.p;
+        a.Slead = S.lead.p;
+        a.Sorig = S.orig.p;
+        a.ctr = ctr.p;
+        a.F = F;
+        for (int c = 0; c < nhash; c++) {
+            a.class_count = class_count.p + c;
+            a.class_list = class_list.p + (size_t)c * nrows;
+            const size_t slot = F.small ? 8 : 12;
+            const size_t lds = ((size_t)1 << kClasses[c].logt) * slot + 16;
+            int per_cu = (int)std::min<size_t>(32 / (kClasses[c].tpb / 64), (160 * 1024) / lds);
+            if (per_cu < 1) per_cu = 1;
+            const int grid = std::min(nrows, num_cu * per_cu);
+            if (F.small) launch_scatter_class<true>(c, a, grid, stream);
+            else launch_scatter_class<false>(c, a, grid, stream);
+        }
+        hipLaunchKernelGGL(k_scatter_mark_failed, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, Llen.p, S.len.p, S.lead.p);
+        HIPCHK(hipGetLastError());
+        // the Schur rows start where their slots start
+        HIPCHK(hipMemcpyAsync(S.start.p, sstart.p, ((size_t)nrows + 1) * sizeof(i64d), hipMemcpyDeviceToDevice, stream));
+    }
+
+    void fetch_counters()
+    {
+        HIPCHK(hipMemcpyAsync(&hctr, ctr.p, sizeof(RoundCounters), hipMemcpyDeviceToHost, stream));
+        int cc[NCLASS];
+        HIPCHK(hipMemcpyAsync(cc, class_count.p, sizeof cc, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (hctr.lpool_overflow) throw EngineError("multiplier pool exhausted");
+        if (hctr.solve_failed) throw EngineError("a row reaches more than 4096 pivot rows of one round: beyond this build's solve classes");
+        if (cc[NCLASS - 1] > 0) throw EngineError("a Schur row needs more than the largest LDS hash table: beyond this build's scatter classes");
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// host CSR -> device matrix
+// ------------------------------------------------------------------------------------------------
+void upload_csr(const struct spasm_csr *A, int row_lo, int row_hi, DevMat &M, hipStream_t s)
+{
+    const int n = row_hi - row_lo;
+    const i64 base = A->p[row_lo];
+    const i64 nnz = A->p[row_hi] - base;
+    M.n = n;
+    M.m = A->m;
+    M.start.ensure((size_t)n + 1);
+    M.len.ensure((size_t)n + 1);
+    M.lead.ensure((size_t)n + 1);
+    M.orig.ensure((size_t)n + 1);
+    M.ent.ensure((size_t)nnz + 1);
+    DevBuf<i64d> dp;
+    DevBuf<int> dj, dx;
+    dp.alloc((size_t)n + 1);
+    dj.alloc((size_t)nnz + 1);
+    dx.alloc((size_t)nnz + 1);
+    // row pointers relative to the shard
+    std::vector<i64d> hp((size_t)n + 1);
+    for (int i = 0; i <= n; i++) hp[(size_t)i] = A->p[row_lo + i] - base;
+    HIPCHK(hipMemcpyAsync(dp.p, hp.data(), ((size_t)n + 1) * sizeof(i64d), hipMemcpyHostToDevice, s));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpyAsync(dj.p, A->j + base, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
+        if (A->x) HIPCHK(hipMemcpyAsync(dx.p, A->x + base, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pack_entries, dim3(std::min<i64>(cdiv(nnz, 256), 65536)), dim3(256), 0, s, (i64d)nnz, dj.p, A->x ? dx.p : nullptr, M.ent.p);
+        HIPCHK(hipGetLastError());
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, n, row_lo, dp.p, M.start.p, M.len.p, M.orig.p);
+        HIPCHK(hipGetLastError());
+        constexpr int TEAM = 8;
+        hipLaunchKernelGGL((k_row_lead<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p, M.lead.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(s)); // hp and the staging buffers go out of scope
+}
+
+void require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) throw EngineError("no HIP device: the MI355X engine has no CPU fallback");
+}
+
+void check_input(const struct spasm_csr *A, const char *who)
+{
+    if (!A) throw EngineError(std::string(who) + ": NULL matrix");
+    const i64 p = A->field->p;
+    if (p <= 2 || p > 0xfffffffbLL) throw EngineError(std::string(who) + ": prime out of range (2 < p <= 0xfffffffb)");
+    if (!A->x && A->p[A->n] > 0) throw EngineError(std::string(who) + ": matrix without values");
+}
+
+thread_local std::vector<spasm_amd_round_stats> g_last_rounds;
+
+i64 read_bytes_of(const RoundCounters &c, int m) { return 8 * (i64)c.nnz_reduced + 16 * (i64)c.segments + 4 * (i64)m; }
+
+void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_in, i64 nnz_in)
+{
+    memset(&st, 0, sizeof st);
+    st.round = round;
+    st.rows_in = rows_in;
+    st.nnz_in = nnz_in;
+    st.npiv = R.npiv;
+    st.rows_out = R.hctr.nonempty_out;
+    st.nnz_out = (i64)R.hctr.nnz_out;
+    st.nnz_reduced = (i64)R.hctr.nnz_reduced;
+    st.applications = (i64)R.hctr.applications;
+    st.read_bytes = read_bytes_of(R.hctr, R.m);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, R.ev[0], R.ev[1]) == hipSuccess) st.ms_pivots = ms;
+    if (hipEventElapsedTime(&ms, R.ev[1], R.ev[2]) == hipSuccess) st.ms_solve = ms;
+    if (hipEventElapsedTime(&ms, R.ev[2], R.ev[3]) == hipSuccess) st.ms_scatter = ms;
+    if (hipEventElapsedTime(&ms, R.ev[0], R.ev[3]) == hipSuccess) st.ms_total = ms;
+}
+
+struct HostU {
+    std::vector<i64> p;      // row pointers
+    std::vector<int> j, x;
+    std::vector<int> pivcol; // pivot column of each row
+    std::vector<int> orig;   // originating row of the input
+};
+
+// append the pivot rows of a round (device) to the host copy of U
+void append_round_U(HostU &U, const Round &R, const DevMat &A, hipStream_t s)
+{
+    const int np = R.npiv;
+    if (np == 0) return;
+    std::vector<int2> ent((size_t)R.utotal);
+    std::vector<i64d> off((size_t)np + 1);
+    std::vector<int> pc((size_t)np), pr((size_t)np);
+    std::vector<int> orig((size_t)A.n);
+    HIPCHK(hipMemcpyAsync(ent.data(), R.Ufull.p, (size_t)R.utotal * sizeof(int2), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(off.data(), R.uoff.p, ((size_t)np + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pc.data(), R.pivcol.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pr.data(), R.pivrow.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (A.n > 0) HIPCHK(hipMemcpyAsync(orig.data(), A.orig.p, (size_t)A.n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const i64 base = U.p.back();
+    for (int k = 0; k < np; k++) {
+        U.p.push_back(base + off[(size_t)k + 1]);
+        U.pivcol.push_back(pc[(size_t)k]);
+        U.orig.push_back(orig[(size_t)pr[(size_t)k]]);
+    }
+    U.j.reserve(U.j.size() + ent.size());
+    U.x.reserve(U.x.size() + ent.size());
+    for (const int2 &e : ent) { U.j.push_back(e.x); U.x.push_back(e.y); }
+}
+
+struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
+{
+    (void)opts; // every pivot is a leftmost entry, so rank, pivot columns and kernel do not depend on the tunables
+    require_device();
+    check_input(A, "spasm_echelonize");
+    const int n = A->n, m = A->m;
+    const i64 prime = A->field->p;
+    const double t0 = spasm_wtime();
+    spasm_logf("[echelonize] Start on %d x %d matrix with %lld nnz\n", n, m, (long long)spasm_nnz(A));
+    g_last_rounds.clear();
+
+    hipStream_t stream = nullptr;
+    HostU U;
+    U.p.push_back(0);
+    std::unique_ptr<DevMat> cur(new DevMat());
+    upload_csr(A, 0, n, *cur, stream);
+    i64 cur_nnz = spasm_nnz(A);
+
+    std::unique_ptr<Round> R(new Round());
+    R->F = zp_field_make(prime);
+    R->stream = stream;
+    int round = 0;
+    while (cur->n > 0 && m > 0) {
+        HIPCHK(hipEventRecord(R->ev[0], stream));
+        R->elect_local(*cur, 0);
+        R->assign_pivots();
+        if (R->npiv == 0) break; // no non-empty row left
+        R->mark_local(*cur, 0);
+        R->build_U(*cur, R->pivrow.p);
+        HIPCHK(hipEventRecord(R->ev[1], stream));
+        const int nnp = R->nnp;
+        const i64 tot = R->solve_phase(*cur, R->np_rows.p, nullptr, nnp, 4 * cur_nnz);
+        HIPCHK(hipEventRecord(R->ev[2], stream));
+        R->S.ent.ensure((size_t)tot + 1);
+        R->run_scatter(*cur, R->np_rows.p, nnp);
+        HIPCHK(hipEventRecord(R->ev[3], stream));
+        R->fetch_counters();
+        append_round_U(U, *R, *cur, stream);
+
+        spasm_amd_round_stats st;
+        fill_stats(st, *R, round, cur->n, cur_nnz);
+        g_last_rounds.push_back(st);
+        spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found [%.1fs]\n", round, R->npiv, st.ms_pivots * 1e-3);
+        spasm_logf("Schur complement: %d * %d [%lld nz / density= %.3f], %.1fs\n", nnp, m - (int)U.pivcol.size(),
+                   (long long)st.nnz_out, nnp > 0 && m > 0 ? (double)st.nnz_out / ((double)nnp * (double)m) : 0.0,
+                   (st.ms_solve + st.ms_scatter) * 1e-3);
+
+        // the Schur complement becomes the matrix of the next round
+        std::unique_ptr<DevMat> next(new DevMat());
+        next->n = nnp;
+        next->m = m;
+        next->start = std::move(R->S.start);
+        next->len = std::move(R->S.len);
+        next->lead = std::move(R->S.lead);
+        next->orig = std::move(R->S.orig);
+        next->ent = std::move(R->S.ent);
+        cur = std::move(next);
+        cur_nnz = st.nnz_out;
+        round++;
+        if (cur_nnz == 0) break;
+    }
+
+    // ---- assemble the host LU (layout reference src/SpaSM.jl:262-270; ownership :273-277)
+    const int r = (int)U.pivcol.size();
+    struct spasm_csr *Uc = spasm_csr_alloc(r, m, U.p.back(), prime, true);
+    if (!Uc) throw EngineError("out of host memory for U");
+    memcpy(Uc->p, U.p.data(), sizeof(i64) * ((size_t)r + 1));
+    if (!U.j.empty()) {
+        memcpy(Uc->j, U.j.data(), sizeof(int) * U.j.size());
+        memcpy(Uc->x, U.x.data(), sizeof(int) * U.x.size());
+    }
+    struct spasm_lu *N = (struct spasm_lu *)malloc(sizeof *N);
+    const int plen = std::max(std::max(n, m), 1);
+    int *qinv = (int *)malloc(sizeof(int) * (size_t)std::max(m, 1));
+    int *p = (int *)malloc(sizeof(int) * (size_t)plen);
+    for (int j = 0; j < m; j++) qinv[j] = -1;
+    for (int k = 0; k < r; k++) qinv[U.pivcol[(size_t)k]] = k;
+    {
+        // pivotal rows first, then the others in ascending order
+        std::vector<char> used((size_t)std::max(n, 1), 0);
+        int w = 0;
+        for (int k = 0; k < r; k++) { p[w++] = U.orig[(size_t)k]; used[(size_t)U.orig[(size_t)k]] = 1; }
+        for (int i = 0; i < n; i++) if (!used[(size_t)i]) p[w++] = i;
+        for (; w < plen; w++) p[w] = -1;
+    }
+    N->r = r;
+    N->complete = false;
+    N->L = nullptr;
+    N->U = Uc;
+    N->qinv = qinv;
+    N->p = p;
+    N->Ltmp = nullptr;
+    spasm_logf("[echelonize] Done in %.1fs. Rank %d, %lld nz in basis\n", spasm_wtime() - t0, r, (long long)U.p.back());
+    return N;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// device transpose: column j of M becomes an output row when keep[j] < 0 (keep == NULL: every column);
+// entries are labelled label[row] (NULL: the row index); diag = 1 prepends (j,-1) to every output row
+// ------------------------------------------------------------------------------------------------
+struct TransposeOut {
+    int nrows = 0;
+    i64 nnz = 0;
+    DevBuf<i64d> Tp;
+    DevBuf<int2> Tent;
+};
+
+void device_transpose(const DevMat &M, int nrowsM, const int *keep, const int *label, int diag, Scanner &scan, hipStream_t s, TransposeOut &out)
+{
+    const int m = M.m;
+    DevBuf<int> cnt, flag, rowidx, cursor;
+    DevBuf<i64d> tlen, tstart;
+    cnt.alloc((size_t)m + 1);
+    flag.alloc((size_t)m + 1);
+    rowidx.alloc((size_t)m + 1);
+    cursor.alloc((size_t)m + 1);
+    tlen.alloc((size_t)m + 1);
+    tstart.alloc((size_t)m + 1);
+    cnt.zero(s);
+    constexpr int TEAM = 8;
+    if (nrowsM > 0) {
+        hipLaunchKernelGGL((k_count_cols<TEAM>), dim3(cdiv((i64)nrowsM * TEAM, 256)), dim3(256), 0, s, nrowsM, M.start.p, M.len.p, M.ent.p, cnt.p);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_trow_len, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, s, m, keep, cnt.p, diag, tlen.p, flag.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(tlen.p, tstart.p, (size_t)m + 1, s);
+    scan.exclusive(flag.p, rowidx.p, (size_t)m + 1, s);
+    i64d tot = 0;
+    int nrows = 0;
+    HIPCHK(hipMemcpyAsync(&tot, tstart.p + m, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nrows, rowidx.p + m, sizeof nrows, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    out.nrows = nrows;
+    out.nnz = tot;
+    out.Tp.alloc((size_t)nrows + 1);
+    out.Tent.alloc((size_t)tot + 1);
+    hipLaunchKernelGGL(k_trow_ptr, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, s, m, keep, rowidx.p, tstart.p, diag, out.Tp.p, out.Tent.p, cursor.p);
+    HIPCHK(hipGetLastError());
+    if (nrowsM > 0) {
+        hipLaunchKernelGGL((k_tfill<TEAM>), dim3(cdiv((i64)nrowsM * TEAM, 256)), dim3(256), 0, s, nrowsM, M.start.p, M.len.p, M.ent.p, label, tstart.p, cursor.p, out.Tent.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(s));
+}
+
+struct spasm_csr *transpose_out_to_host(const TransposeOut &T, int ncols, i64 prime, hipStream_t s)
+{
+    struct spasm_csr *K = spasm_csr_alloc(T.nrows, ncols, T.nnz, prime, true);
+    if (!K) throw EngineError("out of host memory");
+    std::vector<int2> ent((size_t)T.nnz);
+    HIPCHK(hipMemcpyAsync(K->p, T.Tp.p, ((size_t)T.nrows + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    if (T.nnz > 0) HIPCHK(hipMemcpyAsync(ent.data(), T.Tent.p, (size_t)T.nnz * sizeof(int2), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (i64 k = 0; k < T.nnz; k++) { K->j[k] = ent[(size_t)k].x; K->x[k] = ent[(size_t)k].y; }
+    return K;
+}
+
+struct spasm_csr *do_transpose(const struct spasm_csr *A)
+{
+    require_device();
+    if (!A) throw EngineError("spasm_transpose: NULL matrix");
+    hipStream_t s = nullptr;
+    DevMat M;
+    upload_csr(A, 0, A->n, M, s);
+    Scanner scan;
+    TransposeOut T;
+    device_transpose(M, A->n, nullptr, nullptr, 0, scan, s, T);
+    struct spasm_csr *R = transpose_out_to_host(T, A->n, A->field->p, s);
+    if (!A->x) { free(R->x); R->x = nullptr; }
+    return R;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel basis from an echelonized U (reference call site src/SpaSM.jl:879).
+// The reduced row echelon form R of U is computed with the SAME solve + scatter kernels as a Schur
+// round (each row of U is reduced by all the others); the kernel vector of free column j is then
+// -e_j + sum_a R[a][j] e_{pivcol(a)}: a transpose of R's free part (known answers test/runtests.jl:20-23).
+// ------------------------------------------------------------------------------------------------
+struct spasm_csr *do_kernel(const struct spasm_lu *fact)
+{
+    require_device();
+    if (!fact || !fact->U || !fact->qinv) throw EngineError("spasm_kernel: incomplete factorization (U / qinv missing)");
+    const struct spasm_csr *U = fact->U;
+    check_input(U, "spasm_kernel");
+    const int r = U->n, m = U->m;
+    const int *qinv = fact->qinv;
+    const i64 prime = U->field->p;
+    const double t0 = spasm_wtime();
+    spasm_logf("[kernel] start. U is %d x %d (%lld nnz). Transposing U\n", r, m, (long long)spasm_nnz(U));
+
+    // pivot column of each row; check the unit pivots the solve relies on (reference src/SpaSM.jl:712)
+    std::vector<int> pc((size_t)std::max(r, 1), -1);
+    for (int j = 0; j < m; j++) {
+        const int a = qinv[j];
+        if (a >= r) throw EngineError("spasm_kernel: qinv points outside U");
+        if (a >= 0) pc[(size_t)a] = j;
+    }
+    for (int a = 0; a < r; a++) {
+        if (pc[(size_t)a] < 0) throw EngineError("spasm_kernel: a row of U has no pivot column in qinv");
+        bool unit = false;
+        for (i64 k = U->p[a]; k < U->p[a + 1]; k++) if (U->j[k] == pc[(size_t)a] && U->x[k] == 1) unit = true;
+        if (!unit) throw EngineError("spasm_kernel: pivots of U must be 1");
+    }
+    // pivot numbering: a topological order of "row a has an entry on the pivot column of row b => a before b".
+    // U produced by this engine is already ordered (identity); otherwise a depth-first numbering is used.
+    std::vector<int> perm((size_t)std::max(r, 1)), idx_of((size_t)std::max(r, 1));
+    bool ordered = true;
+    for (int a = 0; a < r && ordered; a++)
+        for (i64 k = U->p[a]; k < U->p[a + 1]; k++) {
+            const int b = qinv[U->j[k]];
+            if (b >= 0 && b < a) { ordered = false; break; }
+        }
+    if (ordered) {
+        for (int a = 0; a < r; a++) perm[(size_t)a] = a;
+    } else {
+        std::vector<char> state((size_t)r, 0);
+        std::vector<int> stack, post;
+        std::vector<i64> pos((size_t)r, 0);
+        post.reserve((size_t)r);
+        for (int root = 0; root < r; root++) {
+            if (state[(size_t)root]) continue;
+            stack.push_back(root);
+            state[(size_t)root] = 1;
+            pos[(size_t)root] = U->p[root];
+            while (!stack.empty()) {
+                const int a = stack.back();
+                bool pushed = false;
+                while (pos[(size_t)a] < U->p[a + 1]) {
+                    const int b = qinv[U->j[pos[(size_t)a]++]];
+                    if (b < 0 || b == a) continue;
+                    if (state[(size_t)b] == 1) throw EngineError("spasm_kernel: U is not (permuted) triangular");
+                    if (state[(size_t)b] == 0) {
+                        state[(size_t)b] = 1;
+                        pos[(size_t)b] = U->p[b];
+                        stack.push_back(b);
+                        pushed = true;
+                        break;
+                    }
+                }
+                if (!pushed) { state[(size_t)a] = 2; post.push_back(a); stack.pop_back(); }
+            }
+        }
+        for (int t = 0; t < r; t++) perm[(size_t)t] = post[(size_t)(r - 1 - t)];
+    }
+    for (int t = 0; t < r; t++) idx_of[(size_t)perm[(size_t)t]] = t;
+    std::vector<int> h_qinv_r((size_t)m + 1, -1), h_pivcol((size_t)std::max(r, 1));
+    for (int j = 0; j < m; j++) if (qinv[j] >= 0) h_qinv_r[(size_t)j] = idx_of[(size_t)qinv[j]];
+    for (int t = 0; t < r; t++) h_pivcol[(size_t)t] = pc[(size_t)perm[(size_t)t]];
+
+    hipStream_t s = nullptr;
+    DevMat PM;
+    upload_csr(U, 0, r, PM, s);
+    std::unique_ptr<Round> R(new Round());
+    R->F = zp_field_make(prime);
+    R->stream = s;
+    R->m = m;
+    R->npiv = r;
+    R->qinv_r.alloc((size_t)m + 1);
+    R->pivcol.alloc((size_t)r + 1);
+    DevBuf<int> rowsrc, iota;
+    rowsrc.alloc((size_t)r + 1);
+    iota.alloc((size_t)r + 1);
+    HIPCHK(hipMemcpyAsync(R->qinv_r.p, h_qinv_r.data(), ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    if (r > 0) {
+        HIPCHK(hipMemcpyAsync(R->pivcol.p, h_pivcol.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(rowsrc.p, perm.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(r, 256)), dim3(256), 0, s, r, iota.p);
+        HIPCHK(hipGetLastError());
+    }
+    R->build_U(PM, rowsrc.p);
+    const i64 tot = R->solve_phase(PM, rowsrc.p, iota.p, r, 4 * spasm_nnz(U));
+    R->S.ent.ensure((size_t)tot + 1);
+    R->run_scatter(PM, rowsrc.p, r);
+    R->fetch_counters();
+    R->S.n = r;
+    R->S.m = m;
+    TransposeOut T;
+    device_transpose(R->S, r, R->qinv_r.p, R->pivcol.p, 1, R->scan, s, T);
+    struct spasm_csr *K = transpose_out_to_host(T, m, prime, s);
+    spasm_logf("[kernel] done in %.1fs. NNZ(K) = %lld\n", spasm_wtime() - t0, (long long)spasm_nnz(K));
+    return K;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// device-resident plan for ONE Schur round (bench / multi-GPU shard)
+// ------------------------------------------------------------------------------------------------
+struct spasm_amd_schur_plan {
+    DevMat A;
+    Round R;
+    int lo = 0, hi = 0;
+    i64 nnz_in = 0;
+    i64 prime = 0;
+    bool ran = false;
+};
+
+namespace {
+
+spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi)
+{
+    require_device();
+    check_input(A, "spasm_amd_schur_plan_create");
+    if (lo < 0 || hi > A->n || lo > hi) throw EngineError("spasm_amd_schur_plan_create: bad row range");
+    std::unique_ptr<spasm_amd_schur_plan> P(new spasm_amd_schur_plan());
+    P->lo = lo;
+    P->hi = hi;
+    P->prime = A->field->p;
+    P->nnz_in = A->p[hi] - A->p[lo];
+    hipStream_t s = nullptr;
+    // the whole matrix is resident on every device: the election sees all rows, so every shard builds the same U
+    upload_csr(A, 0, A->n, P->A, s);
+    Round &R = P->R;
+    R.F = zp_field_make(P->prime);
+    R.stream = s;
+    HIPCHK(hipEventRecord(R.ev[0], s));
+    R.elect_local(P->A, 0);
+    R.assign_pivots();
+    R.mark_local(P->A, 0, lo, hi);
+    R.build_U(P->A, R.pivrow.p);
+    HIPCHK(hipEventRecord(R.ev[1], s));
+    // dry run of the solve sizes the multiplier pool and the Schur slots once
+    const i64 tot = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, 4 * spasm_nnz(A));
+    R.S.ent.ensure((size_t)tot + 1);
+    return P.release();
+}
+
+void plan_run(spasm_amd_schur_plan *P, hipStream_t s)
+{
+    Round &R = P->R;
+    R.stream = s;
+    HIPCHK(hipEventRecord(R.ev[1], s));
+    R.run_solve(P->A, R.np_rows.p, nullptr, R.nnp);
+    R.run_bounds(R.nnp);
+    HIPCHK(hipEventRecord(R.ev[2], s));
+    R.run_scatter(P->A, R.np_rows.p, R.nnp);
+    HIPCHK(hipEventRecord(R.ev[3], s));
+    P->ran = true;
+}
+
+struct spasm_csr *plan_fetch(spasm_amd_schur_plan *P, int *p_out)
+{
+    Round &R = P->R;
+    if (!P->ran) throw EngineError("spasm_amd_schur_plan_fetch: run the plan first");
+    hipStream_t s = R.stream;
+    const int n = R.nnp;
+    R.fetch_counters();
+    DevBuf<i64d> len64, ostart;
+    len64.alloc((size_t)n + 1);
+    ostart.alloc((size_t)n + 1);
+    hipLaunchKernelGGL(k_copy_len64, dim3(cdiv((i64)n + 1, 256)), dim3(256), 0, s, n, R.S.len.p, len64.p);
+    HIPCHK(hipGetLastError());
+    R.scan.exclusive(len64.p, ostart.p, (size_t)n + 1, s);
+    i64d tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, ostart.p + n, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    DevBuf<int> oj, ox;
+    oj.alloc((size_t)tot + 1);
+    ox.alloc((size_t)tot + 1);
+    if (n > 0) {
+        constexpr int TEAM = 16;
+        hipLaunchKernelGGL((k_compact_rows<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, R.S.start.p, R.S.len.p, R.S.ent.p, ostart.p, oj.p, ox.p);
+        HIPCHK(hipGetLastError());
+    }
+    struct spasm_csr *S = spasm_csr_alloc(n, R.m, tot, P->prime, true);
+    if (!S) throw EngineError("out of host memory");
+    HIPCHK(hipMemcpyAsync(S->p, ostart.p, ((size_t)n + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    if (tot > 0) {
+        HIPCHK(hipMemcpyAsync(S->j, oj.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(S->x, ox.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    if (p_out && n > 0) HIPCHK(hipMemcpyAsync(p_out, R.S.orig.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return S;
+}
+
+} // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+SPASM_API int spasm_amd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+SPASM_API int spasm_amd_set_device(int dev)
+{
+    if (hipSetDevice(dev) != hipSuccess) { spasm_set_error("hipSetDevice(%d) failed", dev); return 1; }
+    return 0;
+}
+
+// reference src/SpaSM.jl:863
+SPASM_API struct spasm_lu *spasm_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
+{
+    spasm_clear_error();
+    try {
+        return do_echelonize(A, opts);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_echelonize: %s", e.what());
+        return nullptr;
+    }
+}
+
+// reference src/SpaSM.jl:879
+SPASM_API struct spasm_csr *spasm_kernel(const struct spasm_lu *fact)
+{
+    spasm_clear_error();
+    try {
+        return do_kernel(fact);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_kernel: %s", e.what());
+        return nullptr;
+    }
+}
+
+// reference src/SpaSM.jl:589
+SPASM_API struct spasm_csr *spasm_transpose(const struct spasm_csr *A)
+{
+    spasm_clear_error();
+    try {
+        return do_transpose(A);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_transpose: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API spasm_amd_schur_plan *spasm_amd_schur_plan_create(const struct spasm_csr *A, int row_lo, int row_hi)
+{
+    spasm_clear_error();
+    try {
+        return plan_create(A, row_lo, row_hi);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_schur_plan_create: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API int spasm_amd_schur_plan_run(spasm_amd_schur_plan *plan, void *stream)
+{
+    try {
+        plan_run(plan, (hipStream_t)stream);
+        return 0;
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_schur_plan_run: %s", e.what());
+        return 1;
+    }
+}
+
+SPASM_API int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spasm_amd_round_stats *stats)
+{
+    try {
+        if (!plan->ran) throw EngineError("run the plan first");
+        plan->R.fetch_counters();
+        fill_stats(*stats, plan->R, 0, plan->hi - plan->lo, plan->nnz_in);
+        return 0;
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_schur_plan_stats: %s", e.what());
+        return 1;
+    }
+}
+
+SPASM_API struct spasm_csr *spasm_amd_schur_plan_fetch(spasm_amd_schur_plan *plan, int *p_out)
+{
+    spasm_clear_error();
+    try {
+        return plan_fetch(plan, p_out);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_schur_plan_fetch: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API void spasm_amd_schur_plan_free(spasm_amd_schur_plan *plan) { delete plan; }
+
+SPASM_API int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds)
+{
+    const int n = (int)g_last_rounds.size();
+    for (int i = 0; i < n && i < max_rounds; i++) out[i] = g_last_rounds[(size_t)i];
+    return n;
+}
+
+} // extern "C"

@@ -1,0 +1,685 @@
+// kernels.hpp -- hand-written gfx950 kernels of the echelonization round.
+//
+// One round = (1) Faugere-Lachartre pivot election, (2) U build (pivot rows scaled to unit pivot and
+// split by column class), (3) SOLVE: per non-pivot row, the multipliers of the pivot rows that reach
+// it (sparse triangular solve restricted to pivot columns), (4) SCATTER: per non-pivot row, the Schur
+// row = its non-pivot entries minus sum(multiplier * pivot row) accumulated in an LDS hash table.
+//
+// Replaces libspasm's spasm_pivots_extract_structural / spasm_schur / spasm_sparse_triangular_solve /
+// spasm_scatter as SpaSM.jl documents them (reference src/SpaSM.jl:776-778, :761-762, :694-713, :619-620).
+//
+// Why the split into SOLVE and SCATTER (instead of libspasm's per-row reach + scatter over a dense x):
+// x_b * U + x_a = B[k]  (reference src/SpaSM.jl:704-707) separates into
+//        x_b * U_PP = B[k]_P          (dependent chain, but U_PP holds only ~14 % of U's entries)
+//        x_a = B[k]_N - x_b * U_PN    (no ordering constraint: every pivot row applied concurrently)
+// with U_PP in PIVOT-INDEX space (strictly upper triangular: pivots are numbered in a topological
+// order) and U_PN in column space.  The scatter trip count is the same as the reference's.
+//
+// Layout in HBM: rows are (start:i64, len:i32) slices of an array of {col:i32, val:i32} pairs
+// ("CSR with slack": a Schur row is written compactly at the start of a slot sized by its bound),
+// so one 8-byte load fetches an entry and a 16-lane group reads a 128-byte line of a pivot row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include "zp.hpp"
+
+typedef long long i64d;
+typedef unsigned long long u64d;
+
+#define EMPTY_KEY (-1)
+#define NO_BEST (~0ull)
+
+// header of a pivot row: off = offset of its slot in UPP/UPN/Ufull, npp/npn = entries on pivot /
+// non-pivot columns (pivot entry itself excluded), len = full length (npp + npn + 1)
+struct __attribute__((aligned(16))) UHdr {
+    unsigned off;
+    int npp;
+    int npn;
+    int len;
+};
+
+struct RoundCounters {
+    u64d applications;   // (row, pivot row) eliminations with nonzero multiplier
+    u64d nnz_reduced;    // reference scatter trip count: sum nnz(A_i) + sum nnz(U_r) over applications
+    u64d segments;       // row segments visited (1 per row + 1 per application)
+    u64d lpool_used;     // entries of the multiplier pool handed out
+    int solve_overflow;  // rows whose reach did not fit the LDS list of the first solve class
+    int solve_failed;    // rows whose reach did not fit the largest solve class
+    int lpool_overflow;  // multiplier pool exhausted
+    int scatter_overflow;// rows whose bound exceeds the largest hash table class
+    int nonempty_out;    // non-empty Schur rows
+    u64d nnz_out;        // entries of the Schur complement
+};
+
+template <int TEAM> __device__ __forceinline__ u64d team_ballot(bool pred)
+{
+    u64d b = __ballot(pred);
+    if (TEAM == 64) return b;
+    const int base = (threadIdx.x & 63) & ~(TEAM - 1);
+    return (b >> base) & ((1ull << (TEAM & 63)) - 1ull);
+}
+
+__device__ __forceinline__ u64d lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// ------------------------------------------------------------------------------------------------
+// ingest: host-style CSR arrays (p,j,x) -> (start,len,ent)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_entries(i64d nnz, const int *__restrict__ j, const int *__restrict__ x, int2 *__restrict__ ent)
+{
+    i64d k = (i64d)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64d stride = (i64d)gridDim.x * blockDim.x;
+    for (; k < nnz; k += stride) ent[k] = make_int2(j[k], x ? x[k] : 1);
+}
+
+__global__ void k_pack_rows(int n, int row_lo, const i64d *__restrict__ p, i64d *__restrict__ start, int *__restrict__ len, int *__restrict__ orig)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    start[i] = p[i];
+    len[i] = (int)(p[i + 1] - p[i]);
+    orig[i] = row_lo + i;
+}
+
+// leftmost column of every row (INT_MAX for an empty row); TEAM lanes per row
+template <int TEAM>
+__global__ void k_row_lead(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent, int *__restrict__ lead)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i >= n) return;
+    const i64d st = start[i];
+    const int ln = len[i];
+    int mn = INT_MAX;
+    for (int k = tl; k < ln; k += TEAM) mn = min(mn, ent[st + k].x);
+    for (int o = TEAM / 2; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, TEAM));
+    if (tl == 0) lead[i] = mn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Faugere-Lachartre election: candidate of a row = its leftmost entry; per column the sparsest
+// candidate wins, ties to the lowest row: atomicMin on (len << 32 | row).
+// `row_base` makes the row id global when rows are sharded over devices.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_elect(int n, int row_base, const int *__restrict__ len, const int *__restrict__ lead, u64d *__restrict__ best)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ln = len[i];
+    if (ln <= 0) return;
+    atomicMin(&best[lead[i]], ((u64d)(unsigned)ln << 32) | (u64d)(unsigned)(row_base + i));
+}
+
+__global__ void k_col_flags(int m, const u64d *__restrict__ best, int *__restrict__ flag)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) flag[j] = best[j] != NO_BEST;
+    if (j == m) flag[j] = 0;
+}
+
+// pivots are numbered by ascending pivot column: with leftmost pivots this is a topological order
+// (a pivot row only has entries to the right of its pivot)
+__global__ void k_col_assign(int m, const u64d *__restrict__ best, const int *__restrict__ scan, int *__restrict__ qinv_r,
+                             int *__restrict__ pivrow, int *__restrict__ pivcol)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const u64d b = best[j];
+    if (b != NO_BEST) {
+        const int idx = scan[j];
+        qinv_r[j] = idx;
+        pivrow[idx] = (int)(unsigned)(b & 0xffffffffull);
+        pivcol[idx] = j;
+    } else {
+        qinv_r[j] = -1;
+    }
+}
+
+__global__ void k_mark_rows(int npiv, int row_lo, int n, const int *__restrict__ pivrow, int *__restrict__ is_piv)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npiv) return;
+    const int r = pivrow[idx] - row_lo;
+    if (r >= 0 && r < n) is_piv[r] = 1;
+}
+
+__global__ void k_row_flags(int n, int lo, int hi, const int *__restrict__ is_piv, const int *__restrict__ len, int *__restrict__ flag)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i >= lo && i < hi && !is_piv[i] && len[i] > 0) ? 1 : 0;
+    if (i == n) flag[i] = 0;
+}
+
+__global__ void k_compact(int n, const int *__restrict__ flag, const int *__restrict__ scan, int *__restrict__ list)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) list[scan[i]] = i;
+}
+
+// length of each pivot row (i64 for the scan); rows are addressed through `rowsrc` = a local row
+__global__ void k_gather_len(int npiv, const int *__restrict__ rowsrc, const int *__restrict__ len, i64d *__restrict__ out)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < npiv) out[idx] = len[rowsrc[idx]];
+    if (idx == npiv) out[idx] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// U build: one TEAM per pivot.  Scales the row by pivot^-1 ("pivots in U are all equal to 1",
+// reference src/SpaSM.jl:712), writes the full row (column space, for the returned U) and the split
+// copies: UPP = entries on OTHER pivot columns as {pivot index, val}; UPN = entries on non-pivot
+// columns as {col, val}.
+// ------------------------------------------------------------------------------------------------
+template <int TEAM>
+__global__ void k_build_U(int npiv, ZpField F, const int *__restrict__ rowsrc, const int *__restrict__ pivcol,
+                          const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent,
+                          const int *__restrict__ qinv_r, const i64d *__restrict__ uoff,
+                          int2 *__restrict__ Ufull, int2 *__restrict__ UPP, int2 *__restrict__ UPN, UHdr *__restrict__ uhdr)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int idx = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (idx >= npiv) return;
+    const int row = rowsrc[idx];
+    const int pc = pivcol[idx];
+    const i64d st = start[row];
+    const int ln = len[row];
+    const i64d uo = uoff[idx];
+    int pv = 0;
+    for (int k = tl; k < ln; k += TEAM) {
+        const int2 e = ent[st + k];
+        if (e.x == pc) pv = e.y;
+    }
+    for (int o = TEAM / 2; o > 0; o >>= 1) pv += __shfl_xor(pv, o, TEAM); // exactly one lane holds it
+    const int inv = zp_inverse(F, pv);
+    int npp = 0, npn = 0;
+    const u64d below = (1ull << tl) - 1ull;
+    for (int k0 = 0; k0 < ln; k0 += TEAM) {
+        const int k = k0 + tl;
+        const bool valid = k < ln;
+        int2 e = make_int2(-1, 0);
+        int v = 0, q = -1;
+        if (valid) {
+            e = ent[st + k];
+            v = (e.x == pc) ? 1 : zp_mul(F, inv, e.y);
+            Ufull[uo + k] = make_int2(e.x, v);
+            if (e.x != pc) q = qinv_r[e.x];
+        }
+        const bool isPP = valid && e.x != pc && q >= 0;
+        const bool isPN = valid && e.x != pc && q < 0;
+        const u64d mPP = team_ballot<TEAM>(isPP), mPN = team_ballot<TEAM>(isPN);
+        if (isPP) UPP[uo + npp + __popcll(mPP & below)] = make_int2(q, v);
+        if (isPN) UPN[uo + npn + __popcll(mPN & below)] = make_int2(e.x, v);
+        npp += __popcll(mPP);
+        npn += __popcll(mPN);
+    }
+    if (tl == 0) {
+        UHdr h;
+        h.off = (unsigned)uo;
+        h.npp = npp;
+        h.npn = npn;
+        h.len = ln;
+        uhdr[idx] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SOLVE.  One TEAM of lanes per non-pivot row.  The team keeps, in LDS, a list of (pivot index,
+// value) sorted by pivot index: the prefix [0,head) is final (the multipliers x_b, i.e. the row of
+// L, reference src/SpaSM.jl:705-707), the suffix is pending.  Pivot indices are a topological
+// order, so popping the smallest pending index is always legal and new indices land in the suffix.
+// Output per row: the list in a bump-allocated pool, its length, and the bound of the Schur row
+// (its non-pivot entries + sum npn over applications), capped by the number of free columns.
+// ------------------------------------------------------------------------------------------------
+struct SolveArgs {
+    int nrows;                 // rows to process
+    const int *rows;           // local row of each (NULL: identity)
+    const int *self_idx;       // per processed row: pivot index to ignore (kernel basis), or NULL
+    const int *retry;          // when non-NULL: list of row slots to process instead of 0..nrows-1
+    const int *retry_count;
+    const i64d *start;
+    const int *len;
+    const int2 *ent;
+    const int *qinv_r;
+    const UHdr *uhdr;
+    const int2 *UPP;
+    int2 *Lpool;
+    u64d lpool_cap;
+    i64d *Lstart;
+    int *Llen;
+    i64d *bound;
+    int free_cols;             // columns without a pivot after this round: cap of any Schur row
+    int *overflow_list;        // row slots whose reach overflowed the LDS list (NULL: only count)
+    int *overflow_count;
+    RoundCounters *ctr;
+    ZpField F;
+};
+
+// LDS-qualified volatile pointer: the team's lanes exchange data through these arrays inside one wave,
+// so every access must be a real ds_read/ds_write in program order (and must stay in address space 3).
+typedef __attribute__((address_space(3))) volatile int lds_vint;
+
+template <int TEAM, int CAP>
+__device__ __forceinline__ bool sorted_insert(lds_vint *key, lds_vint *val, int head, int &cnt, int q, int v,
+                                              const ZpField &F, int tl)
+{
+    // rank of q among the pending keys [head,cnt)
+    int pos = head, found = -1;
+    for (int b = head; b < cnt; b += TEAM) {
+        const int i = b + tl;
+        const int kk = (i < cnt) ? key[i] : INT_MAX;
+        const u64d mlt = team_ballot<TEAM>(kk < q);
+        const u64d meq = team_ballot<TEAM>(kk == q);
+        pos += __popcll(mlt);
+        if (meq) found = b + __ffsll((long long)meq) - 1;
+    }
+    if (found >= 0) {
+        if (tl == 0) val[found] = zp_add(F, val[found], v);
+        return true;
+    }
+    if (cnt >= CAP) return false;
+    // shift [pos,cnt) up by one, highest chunk first
+    for (int hi = cnt; hi > pos; hi -= TEAM) {
+        const int i = hi - 1 - tl;
+        int kk = 0, vv = 0;
+        if (i >= pos) { kk = key[i]; vv = val[i]; }
+        if (i >= pos) { key[i + 1] = kk; val[i + 1] = vv; }
+    }
+    if (tl == 0) { key[pos] = q; val[pos] = v; }
+    cnt++;
+    return true;
+}
+
+template <int TEAM, int CAP, int TPB>
+__global__ __launch_bounds__(TPB) void k_solve(SolveArgs a)
+{
+    constexpr int TEAMS = TPB / TEAM;
+    __shared__ int s_key[TEAMS * CAP];
+    __shared__ int s_val[TEAMS * CAP];
+    const int team = threadIdx.x / TEAM;
+    const int tl = threadIdx.x % TEAM;
+    lds_vint *key = (lds_vint *)(s_key + team * CAP);
+    lds_vint *val = (lds_vint *)(s_val + team * CAP);
+    const ZpField F = a.F;
+
+    int total = a.nrows;
+    if (a.retry) total = *a.retry_count;
+    u64d c_app = 0, c_red = 0, c_seg = 0;
+    for (i64d gteam = (i64d)blockIdx.x * TEAMS + team; gteam < total; gteam += (i64d)gridDim.x * TEAMS) {
+        const int t = a.retry ? a.retry[gteam] : (int)gteam;
+        const int row = a.rows ? a.rows[t] : t;
+        const int self = a.self_idx ? a.self_idx[t] : -1;
+        const i64d st = a.start[row];
+        const int ln = a.len[row];
+        int cnt = 0, nN = 0;
+        bool ok = true;
+        // ---- the row's own entries: pivot columns into the list, the others only counted
+        for (int k0 = 0; k0 < ln && ok; k0 += TEAM) {
+            const int k = k0 + tl;
+            const bool valid = k < ln;
+            int q = -1, v = 0;
+            if (valid) {
+                const int2 e = a.ent[st + k];
+                q = a.qinv_r[e.x];
+                v = e.y;
+            }
+            const bool isP = valid && q >= 0 && q != self;
+            const bool isN = valid && q < 0;
+            u64d mP = team_ballot<TEAM>(isP);
+            nN += __popcll(team_ballot<TEAM>(isN));
+            while (mP) {
+                const int src = __ffsll((long long)mP) - 1;
+                mP &= mP - 1;
+                const int qq = __shfl(q, src, TEAM);
+                const int vv = __shfl(v, src, TEAM);
+                if (!sorted_insert<TEAM, CAP>(key, val, 0, cnt, qq, vv, F, tl)) { ok = false; break; }
+            }
+        }
+        // ---- eliminate in pivot-index order
+        int head = 0;
+        i64d bound = nN;
+        u64d r_app = 0, r_red = (u64d)ln, r_seg = 1;
+        while (ok && head < cnt) {
+            const int idx = key[head];
+            const int mult = val[head];
+            head++;
+            if (mult == 0) continue; // cancelled: nothing to eliminate
+            const UHdr h = a.uhdr[idx];
+            r_app += 1;
+            r_red += (u64d)h.len;
+            r_seg += 1;
+            bound += h.npn;
+            const int nm = zp_neg(F, mult);
+            for (int k0 = 0; k0 < h.npp && ok; k0 += TEAM) {
+                const int k = k0 + tl;
+                int2 e = make_int2(0, 0);
+                if (k < h.npp) e = a.UPP[(i64d)h.off + k];
+                const int nin = min(TEAM, h.npp - k0);
+                for (int s = 0; s < nin; s++) {
+                    const int qq = __shfl(e.x, s, TEAM);
+                    const int vv = __shfl(e.y, s, TEAM);
+                    if (!sorted_insert<TEAM, CAP>(key, val, head, cnt, qq, zp_mul(F, nm, vv), F, tl)) { ok = false; break; }
+                }
+            }
+        }
+        if (!ok) {
+            // reach too large for this class: hand the row to the next class
+            if (tl == 0) {
+                a.Llen[t] = -1;
+                a.Lstart[t] = 0;
+                a.bound[t] = 0;
+                const int pos = atomicAdd(a.overflow_count, 1);
+                if (a.overflow_list) a.overflow_list[pos] = t;
+            }
+        } else {
+            // ---- publish the multipliers
+            u64d base = 0;
+            if (tl == 0) base = atomicAdd(&a.ctr->lpool_used, (u64d)cnt);
+            base = __shfl(base, 0, TEAM);
+            if (base + (u64d)cnt > a.lpool_cap) {
+                if (tl == 0) { atomicAdd(&a.ctr->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
+            } else {
+                for (int i = tl; i < cnt; i += TEAM) a.Lpool[base + i] = make_int2(key[i], val[i]);
+                if (tl == 0) {
+                    a.Lstart[t] = (i64d)base;
+                    a.Llen[t] = cnt;
+                    a.bound[t] = bound < (i64d)a.free_cols ? bound : (i64d)a.free_cols;
+                    c_app += r_app; c_red += r_red; c_seg += r_seg;
+                }
+            }
+        }
+    }
+    // one atomic per wave per counter
+    for (int o = 32; o > 0; o >>= 1) {
+        c_app += __shfl_xor(c_app, o);
+        c_red += __shfl_xor(c_red, o);
+        c_seg += __shfl_xor(c_seg, o);
+    }
+    if ((threadIdx.x & 63) == 0 && (c_app | c_red | c_seg)) {
+        atomicAdd(&a.ctr->applications, c_app);
+        atomicAdd(&a.ctr->nnz_reduced, c_red);
+        atomicAdd(&a.ctr->segments, c_seg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// binning of rows by the size of the hash table their Schur row needs
+// ------------------------------------------------------------------------------------------------
+#define NCLASS 8
+struct BinArgs {
+    int nrows;
+    const i64d *bound;
+    const int *Llen;
+    i64d cap[NCLASS];        // class c takes rows with bound <= cap[c]; the last class takes the rest
+    int *class_count;        // [NCLASS]
+    int *class_list;         // [NCLASS][nrows]
+};
+
+__global__ void k_bin(BinArgs a)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    if (t < a.nrows && a.Llen[t] >= 0) {
+        const i64d b = a.bound[t];
+        cls = NCLASS - 1;
+        for (int c = NCLASS - 2; c >= 0; c--) if (b <= a.cap[c]) cls = c;
+    }
+    for (int c = 0; c < NCLASS; c++) {
+        const u64d m = __ballot(cls == c);
+        if (m == 0) continue;
+        int base = 0;
+        if ((threadIdx.x & 63) == (__ffsll((long long)m) - 1)) base = atomicAdd(&a.class_count[c], __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (cls == c) a.class_list[(size_t)c * a.nrows + base + __popcll(m & lanemask_lt())] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SCATTER.  One workgroup per non-pivot row (grid-stride over the rows of one size class).
+// An open-addressing hash table in LDS maps column -> lazily reduced accumulator.  The row's own
+// non-pivot entries are inserted, then every pivot row of its multiplier list is streamed from
+// UPN by a 16-lane group (one 128-byte line per step) and accumulated with LDS atomics; finally the
+// table is swept, reduced to balanced residues, compacted and written as the Schur row.
+// ------------------------------------------------------------------------------------------------
+struct ScatterArgs {
+    const int *class_count;    // rows in this class
+    const int *class_list;     // row slots of this class
+    const int *rows;           // local row of each slot (NULL: identity)
+    const i64d *start;
+    const int *len;
+    const int *orig;
+    const int2 *ent;
+    const int *qinv_r;
+    const UHdr *uhdr;
+    const int2 *UPN;
+    const int2 *Lpool;
+    const i64d *Lstart;
+    const int *Llen;
+    const i64d *sstart;        // slot of each Schur row in Sent
+    int2 *Sent;
+    int *Slen;
+    int *Slead;
+    int *Sorig;
+    RoundCounters *ctr;
+    ZpField F;
+};
+
+template <int LOGT, bool SMALL>
+__device__ __forceinline__ void table_add(int *s_key, typename ZpAcc<SMALL>::type *s_val, int c, typename ZpAcc<SMALL>::type a)
+{
+    constexpr unsigned T = 1u << LOGT;
+    unsigned h = ((unsigned)c * 0x9E3779B1u) >> (32 - LOGT);
+    for (;;) {
+        const int k = atomicCAS(&s_key[h], EMPTY_KEY, c);
+        if (k == EMPTY_KEY || k == c) break;
+        h = (h + 1) & (T - 1);
+    }
+    if (SMALL) atomicAdd((int *)&s_val[h], (int)a);
+    else atomicAdd((u64d *)&s_val[h], (u64d)a);
+}
+
+template <int LOGT, int TPB, bool SMALL>
+__global__ __launch_bounds__(TPB) void k_scatter(ScatterArgs a)
+{
+    typedef typename ZpAcc<SMALL>::type Acc;
+    constexpr int T = 1 << LOGT;
+    constexpr int G = 16;          // lanes streaming one pivot row
+    constexpr int NGW = 64 / G;    // groups per wave
+    constexpr int NW = TPB / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    Acc *s_val = (Acc *)s_raw;
+    int *s_key = (int *)(s_raw + sizeof(Acc) * T);
+    int *s_misc = s_key + T;       // [0] = entries written, [1] = leftmost column
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane / G, gl = lane % G;
+    const ZpField F = a.F;
+
+    for (int s = tid; s < T; s += TPB) { s_key[s] = EMPTY_KEY; s_val[s] = 0; }
+    if (tid == 0) { s_misc[0] = 0; s_misc[1] = INT_MAX; }
+    __syncthreads();
+
+    const int count = *a.class_count;
+    u64d c_nnz = 0;
+    int c_rows = 0;
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int t = a.class_list[w];
+        const int row = a.rows ? a.rows[t] : t;
+        const i64d st = a.start[row];
+        const int ln = a.len[row];
+        // ---- the row's own entries on non-pivot columns
+        for (int k = tid; k < ln; k += TPB) {
+            const int2 e = a.ent[st + k];
+            if (a.qinv_r[e.x] < 0) table_add<LOGT, SMALL>(s_key, s_val, e.x, (Acc)e.y);
+        }
+        // ---- minus multiplier * pivot row, all pivot rows of the list
+        const i64d ls = a.Lstart[t];
+        const int ll = a.Llen[t];
+        for (int c0 = wave * 64; c0 < ll; c0 += NW * 64) {
+            const int r = c0 + lane;
+            int2 le = make_int2(0, 0);
+            UHdr hd; hd.off = 0; hd.npp = 0; hd.npn = 0; hd.len = 0;
+            if (r < ll) {
+                le = a.Lpool[ls + r];
+                if (le.y != 0) hd = a.uhdr[le.x];
+            }
+            const int nchunk = min(64, ll - c0);
+            const int iters = (nchunk + NGW - 1) / NGW;
+            for (int it = 0; it < iters; it++) {
+                const int e = it * NGW + g;
+                const int src = e < nchunk ? e : 0;
+                const int mult = __shfl(le.y, src);
+                const unsigned off = (unsigned)__shfl((int)hd.off, src);
+                int npn = __shfl(hd.npn, src);
+                if (e >= nchunk || mult == 0) npn = 0;
+                const int nm = zp_neg(F, mult);
+                for (int k = gl; k < npn; k += G) {
+                    const int2 u = a.UPN[(i64d)off + k];
+                    table_add<LOGT, SMALL>(s_key, s_val, u.x, ZpAcc<SMALL>::mul_lazy(F, nm, u.y));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- sweep: reduce, compact, write; reset the table on the way
+        const i64d ss = a.sstart[t];
+        int mylead = INT_MAX;
+        for (int s0 = 0; s0 < T; s0 += TPB) {
+            const int s = s0 + tid;
+            const int c = s_key[s];
+            int v = 0;
+            if (c != EMPTY_KEY) {
+                v = zp_reduce(F, (int64_t)s_val[s]);
+                s_key[s] = EMPTY_KEY;
+                s_val[s] = 0;
+            }
+            const bool nz = v != 0;
+            const u64d m = __ballot(nz);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_misc[0], __popcll(m));
+                base = __shfl(base, 0);
+                if (nz) {
+                    a.Sent[ss + base + __popcll(m & lanemask_lt())] = make_int2(c, v);
+                    mylead = min(mylead, c);
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) mylead = min(mylead, __shfl_xor(mylead, o));
+        if (lane == 0 && mylead != INT_MAX) atomicMin(&s_misc[1], mylead);
+        __syncthreads();
+        if (tid == 0) {
+            const int n_out = s_misc[0];
+            a.Slen[t] = n_out;
+            a.Slead[t] = s_misc[1];
+            a.Sorig[t] = a.orig[row];
+            c_nnz += (u64d)n_out;
+            c_rows += n_out > 0;
+            s_misc[0] = 0;
+            s_misc[1] = INT_MAX;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && (c_nnz || c_rows)) {
+        atomicAdd(&a.ctr->nnz_out, c_nnz);
+        atomicAdd(&a.ctr->nonempty_out, c_rows);
+    }
+}
+
+// rows that were not processed (no class): publish empty rows so that the output is well defined
+__global__ void k_scatter_mark_failed(int nrows, const int *__restrict__ Llen, int *__restrict__ Slen, int *__restrict__ Slead)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nrows && Llen[t] < 0) { Slen[t] = 0; Slead[t] = INT_MAX; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose (counting sort by column) and kernel-basis assembly
+// ------------------------------------------------------------------------------------------------
+__global__ void k_iota(int n, int *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+// cnt[c] += 1 for every entry of the listed rows; TEAM lanes per row
+template <int TEAM>
+__global__ void k_count_cols(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent, int *__restrict__ cnt)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i >= n) return;
+    const i64d st = start[i];
+    const int ln = len[i];
+    for (int k = tl; k < ln; k += TEAM) atomicAdd(&cnt[ent[st + k].x], 1);
+}
+
+// length of every output row: column j of the input becomes a row when keep[j] < 0 (or keep == NULL);
+// `diag` adds one leading entry (the -1 of a kernel vector).  flag[j] = 1 for rows that exist.
+__global__ void k_trow_len(int m, const int *__restrict__ keep, const int *__restrict__ cnt, int diag, i64d *__restrict__ tlen, int *__restrict__ flag)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) {
+        const bool is_row = keep ? keep[j] < 0 : true;
+        tlen[j] = is_row ? (i64d)cnt[j] + diag : 0;
+        flag[j] = is_row ? 1 : 0;
+    }
+    if (j == m) { tlen[j] = 0; flag[j] = 0; }
+}
+
+// row pointers of the output (rows = kept columns, ascending) and the diagonal entries
+__global__ void k_trow_ptr(int m, const int *__restrict__ keep, const int *__restrict__ rowidx, const i64d *__restrict__ tstart, int diag,
+                           i64d *__restrict__ Tp, int2 *__restrict__ Tent, int *__restrict__ cursor)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) {
+        const bool is_row = keep ? keep[j] < 0 : true;
+        if (is_row) {
+            Tp[rowidx[j]] = tstart[j];
+            if (diag) Tent[tstart[j]] = make_int2(j, -1); // K[j] = -1 (reference test/runtests.jl:21: 42012 == -1)
+        }
+        cursor[j] = diag;
+    }
+    if (j == m) Tp[rowidx[m]] = tstart[m];
+}
+
+// entry (c, v) of input row a lands in output row c as (label[a], v)
+template <int TEAM>
+__global__ void k_tfill(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent,
+                        const int *__restrict__ label, const i64d *__restrict__ tstart, int *__restrict__ cursor, int2 *__restrict__ Tent)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i >= n) return;
+    const i64d st = start[i];
+    const int ln = len[i];
+    const int lab = label ? label[i] : i;
+    for (int k = tl; k < ln; k += TEAM) {
+        const int2 e = ent[st + k];
+        const int pos = atomicAdd(&cursor[e.x], 1);
+        Tent[tstart[e.x] + pos] = make_int2(lab, e.y);
+    }
+}
+
+// compact a "CSR with slack" matrix into tight arrays (row order kept)
+__global__ void k_copy_len64(int n, const int *__restrict__ len, i64d *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = len[i];
+    if (i == n) out[i] = 0;
+}
+
+template <int TEAM>
+__global__ void k_compact_rows(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent,
+                               const i64d *__restrict__ ostart, int *__restrict__ oj, int *__restrict__ ox)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i >= n) return;
+    const i64d st = start[i], os = ostart[i];
+    const int ln = len[i];
+    for (int k = tl; k < ln; k += TEAM) {
+        const int2 e = ent[st + k];
+        oj[os + k] = e.x;
+        ox[os + k] = e.y;
+    }
+}
