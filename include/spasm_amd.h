@@ -126,6 +126,12 @@ struct spasm_amd_round_stats {
     double ms_solve;      /* device time, triangular-solve kernel (multipliers) */
     double ms_scatter;    /* device time, scatter/accumulate kernel (Schur rows) */
     double ms_total;
+    /* scatter kernel, per hash-table class (one launch each): device time, rows, entries streamed
+     * (the row's own entries + the non-pivot part of every applied pivot row) and row segments visited */
+    double ms_class[8];
+    int rows_class[8];
+    i64 ent_class[8];
+    i64 seg_class[8];
 };
 
 typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;

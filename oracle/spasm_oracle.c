@@ -307,13 +307,15 @@ static int fl_pivots(const struct spasm_csr *A, struct spasm_csr *U, int *qinv, 
  * Unlike libspasm the output keeps the input row order (deterministic), built in two passes.
  * stats[0] += applications, stats[1] += nnz_reduced (= sum nnz(A_i) + sum nnz(U_r) per application). */
 
-ORC_API struct spasm_csr *orc_schur(const struct spasm_csr *A, const char *is_piv, const struct spasm_csr *U,
-                                    const int *qinv, int *p_out, i64 *stats, int keep_empty)
+static struct spasm_csr *schur_range(const struct spasm_csr *A, const char *is_piv, const struct spasm_csr *U,
+                                     const int *qinv, int *p_out, i64 *stats, int keep_empty, int row_lo, int row_hi)
 {
     int n = A->n, m = A->m;
     int *rows = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
     int nr = 0;
-    for (int i = 0; i < n; i++) if (!is_piv[i] && (keep_empty || A->p[i + 1] > A->p[i])) rows[nr++] = i;
+    if (row_lo < 0) row_lo = 0;
+    if (row_hi > n) row_hi = n;
+    for (int i = row_lo; i < row_hi; i++) if (!is_piv[i] && (keep_empty || A->p[i + 1] > A->p[i])) rows[nr++] = i;
     spasm_ZZp **rx = malloc(sizeof(*rx) * (size_t)(nr > 0 ? nr : 1));
     int **rj = malloc(sizeof(*rj) * (size_t)(nr > 0 ? nr : 1));
     i64 *rn = malloc(sizeof(i64) * (size_t)(nr + 1));
@@ -368,11 +370,28 @@ ORC_API struct spasm_csr *orc_schur(const struct spasm_csr *A, const char *is_pi
     return S;
 }
 
+ORC_API struct spasm_csr *orc_schur(const struct spasm_csr *A, const char *is_piv, const struct spasm_csr *U,
+                                    const int *qinv, int *p_out, i64 *stats, int keep_empty)
+{
+    return schur_range(A, is_piv, U, qinv, p_out, stats, keep_empty, 0, A->n);
+}
+
 /* One Schur round of A on its own (BASELINE config 3 unit of work): elect the FL pivots of A,
  * build U, reduce every non-pivot row.  out[0]=npiv out[1]=applications out[2]=nnz_reduced
  * out[3]=nnz(S) out[4]=rows(S non-empty) out[5]=nnz(U); seconds[0]=pivots seconds[1]=schur. */
+ORC_API struct spasm_csr *orc_schur_round_range(const struct spasm_csr *A, int row_lo, int row_hi, i64 *out, double *seconds,
+                                                struct spasm_csr **U_out, int *qinv_out);
+
 ORC_API struct spasm_csr *orc_schur_round(const struct spasm_csr *A, i64 *out, double *seconds,
                                           struct spasm_csr **U_out, int *qinv_out)
+{
+    return orc_schur_round_range(A, 0, A->n, out, seconds, U_out, qinv_out);
+}
+
+/* Same, but only the non-pivot rows inside [row_lo,row_hi) are reduced (the pivots are still those of
+ * the whole matrix): a bounded sample of the round for the timed CPU baseline, and a row shard. */
+ORC_API struct spasm_csr *orc_schur_round_range(const struct spasm_csr *A, int row_lo, int row_hi, i64 *out, double *seconds,
+                                                struct spasm_csr **U_out, int *qinv_out)
 {
     int n = A->n, m = A->m;
     struct timespec t0, t1, t2;
@@ -385,7 +404,7 @@ ORC_API struct spasm_csr *orc_schur_round(const struct spasm_csr *A, i64 *out, d
     int npiv = fl_pivots(A, U, qinv, NULL, is_piv, NULL, NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     i64 stats[2] = {0, 0};
-    struct spasm_csr *S = orc_schur(A, is_piv, U, qinv, NULL, stats, 1);
+    struct spasm_csr *S = schur_range(A, is_piv, U, qinv, NULL, stats, 1, row_lo, row_hi);
     clock_gettime(CLOCK_MONOTONIC, &t2);
     int nonempty = 0;
     for (int i = 0; i < S->n; i++) nonempty += S->p[i + 1] > S->p[i];

@@ -72,10 +72,18 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
         ("ms_solve", C.c_double),
         ("ms_scatter", C.c_double),
         ("ms_total", C.c_double),
+        ("ms_class", C.c_double * 8),
+        ("rows_class", C.c_int32 * 8),
+        ("ent_class", C.c_int64 * 8),
+        ("seg_class", C.c_int64 * 8),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {}
+        for k, _ in self._fields_:
+            v = getattr(self, k)
+            d[k] = list(v) if hasattr(v, "__len__") else v
+        return d
 
 
 # sizes / offsets the Julia mirrors imply; checked in tests/test_abi.py

@@ -145,11 +145,16 @@ struct Round {
     int free_cols = 0;
     // timing
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_cls[NCLASS + 1];
+    int hclass_count[NCLASS];
+    int nhash_used = 0;
 
     Round()
     {
         memset(&hctr, 0, sizeof hctr);
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+        for (auto &e : ev_cls) { e = nullptr; HIPCHK(hipEventCreate(&e)); }
+        memset(hclass_count, 0, sizeof hclass_count);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
@@ -157,6 +162,7 @@ struct Round {
     ~Round()
     {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto &e : ev_cls) if (e) (void)hipEventDestroy(e);
     }
 
     // ---- (1a) local candidates: best[j] = min over local rows with leftmost column j of (len, global row)
@@ -260,6 +266,7 @@ struct Round {
     void run_solve(const DevMat &M, const int *rows, const int *self_idx, int nrows)
     {
         HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(RoundCounters), stream));
+        HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(bound.p + nrows, 0, sizeof(i64d), stream));
         if (nrows == 0) return;
         SolveArgs a;
@@ -371,7 +378,10 @@ struct Round {
         a.Sorig = S.orig.p;
         a.ctr = ctr.p;
         a.F = F;
+        nhash_used = nhash;
         for (int c = 0; c < nhash; c++) {
+            HIPCHK(hipEventRecord(ev_cls[c], stream));
+            a.cls = c;
             a.class_count = class_count.p + c;
             a.class_list = class_list.p + (size_t)c * nrows;
             const size_t slot = F.small ? 8 : 12;
@@ -382,6 +392,7 @@ struct Round {
             if (F.small) launch_scatter_class<true>(c, a, grid, stream);
             else launch_scatter_class<false>(c, a, grid, stream);
         }
+        HIPCHK(hipEventRecord(ev_cls[nhash], stream));
         hipLaunchKernelGGL(k_scatter_mark_failed, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, Llen.p, S.len.p, S.lead.p);
         HIPCHK(hipGetLastError());
         // the Schur rows start where their slots start
@@ -391,11 +402,12 @@ struct Round {
     void fetch_counters()
     {
         HIPCHK(hipMemcpyAsync(&hctr, ctr.p, sizeof(RoundCounters), hipMemcpyDeviceToHost, stream));
-        int cc[NCLASS];
-        HIPCHK(hipMemcpyAsync(cc, class_count.p, sizeof cc, hipMemcpyDeviceToHost, stream));
+        int *cc = hclass_count;
+        HIPCHK(hipMemcpyAsync(cc, class_count.p, NCLASS * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (hctr.lpool_overflow) throw EngineError("multiplier pool exhausted");
         if (hctr.solve_failed) throw EngineError("a row reaches more than 4096 pivot rows of one round: beyond this build's solve classes");
+        if (hctr.scatter_overflow) throw EngineError("a hash table of the scatter kernel filled up (internal bound violated)");
         if (cc[NCLASS - 1] > 0) throw EngineError("a Schur row needs more than the largest LDS hash table: beyond this build's scatter classes");
     }
 };
@@ -476,6 +488,12 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     if (hipEventElapsedTime(&ms, R.ev[1], R.ev[2]) == hipSuccess) st.ms_solve = ms;
     if (hipEventElapsedTime(&ms, R.ev[2], R.ev[3]) == hipSuccess) st.ms_scatter = ms;
     if (hipEventElapsedTime(&ms, R.ev[0], R.ev[3]) == hipSuccess) st.ms_total = ms;
+    for (int c = 0; c < R.nhash_used && c < 8; c++) {
+        if (hipEventElapsedTime(&ms, R.ev_cls[c], R.ev_cls[c + 1]) == hipSuccess) st.ms_class[c] = ms;
+        st.rows_class[c] = R.hclass_count[c];
+        st.ent_class[c] = (i64)R.hctr.class_ent[c];
+        st.seg_class[c] = (i64)R.hctr.class_seg[c];
+    }
 }
 
 struct HostU {

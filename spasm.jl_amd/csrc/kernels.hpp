@@ -50,6 +50,8 @@ struct RoundCounters {
     int scatter_overflow;// rows whose bound exceeds the largest hash table class
     int nonempty_out;    // non-empty Schur rows
     u64d nnz_out;        // entries of the Schur complement
+    u64d class_ent[8];   // scatter kernel, per class: entries streamed
+    u64d class_seg[8];   // scatter kernel, per class: row segments visited
 };
 
 template <int TEAM> __device__ __forceinline__ u64d team_ballot(bool pred)
@@ -460,21 +462,27 @@ struct ScatterArgs {
     int *Slead;
     int *Sorig;
     RoundCounters *ctr;
+    int cls;                   // index of this size class (for the per-class counters)
     ZpField F;
 };
 
 template <int LOGT, bool SMALL>
-__device__ __forceinline__ void table_add(int *s_key, typename ZpAcc<SMALL>::type *s_val, int c, typename ZpAcc<SMALL>::type a)
+__device__ __forceinline__ void table_add(int *s_key, typename ZpAcc<SMALL>::type *s_val, int c, typename ZpAcc<SMALL>::type a,
+                                          RoundCounters *ctr)
 {
     constexpr unsigned T = 1u << LOGT;
     unsigned h = ((unsigned)c * 0x9E3779B1u) >> (32 - LOGT);
-    for (;;) {
+    // linear probing; the class caps keep the load <= 5/8, the probe bound only guards against a full table
+    for (unsigned probes = 0; probes < T; probes++) {
         const int k = atomicCAS(&s_key[h], EMPTY_KEY, c);
-        if (k == EMPTY_KEY || k == c) break;
+        if (k == EMPTY_KEY || k == c) {
+            if (SMALL) atomicAdd((int *)&s_val[h], (int)a);
+            else atomicAdd((u64d *)&s_val[h], (u64d)a);
+            return;
+        }
         h = (h + 1) & (T - 1);
     }
-    if (SMALL) atomicAdd((int *)&s_val[h], (int)a);
-    else atomicAdd((u64d *)&s_val[h], (u64d)a);
+    atomicAdd(&ctr->scatter_overflow, 1);
 }
 
 template <int LOGT, int TPB, bool SMALL>
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(TPB) void k_scatter(ScatterArgs a)
     __syncthreads();
 
     const int count = *a.class_count;
-    u64d c_nnz = 0;
+    u64d c_nnz = 0, c_ent = 0, c_seg = 0;
     int c_rows = 0;
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
         const int t = a.class_list[w];
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(TPB) void k_scatter(ScatterArgs a)
         // ---- the row's own entries on non-pivot columns
         for (int k = tid; k < ln; k += TPB) {
             const int2 e = a.ent[st + k];
-            if (a.qinv_r[e.x] < 0) table_add<LOGT, SMALL>(s_key, s_val, e.x, (Acc)e.y);
+            if (a.qinv_r[e.x] < 0) table_add<LOGT, SMALL>(s_key, s_val, e.x, (Acc)e.y, a.ctr);
         }
         // ---- minus multiplier * pivot row, all pivot rows of the list
         const i64d ls = a.Lstart[t];
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(TPB) void k_scatter(ScatterArgs a)
             UHdr hd; hd.off = 0; hd.npp = 0; hd.npn = 0; hd.len = 0;
             if (r < ll) {
                 le = a.Lpool[ls + r];
-                if (le.y != 0) hd = a.uhdr[le.x];
+                if (le.y != 0) { hd = a.uhdr[le.x]; c_ent += (u64d)hd.npn; c_seg += 1; }
             }
             const int nchunk = min(64, ll - c0);
             const int iters = (nchunk + NGW - 1) / NGW;
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(TPB) void k_scatter(ScatterArgs a)
                 const int nm = zp_neg(F, mult);
                 for (int k = gl; k < npn; k += G) {
                     const int2 u = a.UPN[(i64d)off + k];
-                    table_add<LOGT, SMALL>(s_key, s_val, u.x, ZpAcc<SMALL>::mul_lazy(F, nm, u.y));
+                    table_add<LOGT, SMALL>(s_key, s_val, u.x, ZpAcc<SMALL>::mul_lazy(F, nm, u.y), a.ctr);
                 }
             }
         }
@@ -574,6 +582,8 @@ __global__ __launch_bounds__(TPB) void k_scatter(ScatterArgs a)
             a.Sorig[t] = a.orig[row];
             c_nnz += (u64d)n_out;
             c_rows += n_out > 0;
+            c_ent += (u64d)ln;
+            c_seg += 1;
             s_misc[0] = 0;
             s_misc[1] = INT_MAX;
         }
@@ -582,6 +592,14 @@ __global__ __launch_bounds__(TPB) void k_scatter(ScatterArgs a)
     if (tid == 0 && (c_nnz || c_rows)) {
         atomicAdd(&a.ctr->nnz_out, c_nnz);
         atomicAdd(&a.ctr->nonempty_out, c_rows);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c_ent += __shfl_xor(c_ent, o);
+        c_seg += __shfl_xor(c_seg, o);
+    }
+    if (lane == 0 && (c_ent | c_seg)) {
+        atomicAdd(&a.ctr->class_ent[a.cls], c_ent);
+        atomicAdd(&a.ctr->class_seg[a.cls], c_seg);
     }
 }
 

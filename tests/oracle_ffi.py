@@ -43,6 +43,8 @@ def lib():
         h.orc_kernel.argtypes = [_P(LuStruct)]
         h.orc_schur_round.restype = _P(CsrStruct)
         h.orc_schur_round.argtypes = [_P(CsrStruct), _P(C.c_int64), _P(C.c_double), _P(_P(CsrStruct)), _P(C.c_int)]
+        h.orc_schur_round_range.restype = _P(CsrStruct)
+        h.orc_schur_round_range.argtypes = [_P(CsrStruct), C.c_int, C.c_int, _P(C.c_int64), _P(C.c_double), _P(_P(CsrStruct)), _P(C.c_int)]
         h.orc_num_threads.restype = C.c_int
         _lib = h
     return _lib
@@ -122,14 +124,16 @@ def transpose(A):
     return OCSR(lib().orc_transpose(A.data))
 
 
-def schur_round(A, want_U=False):
-    """One Schur round on the CPU.  Returns (S, info[, U, qinv])."""
+def schur_round(A, want_U=False, row_lo=0, row_hi=None):
+    """One Schur round on the CPU (optionally only the non-pivot rows of [row_lo,row_hi)).
+    Returns (S, info[, U, qinv])."""
     out = (C.c_int64 * 6)()
     sec = (C.c_double * 2)()
     Uptr = _P(CsrStruct)()
     qinv = np.empty(max(A.m, 1), dtype=np.int32)
-    Sp = lib().orc_schur_round(A.data, out, sec, C.byref(Uptr) if want_U else None,
-                               qinv.ctypes.data_as(_P(C.c_int)) if want_U else None)
+    Sp = lib().orc_schur_round_range(A.data, int(row_lo), int(A.n if row_hi is None else row_hi), out, sec,
+                                     C.byref(Uptr) if want_U else None,
+                                     qinv.ctypes.data_as(_P(C.c_int)) if want_U else None)
     info = dict(npiv=int(out[0]), applications=int(out[1]), nnz_reduced=int(out[2]), nnz_out=int(out[3]),
                 rows_out=int(out[4]), nnz_U=int(out[5]), sec_pivots=sec[0], sec_schur=sec[1],
                 threads=int(lib().orc_num_threads()))

@@ -1,0 +1,231 @@
+"""GPU parity tests: the HIP path, called through the C ABI (spasm_echelonize / spasm_kernel /
+spasm_transpose / the Schur plan), against the CPU oracle, the committed golden vectors and an
+independent dense elimination.  Bit-exact: integer / index work."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+P0 = GOLD["prime"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(S):
+    assert S._abi.lib().spasm_amd_device_count() > 0, "no HIP device visible: GPU tests need the MI355X"
+
+
+def julia_sparse_of_kernel(K, p):
+    D = np.zeros((K.m, K.n), dtype=np.int64)
+    for f, row in enumerate(K.rows()):
+        for c, v in row:
+            D[c, f] = v % p
+    return D
+
+
+# ---- the reference's own tests, through the C ABI -------------------------------------------------
+
+def test_construction_roundtrip(S):
+    m = np.array(GOLD["roundtrip"]["m"])
+    sm = S.CSR(m)
+    assert (S.sparse(sm).toarray() % P0 == m % P0).all()  # reference test/runtests.jl:7-10
+
+
+def test_transpose_involution(S):
+    sm = S.CSR(np.array(GOLD["roundtrip"]["m"]))
+    tt = S.transpose(S.transpose(sm))
+    assert (S.sparse(tt) != S.sparse(sm)).nnz == 0  # reference test/runtests.jl:12-15
+    t = S.transpose(sm)
+    assert t.shape == (sm.m, sm.n)
+    assert (t.todense() == sm.todense().T).all()
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: c["name"])
+def test_reference_known_answer_kernels(S, case):
+    if "m" in case:
+        sm = S.CSR(np.array(case["m"]))
+    else:
+        base = next(c for c in GOLD["cases"] if c["name"] == case["m_transposed_of"])
+        sm = S.transpose(S.CSR(np.array(base["m"])))
+    fact = S.echelonize(sm)
+    assert S.rank(fact) == case["rank"]
+    k = S.kernel(fact)
+    assert (julia_sparse_of_kernel(k, P0) == np.array(case["kernel_sparse"])).all()  # test/runtests.jl:20-23, README.md:44-47
+    # kernel rows come out in ascending free-column order with K[j] = -1 first
+    free = [j for j in range(sm.m) if fact.qinv[j] < 0]
+    assert [int(k.j[k.p[f]]) for f in range(k.n)] == free
+    assert all(int(k.x[k.p[f]]) == -1 for f in range(k.n))
+
+
+def test_one_stop_kernel_and_rank(S):
+    sm = S.CSR(np.array([[1, 2], [3, 6]]))
+    assert S.rank(sm) == 1  # reference src/SpaSM.jl:1149
+    assert (julia_sparse_of_kernel(S.kernel(sm), P0) == np.array([[3], [42012]])).all()  # :1147
+
+
+# ---- random matrices vs the oracle and vs dense elimination -------------------------------------
+
+def check_lu(S, A, fact, D, p):
+    """Invariants of the returned factorization (layout reference src/SpaSM.jl:262-270, :705-712)."""
+    U, qinv = fact.U, fact.qinv
+    r = fact.r
+    assert U.shape == (r, A.m) and len(qinv) == A.m
+    pc = {int(qinv[j]): j for j in range(A.m) if qinv[j] >= 0}
+    assert sorted(pc) == list(range(r))
+    Ud = U.todense()
+    for a in range(r):
+        assert Ud[a, pc[a]] == 1  # unit pivots
+    # U spans the row space of A: rank([A;U]) == rank(A) == r  (checked by the dense eliminator)
+    return pc
+
+
+@pytest.mark.parametrize("n,m,p,density,seed", [
+    (12, 9, 7, 0.4, 1), (30, 40, 127, 0.15, 2), (60, 45, 42013, 0.08, 3), (80, 80, 65521, 0.05, 4),
+    (50, 70, 0xFFFFFFFB, 0.1, 5), (40, 40, 3, 0.3, 6), (1, 17, 42013, 0.5, 7), (25, 1, 42013, 0.5, 8),
+    (200, 150, 65537, 0.03, 9), (150, 220, 2147483647, 0.04, 10),
+])
+def test_echelonize_kernel_vs_oracle_and_dense(S, O, n, m, p, density, seed):
+    from test_oracle_golden import random_rows
+
+    rng = np.random.default_rng(seed)
+    D = random_rows(rng, n, m, p, density, rank_deficient=True)
+    A = S.CSR(D.T.copy(), prime=p)
+    fact = S.echelonize(A)
+    K = S.kernel(fact)
+    olu = O.echelonize(A)
+    oK = O.kernel(olu)
+    assert fact.r == olu.r
+    assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()  # identical pivot columns
+    assert K.rows() == oK.rows()  # identical kernel basis, entry for entry
+    Kd, piv = O.dense_kernel_normal_form(D, p)
+    assert fact.r == len(piv) and sorted(np.nonzero(np.asarray(fact.qinv) >= 0)[0].tolist()) == piv
+    assert (K.todense() == Kd).all()
+    pc = check_lu(S, A, fact, D, p)
+    # every row of U lies in the row space of A: rank of the stacked matrix does not grow
+    stacked = np.vstack([D % p, fact.U.todense() % p])
+    R2, piv2 = O.dense_rref(stacked, p)
+    assert len(piv2) == fact.r
+
+
+def test_edge_cases(S):
+    # empty matrix, zero rows, zero columns, all-zero rows, single entry
+    for n, m in [(0, 5), (5, 0), (3, 4)]:
+        A = S.CSR.from_rows([[] for _ in range(n)], m)
+        fact = S.echelonize(A)
+        assert fact.r == 0
+        K = S.kernel(fact)
+        assert K.shape == (m, m)
+        assert K.rows() == [[(j, -1)] for j in range(m)]
+    A = S.CSR.from_rows([[(3, 5)]], 6)
+    fact = S.echelonize(A)
+    assert fact.r == 1 and fact.qinv.tolist() == [-1, -1, -1, 0, -1, -1]
+    assert fact.U.rows() == [[(3, 1)]]
+    assert S.kernel(fact).rows() == [[(j, -1)] for j in (0, 1, 2, 4, 5)]
+    # duplicate rows and a dense block
+    rows = [[(0, 1), (1, 2), (2, 3)]] * 4 + [[(c, c + 1) for c in range(8)]]
+    A = S.CSR.from_rows(rows, 8)
+    assert S.rank(A) == 2
+
+
+def test_config2_random_10k(S, O):
+    """BASELINE config 2: random 10k x 10k, density 1e-3, p = 42013: echelonize + kernel, rank bit-exact vs CPU."""
+    A = S.synth_csr(0, 10000, 10000, density=1e-3, prime=42013, seed=0x5A5A0002)
+    fact = S.echelonize(A)
+    olu = O.echelonize(A)
+    assert fact.r == olu.r
+    assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()
+    K = S.kernel(fact)
+    oK = O.kernel(olu)
+    assert K.shape == (oK.n, oK.m)
+    assert (K.p == oK.p).all()
+    # same rows up to the order of entries inside a row
+    kp, kj, kx = K.p, K.j, K.x
+    for f in range(K.n):
+        lo, hi = int(kp[f]), int(kp[f + 1])
+        got = sorted(zip(kj[lo:hi].tolist(), kx[lo:hi].tolist()))
+        lo2, hi2 = int(oK.p[f]), int(oK.p[f + 1])
+        want = sorted(zip(oK.j[lo2:hi2].tolist(), oK.x[lo2:hi2].tolist()))
+        assert got == want
+    # A * k^T == 0 for every kernel vector (checked on the sparse structure, exact integers)
+    import scipy.sparse as sp
+
+    nz = S.nnz(A)
+    As = sp.csr_matrix((A.x[:nz].astype(np.int64), A.j[:nz].astype(np.int64), A.p.astype(np.int64)), shape=A.shape)
+    nk = S.nnz(K)
+    Ks = sp.csr_matrix((K.x[:nk].astype(np.int64), K.j[:nk].astype(np.int64), K.p.astype(np.int64)), shape=K.shape)
+    prod = (As @ Ks.T).tocoo()
+    assert (prod.data % 42013 == 0).all()
+
+
+# ---- one Schur round (the benchmark's unit of work) vs the oracle -------------------------------
+
+def run_plan(S, A, lo=0, hi=None):
+    lib = S._abi.lib()
+    hi = A.n if hi is None else hi
+    plan = lib.spasm_amd_schur_plan_create(A.data, lo, hi)
+    assert plan, S._abi.last_error()
+    try:
+        assert lib.spasm_amd_schur_plan_run(plan, None) == 0, S._abi.last_error()
+        st = S._abi.RoundStats()
+        assert lib.spasm_amd_schur_plan_stats(plan, C.byref(st)) == 0, S._abi.last_error()
+        p_out = np.empty(max(A.n, 1), dtype=np.int32)
+        ptr = lib.spasm_amd_schur_plan_fetch(plan, p_out.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert ptr, S._abi.last_error()
+        Sc = S.CSR(ptr)
+        return Sc, st.as_dict(), p_out[: Sc.n]
+    finally:
+        lib.spasm_amd_schur_plan_free(plan)
+
+
+@pytest.mark.parametrize("n,k,p,seed", [(2000, 6, 65521, 21), (20000, 20, 65521, 0x5A5A0003), (5000, 12, 127, 23), (4000, 10, 2147483647, 24)])
+def test_schur_round_vs_oracle(S, O, n, k, p, seed):
+    A = S.synth_csr(1, n, n, row_nnz=k, prime=p, seed=seed)
+    Sc, st, p_out = run_plan(S, A)
+    So, info = O.schur_round(A)
+    assert st["npiv"] == info["npiv"]
+    assert st["applications"] == info["applications"]
+    assert st["nnz_reduced"] == info["nnz_reduced"]  # the unit of work, counted on both sides
+    assert st["nnz_out"] == info["nnz_out"] and st["rows_out"] == info["rows_out"]
+    assert Sc.n == So.n
+    assert np.all(np.diff(p_out) > 0)  # rows keep the input order
+    assert Sc.rows() == So.rows()
+
+
+def test_schur_round_sharded_rows(S, O):
+    """Row shards reduce independently against the same U (multi-GPU partitioning)."""
+    A = S.synth_csr(1, 6000, 6000, row_nnz=10, prime=65521, seed=31)
+    So, info = O.schur_round(A)
+    full, st, p_full = run_plan(S, A)
+    parts, origs, red = [], [], 0
+    for lo, hi in [(0, 1500), (1500, 1501), (1501, 6000)]:
+        Sc, st_s, p_out = run_plan(S, A, lo, hi)
+        parts += Sc.rows()
+        origs += p_out.tolist()
+        assert st_s["npiv"] == info["npiv"]
+        red += st_s["nnz_reduced"]
+    assert origs == p_full.tolist()
+    assert parts == full.rows() == So.rows()
+    assert red == info["nnz_reduced"]
+
+
+def test_schur_round_is_idempotent_on_rerun(S):
+    A = S.synth_csr(1, 3000, 3000, row_nnz=8, prime=65521, seed=41)
+    lib = S._abi.lib()
+    plan = lib.spasm_amd_schur_plan_create(A.data, 0, A.n)
+    assert plan
+    try:
+        outs = []
+        for _ in range(3):
+            assert lib.spasm_amd_schur_plan_run(plan, None) == 0
+            st = S._abi.RoundStats()
+            assert lib.spasm_amd_schur_plan_stats(plan, C.byref(st)) == 0
+            Sc = S.CSR(lib.spasm_amd_schur_plan_fetch(plan, None))
+            outs.append((st.nnz_reduced, st.nnz_out, Sc.rows()))
+        assert outs[0] == outs[1] == outs[2]
+    finally:
+        lib.spasm_amd_schur_plan_free(plan)
