@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspasm_amd.so")
+LIB_PATH = os.environ.get("SPASM_AMD_LIB") or os.path.join(_HERE, "libspasm_amd.so")  # env override: diagnostic builds only
 
 
 class Field(C.Structure):  # reference src/SpaSM.jl:51-56

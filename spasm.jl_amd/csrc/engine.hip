@@ -81,33 +81,40 @@ struct Scanner {
     }
 };
 
-// hash-table classes of the scatter kernel: log2(slots), threads per workgroup, largest row bound
-struct ScatterClass { int logt, tpb; i64 cap; };
-const ScatterClass kClasses[6] = {{8, 64, 160}, {10, 64, 640}, {11, 128, 1280}, {12, 256, 2560}, {13, 256, 5120}, {14, 256, 10240}};
-const int kNumHashClasses = 6;
+// hash-table classes of the scatter kernel: log2(slots), threads per row, waves per workgroup,
+// unrolled rounds of pivot rows, largest row bound (load factor <= 5/8)
+struct ScatterClass { int logt, tpr, wpb, maxr; i64 cap; };
+const ScatterClass kClasses[7] = {{8, 64, 4, 1, 160},  {9, 64, 4, 2, 320},   {10, 64, 4, 4, 640},  {11, 256, 4, 2, 1280},
+                                  {12, 256, 4, 4, 2560}, {13, 256, 4, 5, 5120}, {14, 256, 4, 5, 10240}};
+const int kNumHashClasses = 7;
 
-template <int LOGT, int TPB, bool SMALL> void launch_scatter(const ScatterArgs &a, int grid, hipStream_t s)
+inline size_t scatter_lds_bytes(const ScatterClass &c, bool small)
 {
-    typedef typename ZpAcc<SMALL>::type Acc;
-    const size_t lds = ((size_t)1 << LOGT) * (sizeof(Acc) + sizeof(int)) + 16;
+    const size_t slot = ((size_t)1 << c.logt) * (small ? 8 : 12) + 16;
+    return c.tpr == 64 ? slot * (size_t)c.wpb : slot;
+}
+
+template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL> void launch_scatter(const ScatterArgs &a, int grid, size_t lds, hipStream_t s)
+{
     static bool attr_done = false;
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_scatter<LOGT, TPB, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_scatter<LOGT, TPR, WPB, MAXR, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_scatter<LOGT, TPB, SMALL>), dim3(grid), dim3(TPB), lds, s, a);
+    hipLaunchKernelGGL((k_scatter<LOGT, TPR, WPB, MAXR, SMALL>), dim3(grid), dim3(WPB * 64), lds, s, a);
     HIPCHK(hipGetLastError());
 }
 
-template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, int grid, hipStream_t s)
+template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, int grid, size_t lds, hipStream_t s)
 {
     switch (cls) {
-    case 0: launch_scatter<8, 64, SMALL>(a, grid, s); break;
-    case 1: launch_scatter<10, 64, SMALL>(a, grid, s); break;
-    case 2: launch_scatter<11, 128, SMALL>(a, grid, s); break;
-    case 3: launch_scatter<12, 256, SMALL>(a, grid, s); break;
-    case 4: launch_scatter<13, 256, SMALL>(a, grid, s); break;
-    case 5: if (SMALL) launch_scatter<14, 256, true>(a, grid, s); break;
+    case 0: launch_scatter<8, 64, 4, 1, SMALL>(a, grid, lds, s); break;
+    case 1: launch_scatter<9, 64, 4, 2, SMALL>(a, grid, lds, s); break;
+    case 2: launch_scatter<10, 64, 4, 4, SMALL>(a, grid, lds, s); break;
+    case 3: launch_scatter<11, 256, 4, 2, SMALL>(a, grid, lds, s); break;
+    case 4: launch_scatter<12, 256, 4, 4, SMALL>(a, grid, lds, s); break;
+    case 5: launch_scatter<13, 256, 4, 5, SMALL>(a, grid, lds, s); break;
+    case 6: if (SMALL) launch_scatter<14, 256, 4, 5, true>(a, grid, lds, s); break;
     default: break;
     }
 }
@@ -131,14 +138,33 @@ struct Round {
     i64 utotal = 0;
     DevBuf<int2> Ufull, UPP, UPN;
     DevBuf<UHdr> uhdr;
+    // Uinv = (I + U_PP)^-1, one row per pivot (built once per round when the reach is short)
+    bool use_uinv = false;
+    DevMat E;                       // the unit rows e_r
+    DevBuf<int2> UinvPool;
+    DevBuf<i64d> UinvStart, ubound;
+    DevBuf<int> UinvLen;
+    DevBuf<int4> colinfo;           // per column: pivot index + location of its Uinv row
+    DevBuf<i64d> rstart;            // per processed row slot: start / length of its own entries
+    DevBuf<int> rlen;
+    i64 uinv_nnz = 0;
     // solve
-    DevBuf<int2> Lpool;
+    DevBuf<int4> Lpool;
+    DevBuf<u64d> pool_ctr;          // NPOOL sharded bump counters
+    u64d region_cap = 0;
     DevBuf<i64d> Lstart, bound, sstart;
-    DevBuf<int> Llen, overflow_list;
+    DevBuf<int> Llen, overflow_list, overflow2_list, fail_list;
+    // last-resort solve (dense vector + bitmap over the pivot indices, per workgroup)
+    int big_blocks = 0, big_npiv = -1;
+    DevBuf<int> xdense;
+    DevBuf<unsigned> bitmap;
+    DevBuf<int4> bigscratch;
     DevBuf<RoundCounters> ctr;
     RoundCounters hctr;
     // scatter
     DevBuf<int> class_count, class_list;
+    DevBuf<RowDesc> class_desc;
+    DevBuf<u64d> stamps;            // diagnostic build only
     DevMat S;
     i64 s_capacity = 0;      // entries S.ent can hold (sum of bounds at the time it was sized)
     i64 s_total_bound = 0;
@@ -253,19 +279,165 @@ struct Round {
         bound.ensure((size_t)nrows + 1);
         sstart.ensure((size_t)nrows + 1);
         overflow_list.ensure((size_t)nrows + 1);
-        Lpool.ensure((size_t)lpool_entries + 1);
+        fail_list.ensure((size_t)nrows + 1);
+        overflow2_list.ensure((size_t)nrows + 1);
+        region_cap = ((u64d)lpool_entries + NPOOL - 1) / NPOOL;
+        Lpool.ensure((size_t)(region_cap * NPOOL) + 1);
+        pool_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
+        alloc_big();
         ctr.ensure(1);
         class_count.ensure(NCLASS);
         class_list.ensure((size_t)NCLASS * (size_t)(nrows > 0 ? nrows : 1));
+        class_desc.ensure((size_t)NCLASS * (size_t)(nrows > 0 ? nrows : 1));
         S.start.ensure((size_t)nrows + 1);
         S.len.ensure((size_t)nrows + 1);
         S.lead.ensure((size_t)nrows + 1);
         S.orig.ensure((size_t)nrows + 1);
     }
 
+    void alloc_big()
+    {
+        if (big_npiv == npiv && big_blocks > 0) return;
+        // the dense fallback keeps npiv * 20 bytes per workgroup; stay under ~2 GB
+        const i64 per = std::max<i64>((i64)npiv, 1) * 20;
+        big_blocks = (int)std::max<i64>(1, std::min<i64>(64, ((i64)2 << 30) / per));
+        big_npiv = npiv;
+        const size_t nw = ((size_t)std::max(npiv, 1) + 31) / 32;
+        xdense.alloc((size_t)big_blocks * (size_t)std::max(npiv, 1));
+        bitmap.alloc((size_t)big_blocks * nw);
+        bigscratch.alloc((size_t)big_blocks * (size_t)std::max(npiv, 1));
+        xdense.zero(stream);
+        bitmap.zero(stream);
+    }
+
+    // chain solve: small teams first, then one wave per row, then the unbounded fallback
+    void launch_chain(SolveArgs a, int nrows, bool first_class)
+    {
+        if (first_class) {
+            a.retry = nullptr;
+            a.retry_count = nullptr;
+            a.overflow_list = overflow_list.p;
+            a.overflow_count = &ctr.p->solve_overflow;
+            constexpr int TEAM = 8, CAP = 128, TPB = 256;
+            hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(cdiv((i64)nrows * TEAM, TPB)), dim3(TPB), 0, stream, a);
+            HIPCHK(hipGetLastError());
+        }
+        a.retry = overflow_list.p;
+        a.retry_count = &ctr.p->solve_overflow;
+        a.overflow_list = fail_list.p;
+        a.overflow_count = &ctr.p->solve_failed;
+        {
+            constexpr int TEAM = 64, CAP = 4096, TPB = 64;
+            hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(std::min(nrows, 5 * num_cu)), dim3(TPB), 0, stream, a);
+            HIPCHK(hipGetLastError());
+        }
+        BigSolveArgs b;
+        b.s = a;
+        b.s.retry = fail_list.p;
+        b.s.retry_count = &ctr.p->solve_failed;
+        b.s.overflow_list = nullptr;
+        b.s.overflow_count = nullptr;
+        b.npiv = std::max(npiv, 1);
+        b.nwords = (std::max(npiv, 1) + 31) / 32;
+        b.xdense = xdense.p;
+        b.bitmap = bitmap.p;
+        b.scratch = bigscratch.p;
+        hipLaunchKernelGGL(k_solve_big, dim3(big_blocks), dim3(256), 0, stream, b);
+        HIPCHK(hipGetLastError());
+    }
+
+    // rows of Uinv: the chain solve applied to the unit rows e_r (once per round, after build_U)
+    void prepare_uinv()
+    {
+        use_uinv = false;
+        uinv_nnz = 0;
+        if (npiv == 0) return;
+        E.n = npiv;
+        E.m = m;
+        E.start.ensure((size_t)npiv + 1);
+        E.len.ensure((size_t)npiv + 1);
+        E.ent.ensure((size_t)npiv + 1);
+        UinvStart.ensure((size_t)npiv + 1);
+        UinvLen.ensure((size_t)npiv + 1);
+        ubound.ensure((size_t)npiv + 1);
+        overflow_list.ensure((size_t)npiv + 1);
+        fail_list.ensure((size_t)npiv + 1);
+        ctr.ensure(1);
+        alloc_big();
+        hipLaunchKernelGGL(k_unit_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, pivcol.p, E.start.p, E.len.p, E.ent.p);
+        HIPCHK(hipGetLastError());
+        i64 pool = std::max<i64>(24 * (i64)npiv, 1 << 16);
+        const i64 limit = 96 * (i64)npiv + (1 << 16); // beyond this average reach the combine would cost more than the chains
+        for (;;) {
+            const u64d ucap = ((u64d)pool + NPOOL - 1) / NPOOL;
+            UinvPool.ensure((size_t)(ucap * NPOOL) + 1);
+            pool_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
+            HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(RoundCounters), stream));
+            HIPCHK(hipMemsetAsync(pool_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
+            SolveArgs a;
+            a.nrows = npiv;
+            a.rows = nullptr;
+            a.self_idx = nullptr;
+            a.start = E.start.p;
+            a.len = E.len.p;
+            a.ent = E.ent.p;
+            a.qinv_r = qinv_r.p;
+            a.uhdr = uhdr.p;
+            a.UPP = UPP.p;
+            a.Lpool = nullptr;
+            a.Lpool2 = UinvPool.p;
+            a.lpool_cap = ucap;
+            a.pool_ctr = pool_ctr.p;
+            a.Lstart = UinvStart.p;
+            a.Llen = UinvLen.p;
+            a.bound = ubound.p;
+            a.free_cols = free_cols;
+            a.ctr = ctr.p;
+            a.F = F;
+            // only the LDS classes: a pivot whose own reach is beyond them makes Uinv too large anyway
+            a.retry = nullptr;
+            a.retry_count = nullptr;
+            a.overflow_list = overflow_list.p;
+            a.overflow_count = &ctr.p->solve_overflow;
+            {
+                constexpr int TEAM = 8, CAP = 128, TPB = 256;
+                hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(cdiv((i64)npiv * TEAM, TPB)), dim3(TPB), 0, stream, a);
+                HIPCHK(hipGetLastError());
+            }
+            a.retry = overflow_list.p;
+            a.retry_count = &ctr.p->solve_overflow;
+            a.overflow_list = nullptr;
+            a.overflow_count = &ctr.p->solve_failed;
+            {
+                constexpr int TEAM = 64, CAP = 4096, TPB = 64;
+                hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(std::min(npiv, 5 * num_cu)), dim3(TPB), 0, stream, a);
+                HIPCHK(hipGetLastError());
+            }
+            RoundCounters c;
+            HIPCHK(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, stream));
+            const u64d used = pool_used(); // synchronises
+            if (c.solve_failed) return;                       // some pivot reaches > 4096 others: chains it is
+            if (c.lpool_overflow) {
+                if (pool >= NPOOL * (limit / NPOOL + 1)) return; // Uinv too dense
+                pool = std::min<i64>(std::max<i64>(pool * 4, (i64)used + 1024), NPOOL * (limit / NPOOL + 1));
+                continue;
+            }
+            c.lpool_used = used;
+            uinv_nnz = (i64)c.lpool_used;
+            use_uinv = uinv_nnz <= limit && uinv_nnz < (i64)0x7fffffff;
+            if (use_uinv) {
+                colinfo.ensure((size_t)m + 1);
+                hipLaunchKernelGGL(k_colinfo, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, qinv_r.p, UinvStart.p, UinvLen.p, colinfo.p);
+                HIPCHK(hipGetLastError());
+            }
+            return;
+        }
+    }
+
     void run_solve(const DevMat &M, const int *rows, const int *self_idx, int nrows)
     {
         HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(RoundCounters), stream));
+        HIPCHK(hipMemsetAsync(pool_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
         HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(bound.p + nrows, 0, sizeof(i64d), stream));
         if (nrows == 0) return;
@@ -282,7 +454,9 @@ struct Round {
         a.uhdr = uhdr.p;
         a.UPP = UPP.p;
         a.Lpool = Lpool.p;
-        a.lpool_cap = (u64d)Lpool.n - 1;
+        a.Lpool2 = nullptr;
+        a.lpool_cap = region_cap;
+        a.pool_ctr = pool_ctr.p;
         a.Lstart = Lstart.p;
         a.Llen = Llen.p;
         a.bound = bound.p;
@@ -291,21 +465,66 @@ struct Round {
         a.overflow_count = &ctr.p->solve_overflow;
         a.ctr = ctr.p;
         a.F = F;
-        {
-            constexpr int TEAM = 8, CAP = 128, TPB = 256;
-            hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(cdiv((i64)nrows * TEAM, TPB)), dim3(TPB), 0, stream, a);
+        if (use_uinv) {
+            rstart.ensure((size_t)nrows + 1);
+            rlen.ensure((size_t)nrows + 1);
+            hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, rstart.p, rlen.p);
             HIPCHK(hipGetLastError());
+            CombineArgs c;
+            c.nrows = nrows;
+            c.self_idx = self_idx;
+            c.rstart = rstart.p;
+            c.rlen = rlen.p;
+            c.ent = M.ent.p;
+            c.colinfo = colinfo.p;
+            c.uhdr = uhdr.p;
+            c.UinvPool = UinvPool.p;
+            c.Lpool = Lpool.p;
+            c.lpool_cap = region_cap;
+            c.pool_ctr = pool_ctr.p;
+            c.Lstart = Lstart.p;
+            c.Llen = Llen.p;
+            c.bound = bound.p;
+            c.free_cols = free_cols;
+            c.retry = nullptr;
+            c.retry_count = nullptr;
+            c.overflow_list = overflow2_list.p;
+            c.overflow_count = &ctr.p->combine_overflow;
+            c.ctr = ctr.p;
+            c.F = F;
+            {
+                constexpr int TEAM = 16, LOGC = 8, TPB = 256; // up to 128 distinct pivots per row
+                const int grid = std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 16);
+                if (F.small) hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, true>), dim3(grid), dim3(TPB), 0, stream, c);
+                else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
+                HIPCHK(hipGetLastError());
+            }
+            c.retry = overflow2_list.p;
+            c.retry_count = &ctr.p->combine_overflow;
+            c.overflow_list = overflow_list.p;
+            c.overflow_count = &ctr.p->solve_overflow;
+            {
+                constexpr int TEAM = 64, LOGC = 12, TPB = 64; // one wave per row, up to 2048 distinct pivots
+                const int grid = std::min(nrows, num_cu * 4);
+                if (F.small) hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, true>), dim3(grid), dim3(TPB), 0, stream, c);
+                else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
+                HIPCHK(hipGetLastError());
+            }
+            launch_chain(a, nrows, false); // what is left: chain classes
+        } else {
+            launch_chain(a, nrows, true);
         }
-        // rows whose reach overflowed the small list: one wave per row, 4096-entry list
-        a.retry = overflow_list.p;
-        a.retry_count = &ctr.p->solve_overflow;
-        a.overflow_list = nullptr;
-        a.overflow_count = &ctr.p->solve_failed;
-        {
-            constexpr int TEAM = 64, CAP = 4096, TPB = 64;
-            hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(std::min(nrows, 2 * num_cu)), dim3(TPB), 0, stream, a);
-            HIPCHK(hipGetLastError());
-        }
+    }
+
+    // entries handed out by the fullest region times NPOOL (what a balanced pool would need); synchronises
+    u64d pool_used()
+    {
+        std::vector<u64d> h((size_t)NPOOL * POOL_STRIDE);
+        HIPCHK(hipMemcpyAsync(h.data(), pool_ctr.p, h.size() * sizeof(u64d), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        u64d mx = 0;
+        for (int r = 0; r < NPOOL; r++) mx = std::max(mx, h[(size_t)r * POOL_STRIDE]);
+        return mx * NPOOL;
     }
 
     // solve + bounds with automatic growth of the multiplier pool; returns the total bound of S
@@ -319,8 +538,7 @@ struct Round {
             RoundCounters c;
             HIPCHK(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, stream));
             const i64 tot = fetch_total_bound(nrows); // synchronises
-            if (c.lpool_overflow) { pool = std::max<i64>(pool * 4, (i64)c.lpool_used + 1024); continue; }
-            if (c.solve_failed) throw EngineError("a row reaches more than 4096 pivot rows of one round: beyond this build's solve classes");
+            if (c.lpool_overflow) { pool = std::max<i64>(pool * 2, (i64)(pool_used() * 5 / 4) + 1024); continue; }
             return tot;
         }
     }
@@ -356,41 +574,51 @@ struct Round {
         // classes nhash..NCLASS-2 are unused (cap -1 never matches); the last class collects what fits nowhere
         b.class_count = class_count.p;
         b.class_list = class_list.p;
-        hipLaunchKernelGGL(k_bin, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, b);
+        b.rows = rows;
+        b.start = M.start.p;
+        b.len = M.len.p;
+        b.orig = M.orig.p;
+        b.Lstart = Lstart.p;
+        b.sstart = sstart.p;
+        b.desc = class_desc.p;
+        hipLaunchKernelGGL(k_bin, dim3(cdiv(nrows, 1024)), dim3(256), 0, stream, b);
         HIPCHK(hipGetLastError());
 
         ScatterArgs a;
-        a.rows = rows;
-        a.start = M.start.p;
-        a.len = M.len.p;
-        a.orig = M.orig.p;
         a.ent = M.ent.p;
         a.qinv_r = qinv_r.p;
         a.uhdr = uhdr.p;
         a.UPN = UPN.p;
         a.Lpool = Lpool.p;
-        a.Lstart = Lstart.p;
-        a.Llen = Llen.p;
-        a.sstart = sstart.p;
         a.Sent = S.ent.p;
         a.Slen = S.len.p;
         a.Slead = S.lead.p;
         a.Sorig = S.orig.p;
         a.ctr = ctr.p;
         a.F = F;
+        {
+            const char *dbg = getenv("SPASM_DBG"); // timing ablations of the scatter kernel (wrong results when set)
+            a.dbg = dbg ? atoi(dbg) : 0;
+        }
+        a.stamps = nullptr;
+#ifdef SPASM_STAMPS
+        stamps.ensure(NCLASS * 2 * NSTAMP);
+        HIPCHK(hipMemsetAsync(stamps.p, 0, NCLASS * 2 * NSTAMP * sizeof(u64d), stream));
+        a.stamps = stamps.p;
+#endif
         nhash_used = nhash;
         for (int c = 0; c < nhash; c++) {
             HIPCHK(hipEventRecord(ev_cls[c], stream));
             a.cls = c;
             a.class_count = class_count.p + c;
-            a.class_list = class_list.p + (size_t)c * nrows;
-            const size_t slot = F.small ? 8 : 12;
-            const size_t lds = ((size_t)1 << kClasses[c].logt) * slot + 16;
-            int per_cu = (int)std::min<size_t>(32 / (kClasses[c].tpb / 64), (160 * 1024) / lds);
+            a.desc = class_desc.p + (size_t)c * nrows;
+            const size_t lds = scatter_lds_bytes(kClasses[c], F.small);
+            int per_cu = (int)std::min<size_t>(32 / kClasses[c].wpb, (160 * 1024) / lds);
             if (per_cu < 1) per_cu = 1;
-            const int grid = std::min(nrows, num_cu * per_cu);
-            if (F.small) launch_scatter_class<true>(c, a, grid, stream);
-            else launch_scatter_class<false>(c, a, grid, stream);
+            const int rows_per_block = kClasses[c].tpr == 64 ? kClasses[c].wpb : 1;
+            const int grid = std::max(1, std::min(cdiv(nrows, rows_per_block), num_cu * per_cu));
+            if (F.small) launch_scatter_class<true>(c, a, grid, lds, stream);
+            else launch_scatter_class<false>(c, a, grid, lds, stream);
         }
         HIPCHK(hipEventRecord(ev_cls[nhash], stream));
         hipLaunchKernelGGL(k_scatter_mark_failed, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, Llen.p, S.len.p, S.lead.p);
@@ -405,8 +633,21 @@ struct Round {
         int *cc = hclass_count;
         HIPCHK(hipMemcpyAsync(cc, class_count.p, NCLASS * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+#ifdef SPASM_STAMPS
+        {
+            std::vector<u64d> h(NCLASS * 2 * NSTAMP);
+            HIPCHK(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(u64d), hipMemcpyDeviceToHost));
+            static const char *names[NSTAMP] = {"prologue", "issue", "wait-loads", "own", "rounds", "remainder", "sweep", "-"};
+            for (int c = 0; c < NCLASS; c++) {
+                const double waves = (double)h[(size_t)c * 2 * NSTAMP + NSTAMP];
+                if (waves == 0) continue;
+                fprintf(stderr, "[stamps] class %d rows %d waves %.0f: cycles per wave:", c, cc[c], waves);
+                for (int i = 0; i < 7; i++) fprintf(stderr, " %s=%.0f", names[i], (double)h[(size_t)c * 2 * NSTAMP + i] / waves);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         if (hctr.lpool_overflow) throw EngineError("multiplier pool exhausted");
-        if (hctr.solve_failed) throw EngineError("a row reaches more than 4096 pivot rows of one round: beyond this build's solve classes");
         if (hctr.scatter_overflow) throw EngineError("a hash table of the scatter kernel filled up (internal bound violated)");
         if (cc[NCLASS - 1] > 0) throw EngineError("a Schur row needs more than the largest LDS hash table: beyond this build's scatter classes");
     }
@@ -558,6 +799,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         if (R->npiv == 0) break; // no non-empty row left
         R->mark_local(*cur, 0);
         R->build_U(*cur, R->pivrow.p);
+        R->prepare_uinv();
         HIPCHK(hipEventRecord(R->ev[1], stream));
         const int nnp = R->nnp;
         const i64 tot = R->solve_phase(*cur, R->np_rows.p, nullptr, nnp, 4 * cur_nnz);
@@ -801,6 +1043,7 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact)
         HIPCHK(hipGetLastError());
     }
     R->build_U(PM, rowsrc.p);
+    R->prepare_uinv();
     const i64 tot = R->solve_phase(PM, rowsrc.p, iota.p, r, 4 * spasm_nnz(U));
     R->S.ent.ensure((size_t)tot + 1);
     R->run_scatter(PM, rowsrc.p, r);
@@ -851,6 +1094,7 @@ spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi)
     R.assign_pivots();
     R.mark_local(P->A, 0, lo, hi);
     R.build_U(P->A, R.pivrow.p);
+    R.prepare_uinv();
     HIPCHK(hipEventRecord(R.ev[1], s));
     // dry run of the solve sizes the multiplier pool and the Schur slots once
     const i64 tot = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, 4 * spasm_nnz(A));

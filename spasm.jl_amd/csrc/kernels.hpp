@@ -39,11 +39,17 @@ struct __attribute__((aligned(16))) UHdr {
     int len;
 };
 
+// The multiplier pool is cut into NPOOL regions with one bump counter each (own cache line): a single
+// counter would serialise ~10^6 returning atomics per round (~4 ns each on one address).
+#define NPOOL 1024
+#define POOL_STRIDE 16   // u64 words between two counters (128 bytes)
+
 struct RoundCounters {
     u64d applications;   // (row, pivot row) eliminations with nonzero multiplier
     u64d nnz_reduced;    // reference scatter trip count: sum nnz(A_i) + sum nnz(U_r) over applications
     u64d segments;       // row segments visited (1 per row + 1 per application)
-    u64d lpool_used;     // entries of the multiplier pool handed out
+    u64d lpool_used;     // (unsharded users only) entries of the pool handed out
+    int combine_overflow;// rows with more distinct pivots than the first combine class accepts
     int solve_overflow;  // rows whose reach did not fit the LDS list of the first solve class
     int solve_failed;    // rows whose reach did not fit the largest solve class
     int lpool_overflow;  // multiplier pool exhausted
@@ -54,12 +60,44 @@ struct RoundCounters {
     u64d class_seg[8];   // scatter kernel, per class: row segments visited
 };
 
+// bump allocation of n entries from the region of this workgroup; returns the absolute offset in the pool,
+// or ~0 when the region is full (the host then grows the pool and reruns)
+__device__ __forceinline__ u64d pool_alloc(u64d *counters, u64d region_cap, u64d n)
+{
+    const unsigned region = blockIdx.x % NPOOL;
+    const u64d pos = atomicAdd(&counters[(size_t)region * POOL_STRIDE], n);
+    if (pos + n > region_cap) return ~0ull;
+    return (u64d)region * region_cap + pos;
+}
+
 template <int TEAM> __device__ __forceinline__ u64d team_ballot(bool pred)
 {
     u64d b = __ballot(pred);
     if (TEAM == 64) return b;
     const int base = (threadIdx.x & 63) & ~(TEAM - 1);
     return (b >> base) & ((1ull << (TEAM & 63)) - 1ull);
+}
+
+// workgroup barrier that orders LDS traffic only: outstanding global loads / stores stay in flight
+// (__syncthreads() would drain them: s_waitcnt vmcnt(0) before every s_barrier)
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// min over the 64 lanes without touching LDS (ds_bpermute shuffles cost an LDS round trip each):
+// DPP row shifts inside the 16-lane rows, then the row_bcast steps of the GFX9 reduction idiom
+__device__ __forceinline__ int wave_min_i32(int x)
+{
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x111, 0xf, 0xf, false)); // row_shr:1
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x112, 0xf, 0xf, false)); // row_shr:2
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x114, 0xf, 0xf, false)); // row_shr:4
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x118, 0xf, 0xf, false)); // row_shr:8
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1,3
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2,3
+    return __builtin_amdgcn_readlane(x, 63);
 }
 
 __device__ __forceinline__ u64d lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
@@ -244,8 +282,10 @@ struct SolveArgs {
     const int *qinv_r;
     const UHdr *uhdr;
     const int2 *UPP;
-    int2 *Lpool;
-    u64d lpool_cap;
+    int4 *Lpool;               // multiplier records {pivot index, multiplier, offset of the pivot row in UPN, npn}
+    int2 *Lpool2;              // when non-NULL the list is published as {pivot index, value} instead (rows of Uinv)
+    u64d lpool_cap;            // entries per pool region
+    u64d *pool_ctr;            // NPOOL bump counters, POOL_STRIDE words apart
     i64d *Lstart;
     int *Llen;
     i64d *bound;
@@ -375,12 +415,21 @@ __global__ __launch_bounds__(TPB) void k_solve(SolveArgs a)
         } else {
             // ---- publish the multipliers
             u64d base = 0;
-            if (tl == 0) base = atomicAdd(&a.ctr->lpool_used, (u64d)cnt);
+            if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)cnt);
             base = __shfl(base, 0, TEAM);
-            if (base + (u64d)cnt > a.lpool_cap) {
+            if (base == ~0ull) {
                 if (tl == 0) { atomicAdd(&a.ctr->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
             } else {
-                for (int i = tl; i < cnt; i += TEAM) a.Lpool[base + i] = make_int2(key[i], val[i]);
+                if (a.Lpool2) {
+                    for (int i = tl; i < cnt; i += TEAM) a.Lpool2[base + i] = make_int2(key[i], val[i]);
+                } else {
+                    for (int i = tl; i < cnt; i += TEAM) {
+                        const int kk = key[i], vv = val[i];
+                        UHdr h; h.off = 0; h.npn = 0;
+                        if (vv != 0) h = a.uhdr[kk];
+                        a.Lpool[base + i] = make_int4(kk, vv, (int)h.off, h.npn);
+                    }
+                }
                 if (tl == 0) {
                     a.Lstart[t] = (i64d)base;
                     a.Llen[t] = cnt;
@@ -407,32 +456,103 @@ __global__ __launch_bounds__(TPB) void k_solve(SolveArgs a)
 // binning of rows by the size of the hash table their Schur row needs
 // ------------------------------------------------------------------------------------------------
 #define NCLASS 8
+// everything the scatter kernel needs to know about one row, gathered once by the binning pass so that the
+// kernel's per-row dependent-load chain is: descriptor (prefetched) -> multiplier records -> pivot row entries
+struct __attribute__((aligned(16))) RowDesc {
+    i64d ent_start;   // the row's own entries
+    i64d l_start;     // its multiplier records
+    i64d s_start;     // slot of its Schur row
+    int len;
+    int llen;
+    int t;            // row slot (index of the Schur row)
+    int orig;
+};
+
+// A descriptor fetched with VECTOR loads (every lane reads the same 48 bytes): a scalar load would sit on
+// lgkmcnt, and every LDS wait of the kernel is lgkmcnt(0) -- the prefetch would be waited for at once.
+struct DescRegs { int4 a, b, c; };
+__device__ __forceinline__ DescRegs desc_load(const RowDesc *p)
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z)); // opaque zero: keeps the address in a VGPR
+    const int4 *q = (const int4 *)((const char *)p + z);
+    DescRegs r;
+    r.a = q[0];
+    r.b = q[1];
+    r.c = q[2];
+    return r;
+}
+__device__ __forceinline__ RowDesc desc_unpack(const DescRegs &r)
+{
+    RowDesc d;
+    d.ent_start = (i64d)(((u64d)(unsigned)__builtin_amdgcn_readfirstlane(r.a.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(r.a.x));
+    d.l_start = (i64d)(((u64d)(unsigned)__builtin_amdgcn_readfirstlane(r.a.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(r.a.z));
+    d.s_start = (i64d)(((u64d)(unsigned)__builtin_amdgcn_readfirstlane(r.b.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(r.b.x));
+    d.len = __builtin_amdgcn_readfirstlane(r.b.z);
+    d.llen = __builtin_amdgcn_readfirstlane(r.b.w);
+    d.t = __builtin_amdgcn_readfirstlane(r.c.x);
+    d.orig = __builtin_amdgcn_readfirstlane(r.c.y);
+    return d;
+}
+
 struct BinArgs {
     int nrows;
     const i64d *bound;
     const int *Llen;
+    const int *rows;         // local row of each slot (NULL: identity)
+    const i64d *start;
+    const int *len;
+    const int *orig;
+    const i64d *Lstart;
+    const i64d *sstart;
+    RowDesc *desc;           // [NCLASS][nrows]
     i64d cap[NCLASS];        // class c takes rows with bound <= cap[c]; the last class takes the rest
     int *class_count;        // [NCLASS]
     int *class_list;         // [NCLASS][nrows]
 };
 
-__global__ void k_bin(BinArgs a)
+__global__ __launch_bounds__(256) void k_bin(BinArgs a)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int cls = -1;
-    if (t < a.nrows && a.Llen[t] >= 0) {
-        const i64d b = a.bound[t];
-        cls = NCLASS - 1;
-        for (int c = NCLASS - 2; c >= 0; c--) if (b <= a.cap[c]) cls = c;
+    constexpr int PER = 4; // rows per thread
+    __shared__ int s_cnt[NCLASS];
+    __shared__ int s_base[NCLASS];
+    if (threadIdx.x < NCLASS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int cls[PER], pos[PER];
+    const int base = blockIdx.x * (256 * PER);
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int t = base + i * 256 + threadIdx.x;
+        cls[i] = -1;
+        pos[i] = 0;
+        if (t < a.nrows && a.Llen[t] >= 0) {
+            const i64d b = a.bound[t];
+            int c = NCLASS - 1;
+            for (int k = NCLASS - 2; k >= 0; k--) if (b <= a.cap[k]) c = k;
+            cls[i] = c;
+            pos[i] = atomicAdd(&s_cnt[c], 1);
+        }
     }
-    for (int c = 0; c < NCLASS; c++) {
-        const u64d m = __ballot(cls == c);
-        if (m == 0) continue;
-        int base = 0;
-        if ((threadIdx.x & 63) == (__ffsll((long long)m) - 1)) base = atomicAdd(&a.class_count[c], __popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (cls == c) a.class_list[(size_t)c * a.nrows + base + __popcll(m & lanemask_lt())] = t;
-    }
+    __syncthreads();
+    if (threadIdx.x < NCLASS && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&a.class_count[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (cls[i] >= 0) {
+            const int t = base + i * 256 + threadIdx.x;
+            const size_t slot = (size_t)cls[i] * a.nrows + s_base[cls[i]] + pos[i];
+            a.class_list[slot] = t;
+            const int row = a.rows ? a.rows[t] : t;
+            RowDesc d;
+            d.ent_start = a.start[row];
+            d.l_start = a.Lstart[t];
+            d.s_start = a.sstart[t];
+            d.len = a.len[row];
+            d.llen = a.Llen[t];
+            d.t = t;
+            d.orig = a.orig[row];
+            a.desc[slot] = d;
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -444,162 +564,369 @@ __global__ void k_bin(BinArgs a)
 // ------------------------------------------------------------------------------------------------
 struct ScatterArgs {
     const int *class_count;    // rows in this class
-    const int *class_list;     // row slots of this class
-    const int *rows;           // local row of each slot (NULL: identity)
-    const i64d *start;
-    const int *len;
-    const int *orig;
+    const RowDesc *desc;       // their descriptors
     const int2 *ent;
     const int *qinv_r;
     const UHdr *uhdr;
     const int2 *UPN;
-    const int2 *Lpool;
-    const i64d *Lstart;
-    const int *Llen;
-    const i64d *sstart;        // slot of each Schur row in Sent
+    const int4 *Lpool;
     int2 *Sent;
     int *Slen;
     int *Slead;
     int *Sorig;
     RoundCounters *ctr;
     int cls;                   // index of this size class (for the per-class counters)
+    u64d *stamps;              // diagnostic build only: [class][NSTAMP] cycle sums + [class][NSTAMP] wave counts
+    int dbg;                   // TIMING ABLATIONS ONLY (env SPASM_DBG, results are wrong when non-zero):
+                               // 1 = no Schur stores, 2 = no accumulation of pivot rows, 4 = sweep only resets, 8 = no pivot-row loads
     ZpField F;
 };
 
-template <int LOGT, bool SMALL>
-__device__ __forceinline__ void table_add(int *s_key, typename ZpAcc<SMALL>::type *s_val, int c, typename ZpAcc<SMALL>::type a,
-                                          RoundCounters *ctr)
+// ------------------------------------------------------------------------------------------------
+// LDS hash table of one Schur row: open addressing with double hashing (the probe step is odd, so
+// it visits every slot of the power-of-two table).  Small primes: one 8-byte slot {column, i32
+// accumulator} (64-bit LDS reads / resets in the sweep); large primes: column array + i64 array.
+// ------------------------------------------------------------------------------------------------
+template <int LOGT, bool SMALL> struct RowTable;
+
+template <int LOGT> struct RowTable<LOGT, true> {
+    static constexpr int T = 1 << LOGT;
+    static constexpr size_t BYTES = (size_t)T * 8;
+    int2 *t;
+    __device__ __forceinline__ void bind(unsigned char *base) { t = (int2 *)base; }
+    __device__ __forceinline__ int *keyp(unsigned h) { return &t[h].x; }
+    __device__ __forceinline__ void add(unsigned h, int v) { atomicAdd(&t[h].y, v); }
+    __device__ __forceinline__ void clear(int s) { t[s] = make_int2(EMPTY_KEY, 0); }
+    __device__ __forceinline__ void read(int s, int &key, int &acc) { const int2 e = t[s]; key = e.x; acc = e.y; }
+};
+
+template <int LOGT> struct RowTable<LOGT, false> {
+    static constexpr int T = 1 << LOGT;
+    static constexpr size_t BYTES = (size_t)T * 12;
+    long long *val;
+    int *key;
+    __device__ __forceinline__ void bind(unsigned char *base) { val = (long long *)base; key = (int *)(base + (size_t)T * 8); }
+    __device__ __forceinline__ int *keyp(unsigned h) { return &key[h]; }
+    __device__ __forceinline__ void add(unsigned h, long long v) { atomicAdd((u64d *)&val[h], (u64d)v); }
+    __device__ __forceinline__ void clear(int s) { key[s] = EMPTY_KEY; val[s] = 0; }
+    __device__ __forceinline__ void read(int s, int &k, long long &acc) { k = key[s]; acc = val[s]; }
+};
+
+template <int LOGT> __device__ __forceinline__ void hash2(int c, unsigned &h, unsigned &step)
 {
-    constexpr unsigned T = 1u << LOGT;
-    unsigned h = ((unsigned)c * 0x9E3779B1u) >> (32 - LOGT);
-    // linear probing; the class caps keep the load <= 5/8, the probe bound only guards against a full table
-    for (unsigned probes = 0; probes < T; probes++) {
-        const int k = atomicCAS(&s_key[h], EMPTY_KEY, c);
-        if (k == EMPTY_KEY || k == c) {
-            if (SMALL) atomicAdd((int *)&s_val[h], (int)a);
-            else atomicAdd((u64d *)&s_val[h], (u64d)a);
-            return;
-        }
-        h = (h + 1) & (T - 1);
-    }
-    atomicAdd(&ctr->scatter_overflow, 1);
+    const unsigned x = (unsigned)c * 0x9E3779B1u;
+    h = x >> (32 - LOGT);
+    step = ((x >> 7) & ((1u << LOGT) - 1)) | 1u;
 }
 
-template <int LOGT, int TPB, bool SMALL>
-__global__ __launch_bounds__(TPB) void k_scatter(ScatterArgs a)
+// N entries of a lane inserted together: all pending CAS of a round are in flight at once, so the lane
+// pays about max(probe length) LDS round trips instead of their sum
+template <int LOGT, int N, bool SMALL>
+__device__ __forceinline__ void table_add_n(RowTable<LOGT, SMALL> &tab, const int (&c)[N], const typename ZpAcc<SMALL>::type (&v)[N],
+                                            unsigned valid, RoundCounters *ctr)
+{
+    constexpr unsigned T = 1u << LOGT;
+    unsigned h[N], st[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) hash2<LOGT>(c[j], h[j], st[j]);
+    unsigned pending = valid;
+    for (unsigned round = 0; pending != 0 && round < T; round++) {
+        int k[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            k[j] = 0;
+            if (pending & (1u << j)) k[j] = atomicCAS(tab.keyp(h[j]), EMPTY_KEY, c[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (pending & (1u << j)) {
+                if (k[j] == EMPTY_KEY || k[j] == c[j]) {
+                    tab.add(h[j], v[j]);
+                    pending &= ~(1u << j);
+                } else {
+                    h[j] = (h[j] + st[j]) & (T - 1);
+                }
+            }
+        }
+    }
+    if (pending) atomicAdd(&ctr->scatter_overflow, 1);
+}
+
+template <int LOGT, bool SMALL>
+__device__ __forceinline__ void table_add(RowTable<LOGT, SMALL> &tab, int c, typename ZpAcc<SMALL>::type v, RoundCounters *ctr)
+{
+    const int cc[1] = {c};
+    const typename ZpAcc<SMALL>::type vv[1] = {v};
+    table_add_n<LOGT, 1, SMALL>(tab, cc, vv, 1u, ctr);
+}
+
+// final reduction of a lazy accumulator to the balanced residue
+template <bool SMALL> __device__ __forceinline__ int acc_reduce(const ZpField &F, typename ZpAcc<SMALL>::type acc);
+template <> __device__ __forceinline__ int acc_reduce<true>(const ZpField &F, int acc)
+{
+    // |acc| < 2^31 and p < 2^16: the float quotient is within 1 of the exact one, two corrections finish
+    const int p = (int)F.p, hp = (int)F.halfp, mhp = (int)F.mhalfp;
+    int r = acc - __float2int_rn((float)acc * F.finvp) * p;
+    if (r > hp) r -= p; else if (r < mhp) r += p;
+    if (r > hp) r -= p; else if (r < mhp) r += p;
+    return r;
+}
+template <> __device__ __forceinline__ int acc_reduce<false>(const ZpField &F, long long acc) { return zp_reduce(F, acc); }
+
+// Diagnostic build only (-DSPASM_STAMPS): per-phase cycle sums of the scatter kernel, written to a buffer of
+// their own (ScatterArgs::stamps) that nothing else reads.  Never compiled into the shipped library.
+#ifdef SPASM_STAMPS
+#define NSTAMP 8
+__device__ __forceinline__ u64d stamp_now()
+{
+    u64d t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(i) do { const u64d _n = stamp_now(); st_sum[i] += _n - st_last; st_last = _n; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// TPR = threads cooperating on one row: 64 (a wave per row, WPB independent rows per workgroup, no
+//       barriers) or WPB*64 (the whole workgroup on one row, LDS-only barriers).
+// MAXR = rounds of pivot rows whose loads are all issued before any accumulation (registers);
+//       round r hands pivot row gg + r*NG of the row's multiplier list to the 8-lane group gg.
+// Software pipeline across the rows of a team: descriptor two rows ahead, multiplier records and own
+// entries one row ahead (issued before the sweep), so a row exposes one global-load latency.
+template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL>
+__global__ __launch_bounds__(WPB * 64) void k_scatter(ScatterArgs a)
 {
     typedef typename ZpAcc<SMALL>::type Acc;
+    typedef RowTable<LOGT, SMALL> Tab;
+    constexpr bool WAVE_ROW = (TPR == 64);
+    static_assert(WAVE_ROW || TPR == WPB * 64, "a row is owned by one wave or by the whole workgroup");
     constexpr int T = 1 << LOGT;
-    constexpr int G = 16;          // lanes streaming one pivot row
-    constexpr int NGW = 64 / G;    // groups per wave
-    constexpr int NW = TPB / 64;
+    constexpr int G = 8;            // lanes streaming one pivot row: 64 contiguous bytes per step
+    constexpr int NG = TPR / G;     // pivot rows per round
+    constexpr size_t SLOT = Tab::BYTES + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    Acc *s_val = (Acc *)s_raw;
-    int *s_key = (int *)(s_raw + sizeof(Acc) * T);
-    int *s_misc = s_key + T;       // [0] = entries written, [1] = leftmost column
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int g = lane / G, gl = lane % G;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: row descriptors then live in SGPRs
+    const int rtid = WAVE_ROW ? lane : tid;             // thread index inside the row team
+    unsigned char *base = s_raw + (WAVE_ROW ? (size_t)wave * SLOT : 0);
+    Tab tab;
+    tab.bind(base);
+    int *s_misc = (int *)(base + Tab::BYTES);           // block-per-row only: [0] = entries written, [1] = leftmost column
+    const int gg = rtid / G, gl = rtid % G;
     const ZpField F = a.F;
 
-    for (int s = tid; s < T; s += TPB) { s_key[s] = EMPTY_KEY; s_val[s] = 0; }
-    if (tid == 0) { s_misc[0] = 0; s_misc[1] = INT_MAX; }
+    for (int s = rtid; s < T; s += TPR) tab.clear(s);
+    if (rtid == 0) { s_misc[0] = 0; s_misc[1] = INT_MAX; }
     __syncthreads();
 
     const int count = *a.class_count;
+    const int first = WAVE_ROW ? (int)blockIdx.x * WPB + wave : (int)blockIdx.x;
+    const int stride = WAVE_ROW ? (int)gridDim.x * WPB : (int)gridDim.x;
     u64d c_nnz = 0, c_ent = 0, c_seg = 0;
     int c_rows = 0;
-    for (int w = blockIdx.x; w < count; w += gridDim.x) {
-        const int t = a.class_list[w];
-        const int row = a.rows ? a.rows[t] : t;
-        const i64d st = a.start[row];
-        const int ln = a.len[row];
-        // ---- the row's own entries on non-pivot columns
-        for (int k = tid; k < ln; k += TPB) {
-            const int2 e = a.ent[st + k];
-            if (a.qinv_r[e.x] < 0) table_add<LOGT, SMALL>(s_key, s_val, e.x, (Acc)e.y, a.ctr);
-        }
-        // ---- minus multiplier * pivot row, all pivot rows of the list
-        const i64d ls = a.Lstart[t];
-        const int ll = a.Llen[t];
-        for (int c0 = wave * 64; c0 < ll; c0 += NW * 64) {
-            const int r = c0 + lane;
-            int2 le = make_int2(0, 0);
-            UHdr hd; hd.off = 0; hd.npp = 0; hd.npn = 0; hd.len = 0;
-            if (r < ll) {
-                le = a.Lpool[ls + r];
-                if (le.y != 0) { hd = a.uhdr[le.x]; c_ent += (u64d)hd.npn; c_seg += 1; }
+
+#ifdef SPASM_STAMPS
+    u64d st_sum[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64d st_last = stamp_now();
+#endif
+    // ---- pipeline registers
+    RowDesc d, dn;
+    d.ent_start = d.l_start = d.s_start = 0; d.len = d.llen = d.t = d.orig = 0;
+    dn = d;
+    int2 own = make_int2(0, 0);
+    int4 rec[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) rec[r] = make_int4(0, 0, 0, 0);
+    if (first < count) {
+        d = desc_unpack(desc_load(&a.desc[first]));
+        if (rtid < d.len) own = a.ent[d.ent_start + rtid];
+#pragma unroll
+        for (int r = 0; r < MAXR; r++)
+            if (gg + r * NG < d.llen) rec[r] = a.Lpool[d.l_start + gg + r * NG];
+    }
+    if (first + stride < count) dn = desc_unpack(desc_load(&a.desc[first + stride]));
+
+    STAMP(0); // prologue
+    for (int w = first; w < count; w += stride) {
+        // (A) prefetch the descriptor two rows ahead (vector load; unpacked to SGPRs at the end of the iteration)
+        DescRegs dnn_regs;
+        const bool has_nn = w + 2 * stride < count;
+        if (has_nn) dnn_regs = desc_load(&a.desc[w + 2 * stride]);
+        // (B) every load of the current row: qinv of the own entry, entries of the pivot rows
+        const int ln = d.len, ll = d.llen;
+        int q_own = 0;
+        if (rtid < ln) q_own = a.qinv_r[own.x];
+        int2 u[MAXR][3];
+        int npn[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) {
+            npn[r] = (gg + r * NG < ll && rec[r].y != 0) ? rec[r].w : 0;
+            const int2 *up = a.UPN + (unsigned)rec[r].z;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                u[r][j] = make_int2(0, 0);
+                if (gl + j * G < npn[r] && !(a.dbg & 8)) u[r][j] = up[gl + j * G];
             }
-            const int nchunk = min(64, ll - c0);
-            const int iters = (nchunk + NGW - 1) / NGW;
-            for (int it = 0; it < iters; it++) {
-                const int e = it * NGW + g;
-                const int src = e < nchunk ? e : 0;
-                const int mult = __shfl(le.y, src);
-                const unsigned off = (unsigned)__shfl((int)hd.off, src);
-                int npn = __shfl(hd.npn, src);
-                if (e >= nchunk || mult == 0) npn = 0;
-                const int nm = zp_neg(F, mult);
-                for (int k = gl; k < npn; k += G) {
-                    const int2 u = a.UPN[(i64d)off + k];
-                    table_add<LOGT, SMALL>(s_key, s_val, u.x, ZpAcc<SMALL>::mul_lazy(F, nm, u.y), a.ctr);
+        }
+#ifdef SPASM_STAMPS
+        STAMP(1); // issue of the row's loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(2); // waiting for them
+#endif
+        // (C) accumulate: the own entry, then per round the (up to) 3 entries of this lane as one batch
+        if (rtid < ln && q_own < 0) table_add<LOGT, SMALL>(tab, own.x, (Acc)own.y, a.ctr);
+        STAMP(3); // own entries
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) {
+            if (npn[r] > 0) {
+                if (gl == 0) { c_ent += (u64d)npn[r]; c_seg += 1; }
+                const int nm = zp_neg(F, rec[r].y);
+                int bc[3];
+                Acc bv[3];
+                unsigned valid = 0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    bc[j] = u[r][j].x;
+                    bv[j] = ZpAcc<SMALL>::mul_lazy(F, nm, u[r][j].y);
+                    if (gl + j * G < npn[r]) valid |= 1u << j;
+                }
+                if (a.dbg & 2) asm volatile("" ::"v"(bc[0]), "v"(bv[0]));
+                else table_add_n<LOGT, 3, SMALL>(tab, bc, bv, valid, a.ctr);
+                const int2 *up = a.UPN + (unsigned)rec[r].z;
+                for (int k = gl + 3 * G; k < npn[r]; k += G) { // pivot rows longer than 24 entries
+                    const int2 uu = up[k];
+                    table_add<LOGT, SMALL>(tab, uu.x, ZpAcc<SMALL>::mul_lazy(F, nm, uu.y), a.ctr);
                 }
             }
         }
-        __syncthreads();
-        // ---- sweep: reduce, compact, write; reset the table on the way
-        const i64d ss = a.sstart[t];
+        STAMP(4); // unrolled rounds of pivot rows
+        // (D) what the unrolled part did not cover: more pivot rows than NG*MAXR, own rows longer than TPR
+        for (int e = gg + MAXR * NG; e < ll; e += NG) {
+            const int4 le = a.Lpool[d.l_start + e];
+            if (le.y == 0) continue;
+            if (gl == 0) { c_ent += (u64d)le.w; c_seg += 1; }
+            const int nm = zp_neg(F, le.y);
+            const int2 *up = a.UPN + (unsigned)le.z;
+            for (int k = gl; k < le.w; k += 3 * G) {
+                int bc[3];
+                Acc bv[3];
+                unsigned valid = 0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    int2 uu = make_int2(0, 0);
+                    if (k + j * G < le.w) { uu = up[k + j * G]; valid |= 1u << j; }
+                    bc[j] = uu.x;
+                    bv[j] = ZpAcc<SMALL>::mul_lazy(F, nm, uu.y);
+                }
+                table_add_n<LOGT, 3, SMALL>(tab, bc, bv, valid, a.ctr);
+            }
+        }
+        for (int k = rtid + TPR; k < ln; k += TPR) {
+            const int2 e = a.ent[d.ent_start + k];
+            if (a.qinv_r[e.x] < 0) table_add<LOGT, SMALL>(tab, e.x, (Acc)e.y, a.ctr);
+        }
+        STAMP(5); // remainder loops
+        // (A') stage-1 data of the NEXT row (its own entries and multiplier records) straight into the pipeline
+        // registers, which are dead from here on: these loads fly during the sweep
+        const int ln_cur = ln;
+        own = make_int2(0, 0);
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) rec[r] = make_int4(0, 0, 0, 0);
+        if (w + stride < count) {
+            if (rtid < dn.len) own = a.ent[dn.ent_start + rtid];
+#pragma unroll
+            for (int r = 0; r < MAXR; r++)
+                if (gg + r * NG < dn.llen) rec[r] = a.Lpool[dn.l_start + gg + r * NG];
+        }
+        if (WAVE_ROW) __builtin_amdgcn_wave_barrier(); else lds_barrier();
+        // (E) sweep: reduce, compact, write; reset the table on the way.  U slot groups are read (64-bit) and
+        // cleared up front, the rest is branch-free: an empty slot holds accumulator 0, hence reduces to 0.
+        const i64d ss = d.s_start;
         int mylead = INT_MAX;
-        for (int s0 = 0; s0 < T; s0 += TPB) {
-            const int s = s0 + tid;
-            const int c = s_key[s];
-            int v = 0;
-            if (c != EMPTY_KEY) {
-                v = zp_reduce(F, (int64_t)s_val[s]);
-                s_key[s] = EMPTY_KEY;
-                s_val[s] = 0;
+        int wbase = 0; // wave-per-row: running count of entries written
+        constexpr int NIT = T / TPR;
+        constexpr int U = NIT >= 4 ? 4 : NIT;
+        for (int it0 = 0; it0 < NIT; it0 += U) {
+            int cc[U];
+            Acc aa[U];
+#pragma unroll
+            for (int q = 0; q < U; q++) tab.read((it0 + q) * TPR + rtid, cc[q], aa[q]);
+#pragma unroll
+            for (int q = 0; q < U; q++) tab.clear((it0 + q) * TPR + rtid);
+            int vv[U];
+            u64d mm[U];
+            int tot = 0;
+#pragma unroll
+            for (int q = 0; q < U; q++) {
+                vv[q] = acc_reduce<SMALL>(F, aa[q]);
+                mm[q] = __ballot(vv[q] != 0 && !(a.dbg & 4));
+                tot += __popcll(mm[q]);
             }
-            const bool nz = v != 0;
-            const u64d m = __ballot(nz);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_misc[0], __popcll(m));
-                base = __shfl(base, 0);
-                if (nz) {
-                    a.Sent[ss + base + __popcll(m & lanemask_lt())] = make_int2(c, v);
-                    mylead = min(mylead, c);
+            if (tot == 0) continue;
+            int pos = wbase;
+            if (!WAVE_ROW) { // one reservation per U slot groups and wave
+                if (lane == 0) pos = atomicAdd(&s_misc[0], tot);
+                pos = __builtin_amdgcn_readfirstlane(pos);
+            }
+#pragma unroll
+            for (int q = 0; q < U; q++) {
+                if (vv[q] != 0 && !(a.dbg & 4)) {
+                    if (!(a.dbg & 1)) a.Sent[ss + pos + __popcll(mm[q] & lanemask_lt())] = make_int2(cc[q], vv[q]);
+                    mylead = min(mylead, cc[q]);
                 }
+                pos += __popcll(mm[q]);
             }
+            wbase += tot;
         }
-        for (int o = 32; o > 0; o >>= 1) mylead = min(mylead, __shfl_xor(mylead, o));
-        if (lane == 0 && mylead != INT_MAX) atomicMin(&s_misc[1], mylead);
-        __syncthreads();
-        if (tid == 0) {
-            const int n_out = s_misc[0];
-            a.Slen[t] = n_out;
-            a.Slead[t] = s_misc[1];
-            a.Sorig[t] = a.orig[row];
+        mylead = wave_min_i32(mylead);
+        int n_out = wbase, lead_out = mylead;
+        if (!WAVE_ROW) {
+            if (lane == 0 && mylead != INT_MAX) atomicMin(&s_misc[1], mylead);
+            lds_barrier();
+            n_out = s_misc[0];
+            lead_out = s_misc[1];
+            lds_barrier();
+        }
+        if (rtid == 0) {
+            a.Slen[d.t] = n_out;
+            a.Slead[d.t] = lead_out;
+            a.Sorig[d.t] = d.orig;
             c_nnz += (u64d)n_out;
             c_rows += n_out > 0;
-            c_ent += (u64d)ln;
+            c_ent += (u64d)ln_cur;
             c_seg += 1;
-            s_misc[0] = 0;
-            s_misc[1] = INT_MAX;
+            if (!WAVE_ROW) { s_misc[0] = 0; s_misc[1] = INT_MAX; }
         }
-        __syncthreads();
+        if (WAVE_ROW) __builtin_amdgcn_wave_barrier(); else lds_barrier();
+        STAMP(6); // prefetch issue + sweep + stores
+        // rotate the pipeline
+        d = dn;
+        if (has_nn) dn = desc_unpack(dnn_regs);
     }
-    if (tid == 0 && (c_nnz || c_rows)) {
-        atomicAdd(&a.ctr->nnz_out, c_nnz);
-        atomicAdd(&a.ctr->nonempty_out, c_rows);
+#ifdef SPASM_STAMPS
+    if (lane == 0 && a.stamps) {
+        for (int i = 0; i < NSTAMP; i++) atomicAdd(&a.stamps[(size_t)a.cls * 2 * NSTAMP + i], st_sum[i]);
+        atomicAdd(&a.stamps[(size_t)a.cls * 2 * NSTAMP + NSTAMP], 1ull);
     }
+#endif
+    // counters: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) {
         c_ent += __shfl_xor(c_ent, o);
         c_seg += __shfl_xor(c_seg, o);
+        c_nnz += __shfl_xor(c_nnz, o);
+        c_rows += __shfl_xor(c_rows, o);
     }
-    if (lane == 0 && (c_ent | c_seg)) {
-        atomicAdd(&a.ctr->class_ent[a.cls], c_ent);
-        atomicAdd(&a.ctr->class_seg[a.cls], c_seg);
+    if (lane == 0) {
+        if (c_nnz) atomicAdd(&a.ctr->nnz_out, c_nnz);
+        if (c_rows) atomicAdd(&a.ctr->nonempty_out, c_rows);
+        if (c_ent | c_seg) {
+            atomicAdd(&a.ctr->class_ent[a.cls], c_ent);
+            atomicAdd(&a.ctr->class_seg[a.cls], c_seg);
+        }
     }
 }
 
@@ -699,5 +1026,398 @@ __global__ void k_compact_rows(int n, const i64d *__restrict__ start, const int 
         const int2 e = ent[st + k];
         oj[os + k] = e.x;
         ox[os + k] = e.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SOLVE without dependent chains.  Per round the rows of Uinv = (I + N)^-1 (N = U_PP, strictly upper
+// triangular in pivot-index space) are computed once by the chain solve above applied to the unit
+// rows e_r (only npiv rows, short reach).  The multipliers of a non-pivot row are then
+//        x_b = a_P * Uinv = sum over its entries (c, a_c) on pivot columns of a_c * Uinv[qinv(c)]
+// a dependency-free sparse combine: each TEAM accumulates the lists into a small LDS hash table
+// keyed by pivot index.  Same x_b (the triangular system has one solution), hence the same counters.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_unit_rows(int npiv, const int *__restrict__ pivcol, i64d *__restrict__ start, int *__restrict__ len, int2 *__restrict__ ent)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npiv) return;
+    start[t] = t;
+    len[t] = 1;
+    ent[t] = make_int2(pivcol[t], 1);
+}
+
+// per-column record for the combine: pivot index of the column (or -1) and where its row of Uinv lives
+// (len < 0: that row of Uinv is not available)
+__global__ void k_colinfo(int m, const int *__restrict__ qinv_r, const i64d *__restrict__ UinvStart, const int *__restrict__ UinvLen,
+                          int4 *__restrict__ colinfo)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int q = qinv_r[j];
+    int4 r = make_int4(q, 0, 0, 0);
+    if (q >= 0) { r.y = (int)(unsigned)UinvStart[q]; r.z = UinvLen[q]; }
+    colinfo[j] = r;
+}
+
+// (start,len) of the listed rows, gathered once so that a row team reads them with one load
+__global__ void k_gather_rows(int n, const int *__restrict__ rows, const i64d *__restrict__ start, const int *__restrict__ len,
+                              i64d *__restrict__ ostart, int *__restrict__ olen)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int row = rows ? rows[t] : t;
+    ostart[t] = start[row];
+    olen[t] = len[row];
+}
+
+struct CombineArgs {
+    int nrows;
+    const int *retry;          // when non-NULL: row slots to process (those that overflowed the previous class)
+    const int *retry_count;
+    const int *self_idx;
+    const i64d *rstart;        // per row slot: start / length of the row's own entries
+    const int *rlen;
+    const int2 *ent;
+    const int4 *colinfo;       // per column: {pivot index or -1, offset of its Uinv row, its length, -}
+    const UHdr *uhdr;
+    const int2 *UinvPool;
+    int4 *Lpool;
+    u64d lpool_cap;            // entries per pool region
+    u64d *pool_ctr;
+    i64d *Lstart;
+    int *Llen;
+    i64d *bound;
+    int free_cols;
+    int *overflow_list;
+    int *overflow_count;
+    RoundCounters *ctr;
+    ZpField F;
+};
+
+template <int LOGC, bool SMALL>
+__device__ __forceinline__ bool team_table_add(int *key, typename ZpAcc<SMALL>::type *val, int *cnt, int idx, typename ZpAcc<SMALL>::type prod)
+{
+    constexpr int CAPS = 1 << LOGC;
+    unsigned h = ((unsigned)idx * 0x9E3779B1u) >> (32 - LOGC);
+    for (int probes = 0; probes < CAPS; probes++) {
+        const int kk = atomicCAS(&key[h], EMPTY_KEY, idx);
+        if (kk == EMPTY_KEY || kk == idx) {
+            if (kk == EMPTY_KEY) atomicAdd(cnt, 1);
+            if (SMALL) atomicAdd((int *)&val[h], (int)prod);
+            else atomicAdd((u64d *)&val[h], (u64d)prod);
+            return true;
+        }
+        h = (h + 1) & (CAPS - 1);
+    }
+    return false;
+}
+
+template <int TEAM, int LOGC, int TPB, bool SMALL>
+__global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
+{
+    typedef typename ZpAcc<SMALL>::type Acc;
+    constexpr int CAPS = 1 << LOGC;      // slots per team
+    constexpr int MAXD = CAPS / 2;       // distinct pivot indices a team accepts
+    constexpr int TEAMS = TPB / TEAM;
+    constexpr int MAXP = 4;              // Uinv rows whose loads are issued together
+    __shared__ Acc s_val[TEAMS * CAPS];
+    __shared__ int s_key[TEAMS * CAPS];
+    __shared__ int s_cnt[TEAMS];
+    const int team = threadIdx.x / TEAM;
+    const int tl = threadIdx.x % TEAM;
+    int *key = s_key + team * CAPS;
+    Acc *val = s_val + team * CAPS;
+    int *cnt = &s_cnt[team];
+    const ZpField F = a.F;
+    for (int s = tl; s < CAPS; s += TEAM) { key[s] = EMPTY_KEY; val[s] = 0; }
+    if (tl == 0) *cnt = 0;
+    __syncthreads();
+
+    u64d c_app = 0, c_red = 0, c_seg = 0;
+    const int total = a.retry ? *a.retry_count : a.nrows;
+    const i64d first = (i64d)blockIdx.x * TEAMS + team, stride = (i64d)gridDim.x * TEAMS;
+    // pipeline: (slot, start, len) and the first 2*TEAM own entries of the next row are loaded one row ahead
+    int t_n = 0, ln_n = 0;
+    i64d st_n = 0;
+    int2 own_na = make_int2(0, 0), own_nb = make_int2(0, 0);
+    if (first < total) {
+        t_n = a.retry ? a.retry[first] : (int)first;
+        st_n = a.rstart[t_n];
+        ln_n = a.rlen[t_n];
+        if (tl < ln_n) own_na = a.ent[st_n + tl];
+        if (tl + TEAM < ln_n) own_nb = a.ent[st_n + tl + TEAM];
+    }
+    for (i64d gteam = first; gteam < total; gteam += stride) {
+        const int t = t_n, ln = ln_n;
+        const i64d st = st_n;
+        const int2 own_a = own_na, own_b = own_nb;
+        if (gteam + stride < total) {
+            t_n = a.retry ? a.retry[gteam + stride] : (int)(gteam + stride);
+            st_n = a.rstart[t_n];
+            ln_n = a.rlen[t_n];
+            own_na = make_int2(0, 0);
+            own_nb = make_int2(0, 0);
+            if (tl < ln_n) own_na = a.ent[st_n + tl];
+            if (tl + TEAM < ln_n) own_nb = a.ent[st_n + tl + TEAM];
+        }
+        const int self = a.self_idx ? a.self_idx[t] : -1;
+        int nN = 0;
+        bool ok = true;
+        // one batch of TEAM own entries: entries on pivot columns pull their row of Uinv into the table
+        auto process = [&](const int2 own, const int4 ci, const bool valid) {
+            const bool isP = valid && ci.x >= 0 && ci.x != self;
+            nN += __popcll(team_ballot<TEAM>(valid && ci.x < 0));
+            u64d mP = team_ballot<TEAM>(isP);
+            while (mP && ok) {
+                // up to MAXP pivot entries: all their Uinv rows are requested before any accumulation
+                int av[MAXP], ul[MAXP];
+                unsigned uo[MAXP];
+                int2 wv[MAXP];
+                bool fail = false;
+#pragma unroll
+                for (int j = 0; j < MAXP; j++) {
+                    av[j] = 0; ul[j] = 0; uo[j] = 0;
+                    wv[j] = make_int2(0, 0);
+                    if (mP) {
+                        const int src = __ffsll((long long)mP) - 1;
+                        mP &= mP - 1;
+                        av[j] = __shfl(own.y, src, TEAM);
+                        uo[j] = (unsigned)__shfl(ci.y, src, TEAM);
+                        ul[j] = __shfl(ci.z, src, TEAM);
+                        if (ul[j] < 0) fail = true;
+                        if (tl < ul[j]) wv[j] = a.UinvPool[(i64d)uo[j] + tl];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MAXP; j++) {
+                    if (tl < ul[j] && !team_table_add<LOGC, SMALL>(key, val, cnt, wv[j].x, ZpAcc<SMALL>::mul_lazy(F, av[j], wv[j].y))) fail = true;
+                    for (int i = tl + TEAM; i < ul[j]; i += TEAM) { // rows of Uinv longer than the team
+                        const int2 w2 = a.UinvPool[(i64d)uo[j] + i];
+                        if (!team_table_add<LOGC, SMALL>(key, val, cnt, w2.x, ZpAcc<SMALL>::mul_lazy(F, av[j], w2.y))) fail = true;
+                    }
+                }
+                if (team_ballot<TEAM>(fail) != 0) ok = false;
+                if (*(volatile int *)cnt > MAXD) ok = false; // read after this team's LDS atomics (in-order LDS)
+            }
+        };
+        {
+            // the two prefetched batches: both column-record gathers in flight together
+            const bool va = tl < ln, vb = tl + TEAM < ln;
+            int4 ci_a = make_int4(-1, 0, 0, 0), ci_b = ci_a;
+            if (va) ci_a = a.colinfo[own_a.x];
+            if (vb) ci_b = a.colinfo[own_b.x];
+            process(own_a, ci_a, va);
+            if (ln > TEAM && ok) process(own_b, ci_b, vb);
+        }
+        for (int k0 = 2 * TEAM; k0 < ln && ok; k0 += TEAM) {
+            const int k = k0 + tl;
+            const bool valid = k < ln;
+            int2 own = make_int2(0, 0);
+            int4 ci = make_int4(-1, 0, 0, 0);
+            if (valid) { own = a.ent[st + k]; ci = a.colinfo[own.x]; }
+            process(own, ci, valid);
+        }
+        const int dcount = *(volatile int *)cnt;
+        if (!ok) {
+            for (int s = tl; s < CAPS; s += TEAM) { key[s] = EMPTY_KEY; val[s] = 0; }
+            if (tl == 0) {
+                *cnt = 0;
+                a.Llen[t] = -1;
+                a.Lstart[t] = 0;
+                a.bound[t] = 0;
+                const int pos = atomicAdd(a.overflow_count, 1);
+                if (a.overflow_list) a.overflow_list[pos] = t;
+            }
+            continue;
+        }
+        u64d base = 0;
+        if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)dcount);
+        base = __shfl(base, 0, TEAM);
+        const bool room = base != ~0ull;
+        // ---- sweep 1: reduce and compact the non-zero multipliers to the front of the team's arrays
+        int nout = 0;
+        for (int s0 = 0; s0 < CAPS; s0 += TEAM) {
+            const int s = s0 + tl;
+            const int kk = key[s];
+            int v = 0;
+            if (kk != EMPTY_KEY) v = acc_reduce<SMALL>(F, val[s]);
+            key[s] = EMPTY_KEY;
+            val[s] = 0;
+            const bool nz = v != 0;
+            const u64d m = team_ballot<TEAM>(nz);
+            if (nz) { // nout + rank <= s0 + rank <= s: only slots already consumed are overwritten
+                const int pos = nout + __popcll(m & ((1ull << tl) - 1ull));
+                key[pos] = kk;
+                val[pos] = (Acc)v;
+            }
+            nout += __popcll(m);
+        }
+        // ---- sweep 2: headers of the applied pivot rows (gathers in flight together), records out
+        i64d bound = 0;
+        u64d r_red = 0;
+        for (int i0 = 0; i0 < nout; i0 += 4 * TEAM) {
+            int kk[4], vv[4];
+            UHdr hh[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = i0 + j * TEAM + tl;
+                kk[j] = 0; vv[j] = 0;
+                hh[j].off = 0; hh[j].npp = 0; hh[j].npn = 0; hh[j].len = 0;
+                if (i < nout) { kk[j] = key[i]; vv[j] = (int)val[i]; hh[j] = a.uhdr[kk[j]]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = i0 + j * TEAM + tl;
+                if (i < nout) {
+                    if (room) a.Lpool[base + i] = make_int4(kk[j], vv[j], (int)hh[j].off, hh[j].npn);
+                    bound += hh[j].npn;
+                    r_red += (u64d)hh[j].len;
+                }
+            }
+        }
+        for (int i = tl; i < nout; i += TEAM) { key[i] = EMPTY_KEY; val[i] = 0; }
+        for (int o = TEAM / 2; o > 0; o >>= 1) {
+            bound += __shfl_xor(bound, o, TEAM);
+            r_red += __shfl_xor(r_red, o, TEAM);
+        }
+        bound += nN;
+        r_red += (u64d)ln;
+        if (tl == 0) {
+            *cnt = 0;
+            if (!room) {
+                atomicAdd(&a.ctr->lpool_overflow, 1);
+                a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0;
+            } else {
+                a.Lstart[t] = (i64d)base;
+                a.Llen[t] = nout;
+                a.bound[t] = bound < (i64d)a.free_cols ? bound : (i64d)a.free_cols;
+                c_app += (u64d)nout;
+                c_red += r_red;
+                c_seg += 1 + (u64d)nout;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c_app += __shfl_xor(c_app, o);
+        c_red += __shfl_xor(c_red, o);
+        c_seg += __shfl_xor(c_seg, o);
+    }
+    if ((threadIdx.x & 63) == 0 && (c_app | c_red | c_seg)) {
+        atomicAdd(&a.ctr->applications, c_app);
+        atomicAdd(&a.ctr->nnz_reduced, c_red);
+        atomicAdd(&a.ctr->segments, c_seg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SOLVE, unbounded reach (last resort): one workgroup per row, a dense value vector and a pending
+// bitmap over the pivot indices in global memory (both all-zero between rows), pivots popped in
+// increasing index order.  Serial in the reach; only rows that overflow every LDS class come here.
+// ------------------------------------------------------------------------------------------------
+struct BigSolveArgs {
+    SolveArgs s;
+    int npiv;
+    int nwords;              // (npiv + 31) / 32
+    int *xdense;             // [gridDim.x][npiv]
+    unsigned *bitmap;        // [gridDim.x][nwords]
+    int4 *scratch;           // [gridDim.x][npiv]
+};
+
+__global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
+{
+    const SolveArgs &a = b.s;
+    __shared__ int s_word;       // index of the word holding the next pending pivot, INT_MAX if none in the window
+    __shared__ int s_nN;
+    __shared__ u64d s_base;
+    const int tid = threadIdx.x;
+    const ZpField F = a.F;
+    int *x = b.xdense + (size_t)blockIdx.x * b.npiv;
+    unsigned *bm = b.bitmap + (size_t)blockIdx.x * b.nwords;
+    int4 *out = b.scratch + (size_t)blockIdx.x * b.npiv;
+    const int total = *a.retry_count;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int t = a.retry[w];
+        const int row = a.rows ? a.rows[t] : t;
+        const int self = a.self_idx ? a.self_idx[t] : -1;
+        const i64d st = a.start[row];
+        const int ln = a.len[row];
+        if (tid == 0) s_nN = 0;
+        __syncthreads();
+        int myN = 0;
+        for (int k = tid; k < ln; k += 256) {
+            const int2 e = a.ent[st + k];
+            const int q = a.qinv_r[e.x];
+            if (q >= 0 && q != self) {
+                x[q] = e.y; // columns of a row are distinct
+                atomicOr(&bm[q >> 5], 1u << (q & 31));
+            } else if (q < 0) myN++;
+        }
+        if (myN) atomicAdd(&s_nN, myN);
+        __syncthreads();
+        int cnt = 0, wbase = 0;
+        i64d bound = 0;
+        u64d r_app = 0, r_red = (u64d)ln;
+        while (wbase < b.nwords) {
+            // first non-zero word in [wbase, wbase + 256): lowest lane per wave, lowest wave through LDS
+            const int wi = wbase + tid;
+            const unsigned wv = wi < b.nwords ? bm[wi] : 0u;
+            if (tid == 0) s_word = INT_MAX;
+            __syncthreads();
+            const u64d mb = __ballot(wv != 0);
+            if (mb && (tid & 63) == 0) atomicMin(&s_word, wbase + (tid & ~63) + (__ffsll((long long)mb) - 1));
+            __syncthreads();
+            const int found = s_word;
+            __syncthreads(); // s_word is reset by the next iteration
+            if (found == INT_MAX) { wbase += 256; continue; }
+            const unsigned word = bm[found];
+            const int bit = __ffs((int)word) - 1;
+            const int idx = found * 32 + bit;
+            const int mult = x[idx];
+            __syncthreads();
+            UHdr h; h.off = 0; h.npp = 0; h.npn = 0; h.len = 0;
+            if (mult != 0) h = a.uhdr[idx];
+            if (tid == 0) {
+                atomicAnd(&bm[found], ~(1u << bit)); // other lanes may be setting bits of the same word
+                x[idx] = 0;
+                out[cnt] = make_int4(idx, mult, (int)h.off, h.npn);
+            }
+            cnt++;
+            if (mult != 0) {
+                r_app += 1;
+                r_red += (u64d)h.len;
+                bound += h.npn;
+                const int nm = zp_neg(F, mult);
+                for (int k = tid; k < h.npp; k += 256) {
+                    const int2 e = a.UPP[(i64d)h.off + k];
+                    x[e.x] = zp_axpy(F, nm, e.y, x[e.x]); // targets of one pivot row are distinct
+                    atomicOr(&bm[e.x >> 5], 1u << (e.x & 31));
+                }
+            }
+            __syncthreads();
+            wbase = found; // the same word may hold further pivots
+        }
+        // publish
+        if (tid == 0) s_base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)cnt);
+        __syncthreads();
+        const u64d base = s_base;
+        if (base == ~0ull) {
+            if (tid == 0) { atomicAdd(&a.ctr->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
+        } else {
+            for (int i = tid; i < cnt; i += 256) {
+                const int4 r = out[i];
+                if (a.Lpool2) a.Lpool2[base + i] = make_int2(r.x, r.y);
+                else a.Lpool[base + i] = r;
+            }
+            if (tid == 0) {
+                bound += s_nN;
+                a.Lstart[t] = (i64d)base;
+                a.Llen[t] = cnt;
+                a.bound[t] = bound < (i64d)a.free_cols ? bound : (i64d)a.free_cols;
+                atomicAdd(&a.ctr->applications, r_app);
+                atomicAdd(&a.ctr->nnz_reduced, r_red);
+                atomicAdd(&a.ctr->segments, 1 + r_app);
+            }
+        }
+        __syncthreads();
     }
 }

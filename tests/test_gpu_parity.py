@@ -196,6 +196,27 @@ def test_schur_round_vs_oracle(S, O, n, k, p, seed):
     assert Sc.rows() == So.rows()
 
 
+def test_schur_round_deep_chains(S, O):
+    """Pivot rows that chain through thousands of other pivots: the reach of a row exceeds every LDS
+    class of the solve kernel (and Uinv is too dense to build), so the fallback classes run."""
+    p = 65521
+    N = 6000
+    rng = np.random.default_rng(5)
+    rows = []
+    for i in range(N):  # bidiagonal pivot rows: pivot i chains into i+1, i+2, ...
+        rows.append([(i, int(rng.integers(1, p))), (i + 1, int(rng.integers(1, p))), (N + 1 + int(rng.integers(0, 500)), int(rng.integers(1, p)))])
+    for k in range(40):  # probe rows entering the chain at various depths, heavier than the pivot rows
+        c = int(rng.integers(0, N - 1)) if k else 0
+        cols = sorted(set([c] + [int(x) for x in rng.integers(c, N + 501, size=6)]))
+        rows.append([(cc, int(rng.integers(1, p))) for cc in cols])
+    A = S.CSR.from_rows(rows, N + 501, prime=p)
+    Sc, st, p_out = run_plan(S, A)
+    So, info = O.schur_round(A)
+    assert st["npiv"] == info["npiv"] == N
+    assert st["applications"] == info["applications"] and st["nnz_reduced"] == info["nnz_reduced"]
+    assert Sc.rows() == So.rows()
+
+
 def test_schur_round_sharded_rows(S, O):
     """Row shards reduce independently against the same U (multi-GPU partitioning)."""
     A = S.synth_csr(1, 6000, 6000, row_nnz=10, prime=65521, seed=31)
