@@ -347,11 +347,12 @@ struct Round {
     }
 
     // rows of Uinv: the chain solve applied to the unit rows e_r (once per round, after build_U)
-    void prepare_uinv()
+    // expected_rows = rows the solve will process: building Uinv costs npiv chain solves, so it pays only for more rows than that
+    void prepare_uinv(i64 expected_rows = ((i64)1 << 62))
     {
         use_uinv = false;
         uinv_nnz = 0;
-        if (npiv == 0) return;
+        if (npiv == 0 || expected_rows < (i64)npiv) return;
         E.n = npiv;
         E.m = m;
         E.start.ensure((size_t)npiv + 1);
@@ -770,9 +771,110 @@ void append_round_U(HostU &U, const Round &R, const DevMat &A, hipStream_t s)
     for (const int2 &e : ent) { U.j.push_back(e.x); U.x.push_back(e.y); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dense tail: leftmost-pivot elimination of the live part of `M`; its pivot rows are appended to U
+// ------------------------------------------------------------------------------------------------
+const i64 kDenseMaxEntries = (i64)1 << 28; // 1 GiB of i32
+
+int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
+{
+    const int n = M.n, m = M.m;
+    Scanner scan;
+    // live rows and live columns
+    DevBuf<int> rflag, rscan, rows, cflag, cscan, cmap, clist;
+    rflag.alloc((size_t)n + 1); rscan.alloc((size_t)n + 1); rows.alloc((size_t)n + 1);
+    cflag.alloc((size_t)m + 1); cscan.alloc((size_t)m + 1); cmap.alloc((size_t)m + 1); clist.alloc((size_t)m + 1);
+    hipLaunchKernelGGL(k_flag_live, dim3(cdiv((i64)n + 1, 256)), dim3(256), 0, s, n, M.len.p, rflag.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(rflag.p, rscan.p, (size_t)n + 1, s);
+    hipLaunchKernelGGL(k_compact, dim3(cdiv(std::max(n, 1), 256)), dim3(256), 0, s, n, rflag.p, rscan.p, rows.p);
+    HIPCHK(hipGetLastError());
+    cflag.zero(s);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_flag_cols, dim3(cdiv((i64)n * 64, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p, cflag.p);
+        HIPCHK(hipGetLastError());
+    }
+    scan.exclusive(cflag.p, cscan.p, (size_t)m + 1, s);
+    int R = 0, C = 0;
+    HIPCHK(hipMemcpyAsync(&R, rscan.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&C, cscan.p + m, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (R == 0 || C == 0) return 0;
+    hipLaunchKernelGGL(k_col_map, dim3(cdiv(m, 256)), dim3(256), 0, s, m, cflag.p, cscan.p, cmap.p, clist.p);
+    HIPCHK(hipGetLastError());
+    const i64 ldc = ((i64)C + 63) / 64 * 64;
+    DevBuf<int> D, is_piv, pivrow_of_col, prow, fcol;
+    DevBuf<DenseState> st;
+    D.alloc((size_t)R * (size_t)ldc);
+    is_piv.alloc((size_t)R + 1);
+    pivrow_of_col.alloc((size_t)C + 1);
+    prow.alloc((size_t)ldc);
+    fcol.alloc((size_t)R + 1);
+    st.alloc(1);
+    D.zero(s); is_piv.zero(s); st.zero(s);
+    hipLaunchKernelGGL(k_dense_fill, dim3(cdiv((i64)R * 64, 256)), dim3(256), 0, s, R, rows.p, M.start.p, M.len.p, M.ent.p, cmap.p, D.p, (i64d)ldc);
+    HIPCHK(hipGetLastError());
+    const int rc = std::max(R, C);
+    for (int c = 0; c < C; c++) {
+        hipLaunchKernelGGL(k_dense_find, dim3(1), dim3(1024), 0, s, c, R, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, st.p);
+        hipLaunchKernelGGL(k_dense_scale, dim3(cdiv(rc, 256)), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, st.p);
+        hipLaunchKernelGGL(k_dense_store_prow, dim3(cdiv(C, 256)), dim3(256), 0, s, c, C, D.p, (i64d)ldc, prow.p, st.p);
+        hipLaunchKernelGGL(k_dense_elim, dim3(cdiv(C - c, 256), R), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, prow.p, fcol.p, st.p);
+        if ((c & 255) == 255) HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipGetLastError());
+    // extract the pivot rows
+    DevBuf<int> pflag, pscan;
+    pflag.alloc((size_t)C + 1); pscan.alloc((size_t)C + 1);
+    hipLaunchKernelGGL(k_flag_nonneg, dim3(cdiv((i64)C + 1, 256)), dim3(256), 0, s, C, pivrow_of_col.p, pflag.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(pflag.p, pscan.p, (size_t)C + 1, s);
+    int npd = 0;
+    HIPCHK(hipMemcpyAsync(&npd, pscan.p + C, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (npd == 0) return 0;
+    DevBuf<i64d> ulen, uoff;
+    ulen.alloc((size_t)npd + 1); uoff.alloc((size_t)npd + 1);
+    ulen.zero(s);
+    hipLaunchKernelGGL(k_dense_count, dim3(C), dim3(256), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, ulen.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(ulen.p, uoff.p, (size_t)npd + 1, s);
+    i64d tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, uoff.p + npd, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    DevBuf<int2> Ufull;
+    DevBuf<int> pivcol, porig;
+    Ufull.alloc((size_t)tot + 1); pivcol.alloc((size_t)npd + 1); porig.alloc((size_t)npd + 1);
+    hipLaunchKernelGGL(k_dense_emit, dim3(C), dim3(64), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, uoff.p, clist.p, rows.p, M.orig.p,
+                       Ufull.p, pivcol.p, porig.p);
+    HIPCHK(hipGetLastError());
+    std::vector<int2> ent((size_t)tot);
+    std::vector<i64d> off((size_t)npd + 1);
+    std::vector<int> pc((size_t)npd), po((size_t)npd);
+    if (tot > 0) HIPCHK(hipMemcpyAsync(ent.data(), Ufull.p, (size_t)tot * sizeof(int2), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(off.data(), uoff.p, ((size_t)npd + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pc.data(), pivcol.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(po.data(), porig.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const i64 base = U.p.back();
+    for (int k = 0; k < npd; k++) {
+        U.p.push_back(base + off[(size_t)k + 1]);
+        U.pivcol.push_back(pc[(size_t)k]);
+        U.orig.push_back(po[(size_t)k]);
+    }
+    U.j.reserve(U.j.size() + ent.size());
+    U.x.reserve(U.x.size() + ent.size());
+    for (const int2 &x : ent) { U.j.push_back(x.x); U.x.push_back(x.y); }
+    spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots\n", R, C, npd);
+    return npd;
+}
+
 struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
 {
-    (void)opts; // every pivot is a leftmost entry, so rank, pivot columns and kernel do not depend on the tunables
+    // every pivot is a leftmost entry, so rank, pivot columns and kernel do not depend on the tunables;
+    // enable_dense / sparsity_threshold (reference src/SpaSM.jl:329,337) decide when the dense tail takes over
+    struct echelonize_opts dflt;
+    if (!opts) { spasm_echelonize_init_opts(&dflt); opts = &dflt; }
     require_device();
     check_input(A, "spasm_echelonize");
     const int n = A->n, m = A->m;
@@ -792,14 +894,26 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     R->F = zp_field_make(prime);
     R->stream = stream;
     int round = 0;
+    i64 cur_live = n;
     while (cur->n > 0 && m > 0) {
+        {
+            const i64 cfree = (i64)m - (i64)U.pivcol.size();
+            const double cells = (double)cur_live * (double)cfree;
+            if (opts->enable_dense && cur_nnz > 0 && cells > 0 && cells <= (double)kDenseMaxEntries &&
+                (double)cur_nnz > opts->sparsity_threshold * cells) {
+                spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
+                           cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
+                run_dense_tail(*cur, R->F, U, stream);
+                break;
+            }
+        }
         HIPCHK(hipEventRecord(R->ev[0], stream));
         R->elect_local(*cur, 0);
         R->assign_pivots();
         if (R->npiv == 0) break; // no non-empty row left
         R->mark_local(*cur, 0);
         R->build_U(*cur, R->pivrow.p);
-        R->prepare_uinv();
+        R->prepare_uinv(R->nnp);
         HIPCHK(hipEventRecord(R->ev[1], stream));
         const int nnp = R->nnp;
         const i64 tot = R->solve_phase(*cur, R->np_rows.p, nullptr, nnp, 4 * cur_nnz);
@@ -829,6 +943,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         next->ent = std::move(R->S.ent);
         cur = std::move(next);
         cur_nnz = st.nnz_out;
+        cur_live = st.rows_out;
         round++;
         if (cur_nnz == 0) break;
     }
@@ -1018,9 +1133,16 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact)
         for (int t = 0; t < r; t++) perm[(size_t)t] = post[(size_t)(r - 1 - t)];
     }
     for (int t = 0; t < r; t++) idx_of[(size_t)perm[(size_t)t]] = t;
-    std::vector<int> h_qinv_r((size_t)m + 1, -1), h_pivcol((size_t)std::max(r, 1));
-    for (int j = 0; j < m; j++) if (qinv[j] >= 0) h_qinv_r[(size_t)j] = idx_of[(size_t)qinv[j]];
-    for (int t = 0; t < r; t++) h_pivcol[(size_t)t] = pc[(size_t)perm[(size_t)t]];
+
+    // Transposed triangular system (what libspasm solves per free column, README.md:39 "Transposing U"):
+    // unknowns y_a = k[pivcol(a)], equations y_a + sum_{b != a} U[a][pivcol(b)] y_b = U[a][j].  Numbering the
+    // pivots in REVERSE topological order (ridx) makes the system strictly upper triangular for the solve kernels:
+    // "pivot row" ridx(b) = column pivcol(b) of U, "right-hand side" of free column j = column j of U.
+    std::vector<int> h_lab((size_t)std::max(r, 1)), h_rowsrc((size_t)std::max(r, 1)), h_free;
+    for (int a = 0; a < r; a++) h_lab[(size_t)a] = r - 1 - idx_of[(size_t)a];
+    for (int t = 0; t < r; t++) h_rowsrc[(size_t)(r - 1 - t)] = pc[(size_t)perm[(size_t)t]]; // column of pivot ridx
+    for (int j = 0; j < m; j++) if (qinv[j] < 0) h_free.push_back(j);
+    const int nfree = (int)h_free.size();
 
     hipStream_t s = nullptr;
     DevMat PM;
@@ -1028,31 +1150,69 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact)
     std::unique_ptr<Round> R(new Round());
     R->F = zp_field_make(prime);
     R->stream = s;
-    R->m = m;
-    R->npiv = r;
-    R->qinv_r.alloc((size_t)m + 1);
-    R->pivcol.alloc((size_t)r + 1);
-    DevBuf<int> rowsrc, iota;
+    DevBuf<int> lab, rowsrc, freecol;
+    lab.alloc((size_t)r + 1);
     rowsrc.alloc((size_t)r + 1);
-    iota.alloc((size_t)r + 1);
-    HIPCHK(hipMemcpyAsync(R->qinv_r.p, h_qinv_r.data(), ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    freecol.alloc((size_t)nfree + 1);
     if (r > 0) {
-        HIPCHK(hipMemcpyAsync(R->pivcol.p, h_pivcol.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(rowsrc.p, perm.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_iota, dim3(cdiv(r, 256)), dim3(256), 0, s, r, iota.p);
+        HIPCHK(hipMemcpyAsync(lab.p, h_lab.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(rowsrc.p, h_rowsrc.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    if (nfree > 0) HIPCHK(hipMemcpyAsync(freecol.p, h_free.data(), (size_t)nfree * sizeof(int), hipMemcpyHostToDevice, s));
+    // Ut: row j = column j of U with entries labelled ridx(a)
+    TransposeOut Ut;
+    device_transpose(PM, r, nullptr, lab.p, 0, R->scan, s, Ut);
+    DevMat T;
+    T.n = m;
+    T.m = r;
+    T.start.alloc((size_t)m + 1);
+    T.len.alloc((size_t)m + 1);
+    T.lead.alloc(1);
+    T.orig.alloc((size_t)m + 1);
+    T.ent = std::move(Ut.Tent);
+    if (m > 0) {
+        hipLaunchKernelGGL(k_rows_from_ptr, dim3(cdiv(m, 256)), dim3(256), 0, s, m, Ut.Tp.p, T.start.p, T.len.p, T.orig.p);
         HIPCHK(hipGetLastError());
     }
-    R->build_U(PM, rowsrc.p);
-    R->prepare_uinv();
-    const i64 tot = R->solve_phase(PM, rowsrc.p, iota.p, r, 4 * spasm_nnz(U));
-    R->S.ent.ensure((size_t)tot + 1);
-    R->run_scatter(PM, rowsrc.p, r);
-    R->fetch_counters();
-    R->S.n = r;
-    R->S.m = m;
-    TransposeOut T;
-    device_transpose(R->S, r, R->qinv_r.p, R->pivcol.p, 1, R->scan, s, T);
-    struct spasm_csr *K = transpose_out_to_host(T, m, prime, s);
+    // the solve structures over the ridx space: every "column" 0..r-1 carries a pivot
+    R->m = r;
+    R->npiv = r;
+    R->qinv_r.alloc((size_t)r + 1);
+    R->pivcol.alloc((size_t)r + 1);
+    if (r > 0) {
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(r, 256)), dim3(256), 0, s, r, R->qinv_r.p);
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(r, 256)), dim3(256), 0, s, r, R->pivcol.p);
+        HIPCHK(hipGetLastError());
+    }
+    R->build_U(T, rowsrc.p);
+    R->prepare_uinv(nfree);
+    R->solve_phase(T, freecol.p, nullptr, nfree, 4 * spasm_nnz(U));
+    // assemble K: row f = {(free column, -1)} U {(column of pivot ridx, y_ridx)}
+    DevBuf<i64d> klen, kstart;
+    klen.alloc((size_t)nfree + 1);
+    kstart.alloc((size_t)nfree + 1);
+    hipLaunchKernelGGL(k_kcount, dim3(cdiv(((i64)nfree + 1) * 64, 256)), dim3(256), 0, s, nfree, R->Lstart.p, R->Llen.p, R->Lpool.p, klen.p);
+    HIPCHK(hipGetLastError());
+    R->scan.exclusive(klen.p, kstart.p, (size_t)nfree + 1, s);
+    i64d ktot = 0;
+    HIPCHK(hipMemcpyAsync(&ktot, kstart.p + nfree, sizeof ktot, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    DevBuf<int2> Kent;
+    Kent.alloc((size_t)ktot + 1);
+    if (nfree > 0) {
+        hipLaunchKernelGGL(k_kfill, dim3(cdiv((i64)nfree * 64, 256)), dim3(256), 0, s, nfree, freecol.p, rowsrc.p, R->Lstart.p, R->Llen.p, R->Lpool.p,
+                           kstart.p, Kent.p);
+        HIPCHK(hipGetLastError());
+    }
+    struct spasm_csr *K = spasm_csr_alloc(nfree, m, ktot, prime, true);
+    if (!K) throw EngineError("out of host memory");
+    {
+        std::vector<int2> ent((size_t)ktot);
+        HIPCHK(hipMemcpyAsync(K->p, kstart.p, ((size_t)nfree + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+        if (ktot > 0) HIPCHK(hipMemcpyAsync(ent.data(), Kent.p, (size_t)ktot * sizeof(int2), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (i64 q = 0; q < ktot; q++) { K->j[q] = ent[(size_t)q].x; K->x[q] = ent[(size_t)q].y; }
+    }
     spasm_logf("[kernel] done in %.1fs. NNZ(K) = %lld\n", spasm_wtime() - t0, (long long)spasm_nnz(K));
     return K;
 }
@@ -1094,7 +1254,7 @@ spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi)
     R.assign_pivots();
     R.mark_local(P->A, 0, lo, hi);
     R.build_U(P->A, R.pivrow.p);
-    R.prepare_uinv();
+    R.prepare_uinv(R.nnp);
     HIPCHK(hipEventRecord(R.ev[1], s));
     // dry run of the solve sizes the multiplier pool and the Schur slots once
     const i64 tot = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, 4 * spasm_nnz(A));

@@ -1421,3 +1421,219 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
         __syncthreads();
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// DENSE TAIL (replaces libspasm's spasm_schur_dense + spasm_ffpack_rref finish, prototypes reference
+// src/SpaSM.jl:765-769, :805-806).  The live rows x live columns of the Schur complement are gathered
+// into a dense row-major i32 matrix and eliminated column by column with the LEFTMOST-pivot rule
+// (first non-pivotal row holding a non-zero in the column), so the pivot columns stay the leading
+// columns of the row space.  Pivot decisions live on the device: the host only enqueues kernels.
+// This first version is a right-looking rank-1 update per column (HBM-bound); the blocked variant
+// with an MFMA trailing update is the planned replacement.
+// ------------------------------------------------------------------------------------------------
+struct DenseState {
+    int cur;       // pivot row of the column being eliminated, -1 if the column has none
+    int npiv;      // pivots found so far
+};
+
+__global__ void k_flag_cols(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent, int *__restrict__ flag)
+{
+    // one wave-sized team per row keeps it simple: rows of the tail are long
+    const int tl = threadIdx.x & 63;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= n) return;
+    const i64d st = start[i];
+    const int ln = len[i];
+    for (int k = tl; k < ln; k += 64) flag[ent[st + k].x] = 1;
+}
+
+__global__ void k_col_map(int m, const int *__restrict__ flag, const int *__restrict__ scan, int *__restrict__ cmap, int *__restrict__ clist)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    if (flag[j]) { cmap[j] = scan[j]; clist[scan[j]] = j; }
+    else cmap[j] = -1;
+}
+
+__global__ void k_dense_fill(int R, const int *__restrict__ rows, const i64d *__restrict__ start, const int *__restrict__ len,
+                             const int2 *__restrict__ ent, const int *__restrict__ cmap, int *__restrict__ D, i64d ldc)
+{
+    const int tl = threadIdx.x & 63;
+    const int r = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (r >= R) return;
+    const int row = rows[r];
+    const i64d st = start[row];
+    const int ln = len[row];
+    for (int k = tl; k < ln; k += 64) {
+        const int2 e = ent[st + k];
+        D[(i64d)r * ldc + cmap[e.x]] = e.y;
+    }
+}
+
+// first non-pivotal row with a non-zero in column c (one workgroup)
+__global__ __launch_bounds__(1024) void k_dense_find(int c, int R, const int *__restrict__ D, i64d ldc, int *__restrict__ is_piv,
+                                                     int *__restrict__ pivrow_of_col, DenseState *__restrict__ st)
+{
+    __shared__ int s_best;
+    if (threadIdx.x == 0) s_best = INT_MAX;
+    __syncthreads();
+    int best = INT_MAX;
+    for (int i = threadIdx.x; i < R && i < best; i += 1024)
+        if (!is_piv[i] && D[(i64d)i * ldc + c] != 0) { best = i; break; }
+    best = wave_min_i32(best);
+    if ((threadIdx.x & 63) == 0 && best != INT_MAX) atomicMin(&s_best, best);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int b = s_best;
+        if (b != INT_MAX) {
+            st->cur = b;
+            st->npiv += 1;
+            is_piv[b] = 1;
+            pivrow_of_col[c] = b;
+        } else {
+            st->cur = -1;
+            pivrow_of_col[c] = -1;
+        }
+    }
+}
+
+// normalise the pivot row (unit pivot) into prow[c..C), keep it in D as the U row, and copy column c of the
+// non-pivotal rows into fcol (the elimination factors) so that the update kernel has no read/write race on it
+__global__ void k_dense_scale(int c, int R, int C, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ is_piv,
+                              int *__restrict__ prow, int *__restrict__ fcol, const DenseState *__restrict__ st)
+{
+    const int p = st->cur;
+    if (p < 0) return;
+    const int inv = zp_inverse(F, D[(i64d)p * ldc + c]);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c && i < C) {
+        const int v = zp_mul(F, inv, D[(i64d)p * ldc + i]);
+        prow[i] = v;
+    }
+    if (i < R) fcol[i] = is_piv[i] ? 0 : D[(i64d)i * ldc + c];
+}
+
+__global__ void k_dense_store_prow(int c, int C, int *__restrict__ D, i64d ldc, const int *__restrict__ prow, const DenseState *__restrict__ st)
+{
+    const int p = st->cur;
+    if (p < 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c && i < C) D[(i64d)p * ldc + i] = prow[i];
+}
+
+// D[i][c..C) -= fcol[i] * prow[c..C) for every non-pivotal row i; blockIdx.y = row, blockIdx.x tiles the columns
+__global__ __launch_bounds__(256) void k_dense_elim(int c, int R, int C, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ prow,
+                                                    const int *__restrict__ fcol, const DenseState *__restrict__ st)
+{
+    if (st->cur < 0) return;
+    const int i = blockIdx.y;
+    const int f = fcol[i];
+    if (f == 0) return;
+    const int nf = zp_neg(F, f);
+    const int j = c + blockIdx.x * 256 + threadIdx.x;
+    if (j < C) {
+        int *d = D + (i64d)i * ldc + j;
+        *d = zp_axpy(F, nf, prow[j], *d);
+    }
+}
+
+// U rows out of the eliminated dense matrix: pivot column c (dense index) -> row pivrow_of_col[c], entries at columns >= c
+__global__ void k_dense_count(int C, const int *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
+                              i64d *__restrict__ ulen)
+{
+    // one workgroup per dense column; pscan = exclusive scan of (pivrow_of_col >= 0)
+    const int c = blockIdx.x;
+    const int p = pivrow_of_col[c];
+    if (p < 0) return;
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int j = c + threadIdx.x; j < C; j += blockDim.x) cnt += D[(i64d)p * ldc + j] != 0;
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) ulen[pscan[c]] = s_cnt;
+}
+
+__global__ void k_dense_emit(int C, const int *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
+                             const i64d *__restrict__ uoff, const int *__restrict__ clist, const int *__restrict__ rows, const int *__restrict__ orig,
+                             int2 *__restrict__ Ufull, int *__restrict__ pivcol, int *__restrict__ piv_orig)
+{
+    // one wave per pivot column keeps the entries of a U row in ascending column order
+    const int c = blockIdx.x;
+    const int p = pivrow_of_col[c];
+    if (p < 0) return;
+    const int k = pscan[c];
+    const int lane = threadIdx.x & 63;
+    i64d pos = uoff[k];
+    for (int j0 = c; j0 < C; j0 += 64) {
+        const int j = j0 + lane;
+        const int v = j < C ? D[(i64d)p * ldc + j] : 0;
+        const u64d m = __ballot(v != 0);
+        if (v != 0) Ufull[pos + __popcll(m & lanemask_lt())] = make_int2(clist[j], v);
+        pos += __popcll(m);
+    }
+    if (lane == 0) { pivcol[k] = clist[c]; piv_orig[k] = orig[rows[p]]; }
+}
+
+__global__ void k_flag_nonneg(int n, const int *__restrict__ v, int *__restrict__ flag)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = v[i] >= 0;
+    if (i == n) flag[i] = 0;
+}
+
+__global__ void k_flag_live(int n, const int *__restrict__ len, int *__restrict__ flag)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = len[i] > 0;
+    if (i == n) flag[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel basis assembly (reference call site src/SpaSM.jl:879)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_rows_from_ptr(int n, const i64d *__restrict__ p, i64d *__restrict__ start, int *__restrict__ len, int *__restrict__ orig)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    start[i] = p[i];
+    len[i] = (int)(p[i + 1] - p[i]);
+    orig[i] = i;
+}
+
+// entries of kernel vector f: the -1 on its free column plus one per non-zero multiplier
+__global__ void k_kcount(int nfree, const i64d *__restrict__ Lstart, const int *__restrict__ Llen, const int4 *__restrict__ Lpool, i64d *__restrict__ klen)
+{
+    const int lane = threadIdx.x & 63;
+    const int f = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (f > nfree) return;
+    if (f == nfree) { if (lane == 0) klen[f] = 0; return; }
+    const i64d ls = Lstart[f];
+    const int ll = Llen[f];
+    int cnt = 0;
+    for (int i = lane; i < ll; i += 64) cnt += Lpool[ls + i].y != 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) klen[f] = (i64d)cnt + 1;
+}
+
+__global__ void k_kfill(int nfree, const int *__restrict__ freecol, const int *__restrict__ colof, const i64d *__restrict__ Lstart,
+                        const int *__restrict__ Llen, const int4 *__restrict__ Lpool, const i64d *__restrict__ kstart, int2 *__restrict__ Kent)
+{
+    const int lane = threadIdx.x & 63;
+    const int f = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (f >= nfree) return;
+    const i64d ls = Lstart[f];
+    const int ll = Llen[f];
+    i64d pos = kstart[f];
+    if (lane == 0) Kent[pos] = make_int2(freecol[f], -1); // K[j] = -1 (reference test/runtests.jl:21: 42012 == -1 mod 42013)
+    pos += 1;
+    for (int i0 = 0; i0 < ll; i0 += 64) {
+        const int i = i0 + lane;
+        int4 r = make_int4(0, 0, 0, 0);
+        if (i < ll) r = Lpool[ls + i];
+        const u64d m = __ballot(r.y != 0);
+        if (r.y != 0) Kent[pos + __popcll(m & lanemask_lt())] = make_int2(colof[r.x], r.y);
+        pos += __popcll(m);
+    }
+}

@@ -89,13 +89,14 @@ def check_lu(S, A, fact, D, p):
     (50, 70, 0xFFFFFFFB, 0.1, 5), (40, 40, 3, 0.3, 6), (1, 17, 42013, 0.5, 7), (25, 1, 42013, 0.5, 8),
     (200, 150, 65537, 0.03, 9), (150, 220, 2147483647, 0.04, 10),
 ])
-def test_echelonize_kernel_vs_oracle_and_dense(S, O, n, m, p, density, seed):
+@pytest.mark.parametrize("enable_dense", [True, False], ids=["dense_tail", "sparse_rounds_only"])
+def test_echelonize_kernel_vs_oracle_and_dense(S, O, n, m, p, density, seed, enable_dense):
     from test_oracle_golden import random_rows
 
     rng = np.random.default_rng(seed)
     D = random_rows(rng, n, m, p, density, rank_deficient=True)
     A = S.CSR(D.T.copy(), prime=p)
-    fact = S.echelonize(A)
+    fact = S.echelonize(A, enable_dense=enable_dense)  # reference option, src/SpaSM.jl:329
     K = S.kernel(fact)
     olu = O.echelonize(A)
     oK = O.kernel(olu)
@@ -110,6 +111,38 @@ def test_echelonize_kernel_vs_oracle_and_dense(S, O, n, m, p, density, seed):
     stacked = np.vstack([D % p, fact.U.todense() % p])
     R2, piv2 = O.dense_rref(stacked, p)
     assert len(piv2) == fact.r
+
+
+def test_kernel_accepts_foreign_factorizations(S, O):
+    """spasm_kernel on a factorization this engine did not produce: U rows in arbitrary order, pivot not the
+    first entry of its row (reference src/SpaSM.jl:711 allows both); here the oracle's LU, rows shuffled."""
+    import ctypes as C
+
+    rng = np.random.default_rng(77)
+    from test_oracle_golden import random_rows
+
+    D = random_rows(rng, 60, 80, 65521, 0.06, rank_deficient=True)
+    A = S.CSR(D.T.copy(), prime=65521)
+    olu = O.echelonize(A)
+    want = O.kernel(olu).rows()
+    r = olu.r
+    perm = rng.permutation(r)
+    Urows = olu.U.rows()
+    shuffled = [list(reversed(Urows[int(a)])) for a in perm]  # row order and entry order both scrambled
+    Us = S.CSR.from_rows(shuffled, A.m, prime=65521)
+    inv = np.empty(r, dtype=np.int64)
+    inv[perm] = np.arange(r)
+    qinv = np.array([inv[q] if q >= 0 else -1 for q in olu.qinv], dtype=np.int32)
+    lu = S._abi.LuStruct()
+    lu.r = r
+    lu.complete = False
+    lu.L = None
+    lu.U = Us.data
+    lu.qinv = qinv.ctypes.data_as(C.POINTER(C.c_int32))
+    lu.p = None
+    ptr = S._abi.lib().spasm_kernel(C.byref(lu))
+    assert ptr, S._abi.last_error()
+    assert S.CSR(ptr).rows() == want
 
 
 def test_edge_cases(S):
