@@ -66,9 +66,23 @@ def main():
     lo, hi = rank * n // world, (rank + 1) * n // world
 
     t_setup = time.time()
-    plan = lib.spasm_amd_schur_plan_create(A.data, lo, hi)
-    if not plan:
-        raise SystemExit("plan_create failed: " + S._abi.last_error())
+    exchange = None
+    engine = None
+    if world > 1 and os.environ.get("SPASM_BENCH_EXCHANGE", "1") != "0":
+        # every rank uploads only its row block; the round's pivot rows are elected with an all-reduce(MIN) and
+        # exchanged with an all-gather (RCCL over xGMI), after which U is identical on all ranks
+        from spasm_jl_amd import sharded
+
+        engine = sharded.GpuShardEngine(A, lo, hi)
+        t_x = time.time()
+        npiv_x, exchange = sharded.exchange_pivot_rows(engine)
+        torch.cuda.synchronize()
+        exchange["seconds_incl_U_build"] = round(time.time() - t_x, 4)
+        plan = engine.plan
+    else:
+        plan = lib.spasm_amd_schur_plan_create(A.data, lo, hi)
+        if not plan:
+            raise SystemExit("plan_create failed: " + S._abi.last_error())
     t_setup = time.time() - t_setup
 
     stream = torch.cuda.Stream()
@@ -152,16 +166,21 @@ def main():
                 "nnz_reduced_per_step": nnz_reduced,
                 "applications_per_step": applications,
                 "nnz_out": nnz_out,
-                "parallelism": f"row-block x{world}" if world > 1 else "single GPU",
+                "parallelism": f"row-block x{world}, pivot rows exchanged by all-reduce(MIN)+all-gather" if world > 1 else "single GPU",
             },
             "roofline": roofline,
             "setup_s": {"generate": round(t_gen, 2), "upload_elect_buildU": round(t_setup, 2)},
         }
+        if exchange is not None:
+            out["pivot_row_exchange_rank0"] = exchange
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    lib.spasm_amd_schur_plan_free(plan)
+    if engine is not None:
+        engine.close()
+    else:
+        lib.spasm_amd_schur_plan_free(plan)
     if world > 1:
         dist.destroy_process_group()
 

@@ -165,6 +165,26 @@ int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spasm_amd_roun
 struct spasm_csr *spasm_amd_schur_plan_fetch(spasm_amd_schur_plan *plan, int *p_out);
 void spasm_amd_schur_plan_free(spasm_amd_schur_plan *plan);
 
+/* ---- row-sharded round with an exchange of the pivot rows (one process per GPU; the collectives are the
+ * caller's: torch.distributed / RCCL all-reduce(MIN) on the keys, all-gather on the exported rows) ----
+ * All `*_dev` arguments are DEVICE pointers owned by the caller.
+ *   1. shard_create   uploads rows [row_lo,row_hi) of A only
+ *   2. shard_elect    writes this shard's election keys, one i64 per column: (row length << 32 | global row),
+ *                     INT64_MAX where the shard proposes nothing            -> caller: all-reduce(MIN)
+ *   3. shard_set_keys takes the reduced keys, numbers the pivots; returns npiv (< 0 on error) and reports
+ *                     how many pivot rows / entries this shard owns         -> caller: all-gather of the counts
+ *   4. shard_export   packs the owned pivot rows: hdr_dev[2*k] = pivot index, hdr_dev[2*k+1] = length;
+ *                     ent_dev = their {col,val} pairs back to back          -> caller: all-gather (variable length)
+ *   5. shard_import   takes the concatenation over ranks (any order of parts), builds U; then plan_run /
+ *                     plan_stats / plan_fetch work on the returned plan for this shard's non-pivot rows. */
+typedef struct spasm_amd_shard spasm_amd_shard;
+spasm_amd_shard *spasm_amd_shard_create(const struct spasm_csr *A, int row_lo, int row_hi);
+int spasm_amd_shard_elect(spasm_amd_shard *sh, int64_t *keys_dev);
+int spasm_amd_shard_set_keys(spasm_amd_shard *sh, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned);
+int spasm_amd_shard_export(spasm_amd_shard *sh, int *hdr_dev, int *ent_dev);
+spasm_amd_schur_plan *spasm_amd_shard_import(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev);
+void spasm_amd_shard_free(spasm_amd_shard *sh);
+
 /* Per-round records of the most recent spasm_echelonize call on this thread. */
 int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds);
 

@@ -196,7 +196,8 @@ struct Round {
     {
         m = A.m;
         best.ensure((size_t)m + 1);
-        HIPCHK(hipMemsetAsync(best.p, 0xff, ((size_t)m + 1) * sizeof(u64d), stream));
+        hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best.p);
+        HIPCHK(hipGetLastError());
         if (A.n > 0) {
             hipLaunchKernelGGL(k_elect, dim3(cdiv(A.n, 256)), dim3(256), 0, stream, A.n, row_base, A.len.p, A.lead.p, best.p);
             HIPCHK(hipGetLastError());
@@ -1224,6 +1225,8 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact)
 // ------------------------------------------------------------------------------------------------
 struct spasm_amd_schur_plan {
     DevMat A;
+    DevMat PM;          // sharded runs: the imported pivot rows
+    DevBuf<int> rowsrc; // sharded runs: pivot index -> row of PM
     Round R;
     int lo = 0, hi = 0;
     i64 nnz_in = 0;
@@ -1232,6 +1235,145 @@ struct spasm_amd_schur_plan {
 };
 
 namespace {
+
+} // namespace
+
+struct spasm_amd_shard {
+    spasm_amd_schur_plan *plan = nullptr; // owns the shard's rows and the round; handed to the caller by shard_import
+    int n_total = 0;
+    int npiv = 0, nown = 0;
+    i64 nnz_own = 0;
+    DevBuf<int> oflag, oscan;
+    DevBuf<int2> ohdr;
+    DevBuf<i64d> olen, ooff;
+    bool imported = false;
+};
+
+namespace {
+
+spasm_amd_shard *shard_create(const struct spasm_csr *A, int lo, int hi)
+{
+    require_device();
+    check_input(A, "spasm_amd_shard_create");
+    if (lo < 0 || hi > A->n || lo > hi) throw EngineError("spasm_amd_shard_create: bad row range");
+    std::unique_ptr<spasm_amd_shard> S(new spasm_amd_shard());
+    std::unique_ptr<spasm_amd_schur_plan> P(new spasm_amd_schur_plan());
+    P->lo = lo;
+    P->hi = hi;
+    P->prime = A->field->p;
+    P->nnz_in = A->p[hi] - A->p[lo];
+    hipStream_t s = nullptr;
+    upload_csr(A, lo, hi, P->A, s); // only this shard's rows; orig = global row ids
+    P->R.F = zp_field_make(P->prime);
+    P->R.stream = s;
+    S->n_total = A->n;
+    S->plan = P.release();
+    return S.release();
+}
+
+void shard_elect(spasm_amd_shard *S, int64_t *keys_dev)
+{
+    Round &R = S->plan->R;
+    R.elect_local(S->plan->A, S->plan->lo);
+    HIPCHK(hipMemcpyAsync(keys_dev, R.best.p, (size_t)S->plan->A.m * sizeof(u64d), hipMemcpyDeviceToDevice, R.stream));
+    HIPCHK(hipStreamSynchronize(R.stream));
+}
+
+int shard_set_keys(spasm_amd_shard *S, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned)
+{
+    spasm_amd_schur_plan *P = S->plan;
+    Round &R = P->R;
+    hipStream_t s = R.stream;
+    const int m = P->A.m;
+    R.m = m;
+    R.best.ensure((size_t)m + 1);
+    HIPCHK(hipMemcpyAsync(R.best.p, keys_dev, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice, s));
+    R.assign_pivots();
+    R.mark_local(P->A, P->lo); // local non-pivot rows; pivrow holds global ids
+    S->npiv = R.npiv;
+    // owned pivot rows, in ascending pivot index
+    const int np = R.npiv;
+    S->oflag.alloc((size_t)np + 1);
+    S->oscan.alloc((size_t)np + 1);
+    hipLaunchKernelGGL(k_owned_flags, dim3(cdiv((i64)np + 1, 256)), dim3(256), 0, s, np, P->lo, P->hi, R.pivrow.p, S->oflag.p);
+    HIPCHK(hipGetLastError());
+    R.scan.exclusive(S->oflag.p, S->oscan.p, (size_t)np + 1, s);
+    HIPCHK(hipMemcpyAsync(&S->nown, S->oscan.p + np, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    S->ohdr.alloc((size_t)S->nown + 1);
+    S->olen.alloc((size_t)S->nown + 1);
+    S->ooff.alloc((size_t)S->nown + 1);
+    HIPCHK(hipMemsetAsync(S->olen.p + S->nown, 0, sizeof(i64d), s));
+    if (np > 0) {
+        hipLaunchKernelGGL(k_export_hdr, dim3(cdiv(np, 256)), dim3(256), 0, s, np, P->lo, S->oflag.p, S->oscan.p, R.pivrow.p, P->A.len.p, S->ohdr.p, S->olen.p);
+        HIPCHK(hipGetLastError());
+    }
+    R.scan.exclusive(S->olen.p, S->ooff.p, (size_t)S->nown + 1, s);
+    i64d tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, S->ooff.p + S->nown, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    S->nnz_own = tot;
+    if (n_owned) *n_owned = S->nown;
+    if (nnz_owned) *nnz_owned = tot;
+    return np;
+}
+
+void shard_export(spasm_amd_shard *S, int *hdr_dev, int *ent_dev)
+{
+    spasm_amd_schur_plan *P = S->plan;
+    Round &R = P->R;
+    hipStream_t s = R.stream;
+    if (S->nown > 0) {
+        HIPCHK(hipMemcpyAsync(hdr_dev, S->ohdr.p, (size_t)S->nown * sizeof(int2), hipMemcpyDeviceToDevice, s));
+        constexpr int TEAM = 16;
+        hipLaunchKernelGGL((k_export_rows<TEAM>), dim3(cdiv((i64)S->nown * TEAM, 256)), dim3(256), 0, s, S->nown, P->lo, S->ohdr.p, S->ooff.p, R.pivrow.p,
+                           P->A.start.p, P->A.ent.p, (int2 *)ent_dev);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(s));
+}
+
+spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev)
+{
+    spasm_amd_schur_plan *P = S->plan;
+    if (!P) throw EngineError("spasm_amd_shard_import: already imported");
+    Round &R = P->R;
+    hipStream_t s = R.stream;
+    if (n_rows != R.npiv) throw EngineError("spasm_amd_shard_import: the parts do not add up to the elected pivots");
+    DevMat &PM = P->PM;
+    PM.n = n_rows;
+    PM.m = P->A.m;
+    PM.start.alloc((size_t)n_rows + 1);
+    PM.len.alloc((size_t)n_rows + 1);
+    PM.lead.alloc(1);
+    PM.orig.alloc((size_t)n_rows + 1);
+    PM.ent.alloc((size_t)n_entries + 1);
+    P->rowsrc.alloc((size_t)n_rows + 1);
+    DevBuf<i64d> l64, off;
+    l64.alloc((size_t)n_rows + 1);
+    off.alloc((size_t)n_rows + 1);
+    hipLaunchKernelGGL(k_hdr_len64, dim3(cdiv((i64)n_rows + 1, 256)), dim3(256), 0, s, n_rows, (const int2 *)hdr_dev, l64.p);
+    HIPCHK(hipGetLastError());
+    R.scan.exclusive(l64.p, off.p, (size_t)n_rows + 1, s);
+    i64d tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, off.p + n_rows, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (tot != n_entries) throw EngineError("spasm_amd_shard_import: header lengths do not match the entry count");
+    if (n_rows > 0) {
+        hipLaunchKernelGGL(k_import_rows, dim3(cdiv(n_rows, 256)), dim3(256), 0, s, n_rows, (const int2 *)hdr_dev, off.p, PM.start.p, PM.len.p, PM.orig.p, P->rowsrc.p);
+        HIPCHK(hipGetLastError());
+    }
+    if (n_entries > 0) HIPCHK(hipMemcpyAsync(PM.ent.p, ent_dev, (size_t)n_entries * sizeof(int2), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipEventRecord(R.ev[0], s));
+    R.build_U(PM, P->rowsrc.p);
+    R.prepare_uinv(R.nnp);
+    HIPCHK(hipEventRecord(R.ev[1], s));
+    const i64 tb = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, 4 * std::max<i64>(P->nnz_in, 1 << 14));
+    R.S.ent.ensure((size_t)tb + 1);
+    S->plan = nullptr; // ownership passes to the caller
+    S->imported = true;
+    return P;
+}
 
 spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi)
 {
@@ -1414,6 +1556,67 @@ SPASM_API struct spasm_csr *spasm_amd_schur_plan_fetch(spasm_amd_schur_plan *pla
 }
 
 SPASM_API void spasm_amd_schur_plan_free(spasm_amd_schur_plan *plan) { delete plan; }
+
+SPASM_API spasm_amd_shard *spasm_amd_shard_create(const struct spasm_csr *A, int row_lo, int row_hi)
+{
+    spasm_clear_error();
+    try {
+        return shard_create(A, row_lo, row_hi);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_create: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API int spasm_amd_shard_elect(spasm_amd_shard *sh, int64_t *keys_dev)
+{
+    try {
+        shard_elect(sh, keys_dev);
+        return 0;
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_elect: %s", e.what());
+        return 1;
+    }
+}
+
+SPASM_API int spasm_amd_shard_set_keys(spasm_amd_shard *sh, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned)
+{
+    try {
+        return shard_set_keys(sh, keys_dev, n_owned, nnz_owned);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_set_keys: %s", e.what());
+        return -1;
+    }
+}
+
+SPASM_API int spasm_amd_shard_export(spasm_amd_shard *sh, int *hdr_dev, int *ent_dev)
+{
+    try {
+        shard_export(sh, hdr_dev, ent_dev);
+        return 0;
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_export: %s", e.what());
+        return 1;
+    }
+}
+
+SPASM_API spasm_amd_schur_plan *spasm_amd_shard_import(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev)
+{
+    spasm_clear_error();
+    try {
+        return shard_import(sh, n_rows, n_entries, hdr_dev, ent_dev);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_import: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API void spasm_amd_shard_free(spasm_amd_shard *sh)
+{
+    if (!sh) return;
+    delete sh->plan;
+    delete sh;
+}
 
 SPASM_API int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds)
 {

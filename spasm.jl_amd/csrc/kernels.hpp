@@ -28,7 +28,7 @@ typedef long long i64d;
 typedef unsigned long long u64d;
 
 #define EMPTY_KEY (-1)
-#define NO_BEST (~0ull)
+#define NO_BEST 0x7fffffffffffffffull   // larger than any (len << 32 | row) key, also as a SIGNED 64-bit value (all-reduce MIN)
 
 // header of a pivot row: off = offset of its slot in UPP/UPN/Ufull, npp/npn = entries on pivot /
 // non-pivot columns (pivot entry itself excluded), len = full length (npp + npn + 1)
@@ -148,6 +148,12 @@ __global__ void k_elect(int n, int row_base, const int *__restrict__ len, const 
     const int ln = len[i];
     if (ln <= 0) return;
     atomicMin(&best[lead[i]], ((u64d)(unsigned)ln << 32) | (u64d)(unsigned)(row_base + i));
+}
+
+__global__ void k_fill_u64(i64d n, u64d v, u64d *__restrict__ out)
+{
+    i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
 }
 
 __global__ void k_col_flags(int m, const u64d *__restrict__ best, int *__restrict__ flag)
@@ -1636,4 +1642,60 @@ __global__ void k_kfill(int nfree, const int *__restrict__ freecol, const int *_
         if (r.y != 0) Kent[pos + __popcll(m & lanemask_lt())] = make_int2(colof[r.x], r.y);
         pos += __popcll(m);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU exchange of the elected pivot rows: a rank exports the pivot rows it owns,
+// every rank imports the concatenation (rank-major, each part in ascending pivot index)
+// ------------------------------------------------------------------------------------------------
+// owned[idx] = 1 when pivot idx is a local row
+__global__ void k_owned_flags(int npiv, int row_lo, int row_hi, const int *__restrict__ pivrow, int *__restrict__ flag)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < npiv) flag[idx] = pivrow[idx] >= row_lo && pivrow[idx] < row_hi;
+    if (idx == npiv) flag[idx] = 0;
+}
+
+// header (pivot index, length) of each owned pivot row, in ascending pivot index
+__global__ void k_export_hdr(int npiv, int row_lo, const int *__restrict__ flag, const int *__restrict__ scan, const int *__restrict__ pivrow,
+                             const int *__restrict__ len, int2 *__restrict__ hdr, i64d *__restrict__ olen)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npiv || !flag[idx]) return;
+    const int l = len[pivrow[idx] - row_lo];
+    hdr[scan[idx]] = make_int2(idx, l);
+    olen[scan[idx]] = l;
+}
+
+template <int TEAM>
+__global__ void k_export_rows(int nown, int row_lo, const int2 *__restrict__ hdr, const i64d *__restrict__ ooff, const int *__restrict__ pivrow,
+                              const i64d *__restrict__ start, const int2 *__restrict__ ent, int2 *__restrict__ out)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int k = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (k >= nown) return;
+    const int2 h = hdr[k];
+    const i64d st = start[pivrow[h.x] - row_lo];
+    const i64d os = ooff[k];
+    for (int i = tl; i < h.y; i += TEAM) out[os + i] = ent[st + i];
+}
+
+// imported headers -> row table of the pivot-row matrix PM and rowsrc[pivot index] = row of PM
+__global__ void k_import_rows(int ntot, const int2 *__restrict__ hdr, const i64d *__restrict__ off, i64d *__restrict__ start, int *__restrict__ len,
+                              int *__restrict__ orig, int *__restrict__ rowsrc)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntot) return;
+    const int2 h = hdr[k];
+    start[k] = off[k];
+    len[k] = h.y;
+    orig[k] = k;
+    rowsrc[h.x] = k;
+}
+
+__global__ void k_hdr_len64(int n, const int2 *__restrict__ hdr, i64d *__restrict__ out)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = hdr[k].y;
+    if (k == n) out[k] = 0;
 }

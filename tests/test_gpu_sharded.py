@@ -1,0 +1,79 @@
+"""GPU test of the row-sharded round with the real exchange path (spasm_amd_shard_* through the C ABI):
+two ranks share the one GPU of the test box, collectives over gloo; shards must concatenate to the
+oracle's unsharded Schur complement and their work counters must add up."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, k, p, seed, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import torch
+    import torch.distributed as dist
+
+    import spasm_jl_amd as S
+    from spasm_jl_amd import sharded
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        lib = S._abi.lib()
+        A = S.synth_csr(1, n, n, row_nnz=k, prime=p, seed=seed)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        eng = sharded.GpuShardEngine(A, lo, hi)
+        npiv, info = sharded.exchange_pivot_rows(eng)
+        assert lib.spasm_amd_schur_plan_run(eng.plan, None) == 0, S._abi.last_error()
+        st = S._abi.RoundStats()
+        assert lib.spasm_amd_schur_plan_stats(eng.plan, C.byref(st)) == 0, S._abi.last_error()
+        p_out = np.empty(max(hi - lo, 1), dtype=np.int32)
+        ptr = lib.spasm_amd_schur_plan_fetch(eng.plan, p_out.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert ptr, S._abi.last_error()
+        Sc = S.CSR(ptr)
+        q.put((rank, npiv, info, st.nnz_reduced, st.applications, p_out[: Sc.n].tolist(), Sc.rows()))
+        eng.close()
+    except Exception as exc:
+        q.put((rank, -1, {"error": repr(exc)}, 0, 0, [], []))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,k,p", [(2, 6000, 10, 65521), (3, 3001, 7, 2147483647)])
+def test_sharded_round_with_exchange(S, O, world, n, k, p):
+    seed = 31
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, k, p, seed, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] >= 0 for r in results), [r[2] for r in results]
+    assert all(pr.exitcode == 0 for pr in procs)
+    results.sort()
+    A = S.synth_csr(1, n, n, row_nnz=k, prime=p, seed=seed)
+    So, info = O.schur_round(A)
+    assert all(r[1] == info["npiv"] for r in results)
+    assert sum(r[2]["owned_rows"] for r in results) == info["npiv"]
+    assert sum(r[3] for r in results) == info["nnz_reduced"]
+    assert sum(r[4] for r in results) == info["applications"]
+    origs = [g for r in results for g in r[5]]
+    assert origs == sorted(origs)  # global row ids, shard order = row order
+    assert [row for r in results for row in r[6]] == So.rows()

@@ -1,0 +1,131 @@
+"""The multi-GPU exchange protocol (spasm.jl_amd/sharded.py) on CPU: two gloo ranks, a numpy engine standing
+in for the device, result compared with the oracle's unsharded Schur round."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+INT64_MAX = np.iinfo(np.int64).max
+
+
+class NumpyShardEngine:
+    """Same contract as GpuShardEngine, plain numpy/python (test double; the Schur rows come from a python elimination)."""
+
+    def __init__(self, rows, m, lo, p):
+        self.rows, self.m, self.lo, self.p = rows, m, lo, p  # rows: this shard's rows, lists of (col, val)
+
+    def elect(self):
+        keys = np.full(self.m, INT64_MAX, dtype=np.int64)
+        for i, r in enumerate(self.rows):
+            if r:
+                lead = min(c for c, _ in r)
+                keys[lead] = min(keys[lead], (len(r) << 32) | (self.lo + i))
+        return torch.from_numpy(keys)
+
+    def set_keys(self, keys):
+        keys = keys.numpy()
+        self.pivcols = [j for j in range(self.m) if keys[j] != INT64_MAX]
+        self.pivrow = [int(keys[j] & 0xFFFFFFFF) for j in self.pivcols]
+        self.owned = [(idx, g - self.lo) for idx, g in enumerate(self.pivrow) if self.lo <= g < self.lo + len(self.rows)]
+        return len(self.pivcols), len(self.owned), sum(len(self.rows[i]) for _, i in self.owned)
+
+    def export(self):
+        hdr = np.array([[idx, len(self.rows[i])] for idx, i in self.owned], dtype=np.int32).reshape(-1, 2)
+        ent = np.array([e for _, i in self.owned for e in self.rows[i]], dtype=np.int32).reshape(-1, 2)
+        return torch.from_numpy(hdr), torch.from_numpy(ent)
+
+    def import_(self, hdr_all, ent_all):
+        hdr_all, ent_all = hdr_all.numpy(), ent_all.numpy()
+        self.U = {}
+        k = 0
+        for idx, ln in hdr_all:
+            row = [(int(c), int(v)) for c, v in ent_all[k:k + ln]]
+            k += ln
+            pc = self.pivcols[idx]
+            inv = pow(dict(row)[pc] % self.p, -1, self.p)
+            self.U[pc] = [(c, v * inv % self.p) for c, v in row]
+
+    def schur_rows(self):
+        p = self.p
+        mine = {i for _, i in self.owned}
+        out = []
+        for i, r in enumerate(self.rows):
+            if i in mine or not r:
+                continue
+            x = {c: v % p for c, v in r}
+            while True:
+                cand = [c for c in x if c in self.U and x[c]]
+                if not cand:
+                    break
+                c = min(cand)
+                f = x[c]
+                for cc, vv in self.U[c]:
+                    x[cc] = (x.get(cc, 0) - f * vv) % p
+            out.append((self.lo + i, sorted((c, v - p if 2 * v > p else v) for c, v in x.items() if v and c not in self.U)))
+        return out
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, m, k, p, seed, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import spasm_jl_amd as S
+    from spasm_jl_amd import sharded
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        A = S.synth_csr(1, n, m, row_nnz=k, prime=p, seed=seed)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        eng = NumpyShardEngine(A.rows()[lo:hi], m, lo, p)
+        npiv, info = sharded.exchange_pivot_rows(eng)
+        q.put((rank, npiv, info, eng.schur_rows()))
+    except Exception as exc:  # surface the failure to the parent instead of letting it time out
+        q.put((rank, -1, {"error": repr(exc)}, []))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_protocol_two_ranks_gloo(S, O):
+    n, m, k, p, seed = 400, 450, 6, 65521, 99
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, m, k, p, seed, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    assert all(r[1] >= 0 for r in results), results
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    A = S.synth_csr(1, n, m, row_nnz=k, prime=p, seed=seed)
+    So, info = O.schur_round(A)
+    results.sort()
+    assert all(r[1] == info["npiv"] for r in results)
+    assert sum(r[2]["owned_rows"] for r in results) == info["npiv"]
+    assert all(r[2]["gathered_rows"] == info["npiv"] for r in results)
+    got = [row for r in results for row in r[3]]
+    got.sort()
+    assert [row for _, row in got] == So.rows()
+
+
+def test_collectives_degenerate_to_identity_without_a_group():
+    from spasm_jl_amd import sharded
+
+    t = torch.arange(6, dtype=torch.int64)
+    assert sharded.all_reduce_min(t) is t
+    assert sharded.all_gather_var(t.reshape(3, 2), [3]).shape == (3, 2)
+    assert sharded.all_gather_counts([4, 5]).tolist() == [[4, 5]]
