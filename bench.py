@@ -6,7 +6,9 @@ One "step" = one pass of the hot path over the synthetic matrix: the Schur round
 all work buffers already resident in HBM.  With N GPUs (one process per GPU, launched by
 torch.distributed.run) the non-pivot rows are block-partitioned over the ranks (BASELINE config 4,
 strong scaling: the matrix is fixed); every rank elects the same pivots and holds the same U, rows
-never move, and the only collectives are the timing barrier and the final sum of the counters.
+never move.  For N > 1 every rank uploads only its row block and the round's pivot rows are exchanged once in
+the setup (all-reduce(MIN) of the election keys + all-gather of the elected rows, RCCL over xGMI;
+SPASM_BENCH_EXCHANGE=0 replicates the matrix instead); the timed region has no data-path collective.
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the scatter launch of
 the busiest hash-table class): algorithmic bytes per launch over its HIP-event duration on the
@@ -24,6 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# scatter launch of each hash-table class (spasm.jl_amd/csrc/engine.hip, kClasses), p < 2^16
+SCATTER_KERNEL_NAMES = ["k_scatter<8, 64, 4, 1, true>", "k_scatter<9, 64, 4, 2, true>", "k_scatter<10, 64, 4, 4, true>",
+                        "k_scatter<11, 256, 4, 2, true>", "k_scatter<12, 256, 4, 4, true>", "k_scatter<13, 256, 4, 5, true>",
+                        "k_scatter<14, 256, 4, 5, true>", None]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -131,6 +137,16 @@ def main():
         k_bytes = 8 * d["ent_class"][cls] + 16 * d["seg_class"][cls]
         k_ms = d["ms_class"][cls]
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # HBM traffic of that kernel from the PMC counters (collected in separate rocprofv3 passes and calibrated for
+        # this access shape, profiles/r01_final_traffic.json); only quoted for the workload it was measured on
+        kname = SCATTER_KERNEL_NAMES[cls] if args.prime < 65536 else None
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")))["kernels"]
+            if world == 1 and n == 1_000_000 and args.row_nnz == 20 and kname in prof:
+                traffic = prof[kname]["fetch_bytes"] + prof[kname]["write_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
             "bound": "hbm",
             "kernel": f"k_scatter class {cls} ({d['rows_class'][cls]} rows)",
@@ -138,7 +154,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "bytes_per_launch": k_bytes,
             "ms_per_launch": round(k_ms, 4),
             "round_algorithmic_read_GBs": round(d["read_bytes"] / ((d["ms_solve"] + d["ms_scatter"]) * 1e-3) / 1e9, 1)
