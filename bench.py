@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # scatter launch of each hash-table class (spasm.jl_amd/csrc/engine.hip, kClasses), p < 2^16
 SCATTER_KERNEL_NAMES = ["k_scatter<8, 64, 4, 1, true>", "k_scatter<9, 64, 4, 2, true>", "k_scatter<10, 64, 4, 4, true>",
-                        "k_scatter<11, 256, 4, 2, true>", "k_scatter<12, 256, 4, 4, true>", "k_scatter<13, 256, 4, 5, true>",
+                        "k_scatter<11, 128, 2, 4, true>", "k_scatter<12, 256, 4, 4, true>", "k_scatter<13, 256, 4, 5, true>",
                         "k_scatter<14, 256, 4, 5, true>", None]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 

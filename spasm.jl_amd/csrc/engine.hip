@@ -84,7 +84,7 @@ struct Scanner {
 // hash-table classes of the scatter kernel: log2(slots), threads per row, waves per workgroup,
 // unrolled rounds of pivot rows, largest row bound (load factor <= 5/8)
 struct ScatterClass { int logt, tpr, wpb, maxr; i64 cap; };
-const ScatterClass kClasses[7] = {{8, 64, 4, 1, 160},  {9, 64, 4, 2, 320},   {10, 64, 4, 4, 640},  {11, 256, 4, 2, 1280},
+const ScatterClass kClasses[7] = {{8, 64, 4, 1, 160},  {9, 64, 4, 2, 320},   {10, 64, 4, 4, 640},  {11, 128, 2, 4, 1280},
                                   {12, 256, 4, 4, 2560}, {13, 256, 4, 5, 5120}, {14, 256, 4, 5, 10240}};
 const int kNumHashClasses = 7;
 
@@ -111,7 +111,7 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
     case 0: launch_scatter<8, 64, 4, 1, SMALL>(a, grid, lds, s); break;
     case 1: launch_scatter<9, 64, 4, 2, SMALL>(a, grid, lds, s); break;
     case 2: launch_scatter<10, 64, 4, 4, SMALL>(a, grid, lds, s); break;
-    case 3: launch_scatter<11, 256, 4, 2, SMALL>(a, grid, lds, s); break;
+    case 3: launch_scatter<11, 128, 2, 4, SMALL>(a, grid, lds, s); break;
     case 4: launch_scatter<12, 256, 4, 4, SMALL>(a, grid, lds, s); break;
     case 5: launch_scatter<13, 256, 4, 5, SMALL>(a, grid, lds, s); break;
     case 6: if (SMALL) launch_scatter<14, 256, 4, 5, true>(a, grid, lds, s); break;

@@ -590,20 +590,23 @@ struct ScatterArgs {
 
 // ------------------------------------------------------------------------------------------------
 // LDS hash table of one Schur row: open addressing with double hashing (the probe step is odd, so
-// it visits every slot of the power-of-two table).  Small primes: one 8-byte slot {column, i32
-// accumulator} (64-bit LDS reads / resets in the sweep); large primes: column array + i64 array.
+// it visits every slot of the power-of-two table).  Column array + accumulator array (i32 lazy for
+// small primes, i64 otherwise).
 // ------------------------------------------------------------------------------------------------
 template <int LOGT, bool SMALL> struct RowTable;
 
 template <int LOGT> struct RowTable<LOGT, true> {
+    // keys and accumulators in SEPARATE arrays: with interleaved {key,val} slots every CAS lands on an even bank and
+    // every add on an odd one, i.e. half the banks per instruction (tools/lds_bank_bench.hip: 2.7 vs 3.8 inserts/clk/CU)
     static constexpr int T = 1 << LOGT;
     static constexpr size_t BYTES = (size_t)T * 8;
-    int2 *t;
-    __device__ __forceinline__ void bind(unsigned char *base) { t = (int2 *)base; }
-    __device__ __forceinline__ int *keyp(unsigned h) { return &t[h].x; }
-    __device__ __forceinline__ void add(unsigned h, int v) { atomicAdd(&t[h].y, v); }
-    __device__ __forceinline__ void clear(int s) { t[s] = make_int2(EMPTY_KEY, 0); }
-    __device__ __forceinline__ void read(int s, int &key, int &acc) { const int2 e = t[s]; key = e.x; acc = e.y; }
+    int *key;
+    int *val;
+    __device__ __forceinline__ void bind(unsigned char *base) { key = (int *)base; val = key + T; }
+    __device__ __forceinline__ int *keyp(unsigned h) { return &key[h]; }
+    __device__ __forceinline__ void add(unsigned h, int v) { atomicAdd(&val[h], v); }
+    __device__ __forceinline__ void clear(int s) { key[s] = EMPTY_KEY; val[s] = 0; }
+    __device__ __forceinline__ void read(int s, int &k, int &acc) { k = key[s]; acc = val[s]; }
 };
 
 template <int LOGT> struct RowTable<LOGT, false> {
