@@ -164,6 +164,11 @@ struct Round {
     // scatter
     DevBuf<int> class_count, class_list;
     DevBuf<RowDesc> class_desc;
+    // last-resort scatter (dense accumulator + bitmap + touched list over the columns, per workgroup)
+    int bigsc_blocks = 0, bigsc_m = -1;
+    DevBuf<long long> sc_xdense;
+    DevBuf<unsigned> sc_bitmap;
+    DevBuf<int> sc_touched;
     DevBuf<u64d> stamps;            // diagnostic build only
     DevMat S;
     i64 s_capacity = 0;      // entries S.ent can hold (sum of bounds at the time it was sized)
@@ -623,6 +628,32 @@ struct Round {
             else launch_scatter_class<false>(c, a, grid, lds, stream);
         }
         HIPCHK(hipEventRecord(ev_cls[nhash], stream));
+        {
+            // rows that fit no LDS table: the last class, through the global-memory kernel
+            if (bigsc_m != m) {
+                const i64 per = std::max<i64>((i64)m, 1) * 13; // bytes per workgroup: 8 accumulator + 4 list + bitmap
+                bigsc_blocks = (int)std::max<i64>(1, std::min<i64>(32, ((i64)1 << 30) / per));
+                bigsc_m = m;
+                const size_t nw = ((size_t)std::max(m, 1) + 31) / 32;
+                sc_xdense.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));
+                sc_bitmap.alloc((size_t)bigsc_blocks * nw);
+                sc_touched.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));
+                sc_xdense.zero(stream);
+                sc_bitmap.zero(stream);
+            }
+            BigScatterArgs bb;
+            bb.s = a;
+            bb.s.cls = NCLASS - 1;
+            bb.s.class_count = class_count.p + (NCLASS - 1);
+            bb.s.desc = class_desc.p + (size_t)(NCLASS - 1) * nrows;
+            bb.m = std::max(m, 1);
+            bb.nwords = (std::max(m, 1) + 31) / 32;
+            bb.xdense = sc_xdense.p;
+            bb.bitmap = sc_bitmap.p;
+            bb.touched = sc_touched.p;
+            hipLaunchKernelGGL(k_scatter_big, dim3(bigsc_blocks), dim3(256), 0, stream, bb);
+            HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_scatter_mark_failed, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, Llen.p, S.len.p, S.lead.p);
         HIPCHK(hipGetLastError());
         // the Schur rows start where their slots start
@@ -651,7 +682,6 @@ struct Round {
 #endif
         if (hctr.lpool_overflow) throw EngineError("multiplier pool exhausted");
         if (hctr.scatter_overflow) throw EngineError("a hash table of the scatter kernel filled up (internal bound violated)");
-        if (cc[NCLASS - 1] > 0) throw EngineError("a Schur row needs more than the largest LDS hash table: beyond this build's scatter classes");
     }
 };
 

@@ -939,6 +939,96 @@ __global__ __launch_bounds__(WPB * 64) void k_scatter(ScatterArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SCATTER, unbounded rows (last resort): one workgroup per row, a dense i64 accumulator over the
+// columns and a touched-bitmap in global memory (both all-zero between rows), the list of touched
+// columns beside them.  Only rows whose bound exceeds the largest LDS table come here.
+// ------------------------------------------------------------------------------------------------
+struct BigScatterArgs {
+    ScatterArgs s;
+    int m;
+    int nwords;            // (m + 31) / 32
+    long long *xdense;     // [gridDim.x][m]
+    unsigned *bitmap;      // [gridDim.x][nwords]
+    int *touched;          // [gridDim.x][m]
+};
+
+__global__ __launch_bounds__(256) void k_scatter_big(BigScatterArgs b)
+{
+    const ScatterArgs &a = b.s;
+    __shared__ int s_ntouch, s_nout, s_lead;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const ZpField F = a.F;
+    long long *x = b.xdense + (size_t)blockIdx.x * b.m;
+    unsigned *bm = b.bitmap + (size_t)blockIdx.x * b.nwords;
+    int *tl = b.touched + (size_t)blockIdx.x * b.m;
+    const int count = *a.class_count;
+    u64d c_ent = 0, c_seg = 0;
+    auto add = [&](int c, int v) {
+        atomicAdd((u64d *)&x[c], (u64d)(long long)v);
+        const unsigned bit = 1u << (c & 31);
+        const unsigned old = atomicOr(&bm[c >> 5], bit);
+        if (!(old & bit)) tl[atomicAdd(&s_ntouch, 1)] = c;
+    };
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const RowDesc d = a.desc[w];
+        if (tid == 0) { s_ntouch = 0; s_nout = 0; s_lead = INT_MAX; }
+        __syncthreads();
+        for (int k = tid; k < d.len; k += 256) {
+            const int2 e = a.ent[d.ent_start + k];
+            if (a.qinv_r[e.x] < 0) add(e.x, e.y);
+        }
+        // 8-lane groups stream the pivot rows, as in the LDS kernel
+        const int gg = tid >> 3, gl = tid & 7;
+        for (int e = gg; e < d.llen; e += 32) {
+            const int4 le = a.Lpool[d.l_start + e];
+            if (le.y == 0) continue;
+            if (gl == 0) { c_ent += (u64d)le.w; c_seg += 1; }
+            const int nm = zp_neg(F, le.y);
+            const int2 *up = a.UPN + (unsigned)le.z;
+            for (int k = gl; k < le.w; k += 8) { const int2 u = up[k]; add(u.x, zp_mul(F, nm, u.y)); }
+        }
+        __syncthreads();
+        const int nt = s_ntouch;
+        for (int i0 = 0; i0 < nt; i0 += 256) {
+            const int i = i0 + tid;
+            int c = 0, v = 0;
+            if (i < nt) {
+                c = tl[i];
+                v = zp_reduce(F, x[c]);
+                x[c] = 0;
+                bm[c >> 5] = 0;
+            }
+            const u64d m = __ballot(v != 0);
+            if (m) {
+                int pos = 0;
+                if (lane == 0) pos = atomicAdd(&s_nout, __popcll(m));
+                pos = __builtin_amdgcn_readfirstlane(pos);
+                if (v != 0) {
+                    a.Sent[d.s_start + pos + __popcll(m & lanemask_lt())] = make_int2(c, v);
+                    atomicMin(&s_lead, c);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            a.Slen[d.t] = s_nout;
+            a.Slead[d.t] = s_lead;
+            a.Sorig[d.t] = d.orig;
+            atomicAdd(&a.ctr->nnz_out, (u64d)s_nout);
+            if (s_nout > 0) atomicAdd(&a.ctr->nonempty_out, 1);
+            c_ent += (u64d)d.len;
+            c_seg += 1;
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) { c_ent += __shfl_xor(c_ent, o); c_seg += __shfl_xor(c_seg, o); }
+    if (lane == 0 && (c_ent | c_seg)) {
+        atomicAdd(&a.ctr->class_ent[a.cls & 7], c_ent);
+        atomicAdd(&a.ctr->class_seg[a.cls & 7], c_seg);
+    }
+}
+
 // rows that were not processed (no class): publish empty rows so that the output is well defined
 __global__ void k_scatter_mark_failed(int nrows, const int *__restrict__ Llen, int *__restrict__ Slen, int *__restrict__ Slead)
 {

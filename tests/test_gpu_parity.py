@@ -250,6 +250,27 @@ def test_schur_round_deep_chains(S, O):
     assert Sc.rows() == So.rows()
 
 
+def test_schur_round_rows_beyond_every_lds_table(S, O):
+    """Schur rows with more than 10240 distinct columns: the global-memory scatter class."""
+    p = 65521
+    m = 40000
+    rng = np.random.default_rng(8)
+    rows = []
+    npv = 60
+    for i in range(npv):  # heavy pivot rows: leading entry i, then 500 entries far to the right
+        cols = sorted(set(int(x) for x in rng.integers(npv, m, size=500)))
+        rows.append([(i, int(rng.integers(1, p)))] + [(c, int(rng.integers(1, p))) for c in cols])
+    for k in range(12):  # probe rows hitting most pivots: heavier than any pivot row so they stay non-pivotal
+        cols = sorted(set(list(range(0, npv, 1 + k % 2)) + [int(x) for x in rng.integers(npv, m, size=700)]))
+        rows.append([(c, int(rng.integers(1, p))) for c in cols])
+    A = S.CSR.from_rows(rows, m, prime=p)
+    Sc, st, p_out = run_plan(S, A)
+    So, info = O.schur_round(A)
+    assert max(len(r) for r in So.rows()) > 10240
+    assert st["npiv"] == info["npiv"] and st["nnz_reduced"] == info["nnz_reduced"] and st["nnz_out"] == info["nnz_out"]
+    assert Sc.rows() == So.rows()
+
+
 def test_schur_round_sharded_rows(S, O):
     """Row shards reduce independently against the same U (multi-GPU partitioning)."""
     A = S.synth_csr(1, 6000, 6000, row_nnz=10, prime=65521, seed=31)
