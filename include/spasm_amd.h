@@ -51,8 +51,17 @@ struct spasm_csr {
     spasm_field field;
 };
 
-/* struct _Triplet, src/SpaSM.jl:234-243 (only named so that spasm_lu can point at it) */
-struct spasm_triplet;
+/* struct _Triplet, src/SpaSM.jl:234-243 (72 bytes) */
+struct spasm_triplet {
+    i64 nzmax;
+    i64 nz;
+    int n;
+    int m;
+    int *i;
+    int *j;
+    spasm_ZZp *x;
+    spasm_field field;
+};
 
 /* struct _LU, src/SpaSM.jl:262-270 (48 bytes) */
 struct spasm_lu {
@@ -95,6 +104,18 @@ void spasm_csr_free(struct spasm_csr *A);                            /* src/SpaS
 void spasm_lu_free(struct spasm_lu *N);                              /* src/SpaSM.jl:463 */
 int spasm_get_num_threads(void);                                     /* src/SpaSM.jl:470 */
 int spasm_get_thread_num(void);                                      /* src/SpaSM.jl:475 */
+
+/* ---- spasm_triplet.c / spasm_io.c surface: the SMS wire format ("n m M" header, 1-based "i j v" lines,
+ * "0 0 0" terminator; reference src/SpaSM.jl:1029-1042, :1063-1086).  Host-side I/O, no device work. ---- */
+struct spasm_triplet *spasm_triplet_alloc(int n, int m, i64 nzmax, i64 prime, bool with_values); /* src/SpaSM.jl:453 */
+void spasm_triplet_realloc(struct spasm_triplet *T, i64 nzmax);      /* src/SpaSM.jl:455 */
+void spasm_triplet_free(struct spasm_triplet *T);                    /* src/SpaSM.jl:457 */
+void spasm_add_entry(struct spasm_triplet *T, int i, int j, i64 x);  /* src/SpaSM.jl:486 */
+void spasm_triplet_transpose(struct spasm_triplet *T);               /* src/SpaSM.jl:491 */
+struct spasm_csr *spasm_compress(const struct spasm_triplet *T);     /* src/SpaSM.jl:493 */
+struct spasm_triplet *spasm_triplet_load(void *file, i64 prime, uint8_t *hash); /* FILE*, src/SpaSM.jl:501; hash = SHA-256 of the stream or NULL */
+void spasm_triplet_save(const struct spasm_triplet *T, void *file);  /* FILE*, src/SpaSM.jl:514 */
+void spasm_csr_save(const struct spasm_csr *A, void *file);          /* FILE*, src/SpaSM.jl:523 */
 
 /* ---- spasm_ZZp.c surface (commented-out binding at src/SpaSM.jl:65; arithmetic restated :73-88,:383-390) ---- */
 void spasm_field_init(i64 p, spasm_field F);

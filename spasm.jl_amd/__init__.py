@@ -10,20 +10,23 @@ from .api import (
     EchelonizeOpts,
     Field,
     SpasmError,
+    Triplet,
     ZZp,
     balanced,
     echelonize,
     kernel,
     last_rounds,
+    load,
     nnz,
     prime0,
     rank,
+    save,
     sparse,
     synth_csr,
     transpose,
 )
 
 __all__ = [
-    "CSR", "LU", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "kernel",
+    "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "kernel",
     "last_rounds", "nnz", "prime0", "rank", "sparse", "synth_csr", "transpose",
 ]

@@ -27,6 +27,19 @@ class CsrStruct(C.Structure):  # reference src/SpaSM.jl:126-134
     ]
 
 
+class TripletStruct(C.Structure):  # reference src/SpaSM.jl:234-243
+    _fields_ = [
+        ("nzmax", C.c_int64),
+        ("nz", C.c_int64),
+        ("n", C.c_int32),
+        ("m", C.c_int32),
+        ("i", C.POINTER(C.c_int32)),
+        ("j", C.POINTER(C.c_int32)),
+        ("x", C.POINTER(C.c_int32)),
+        ("field", Field),
+    ]
+
+
 class LuStruct(C.Structure):  # reference src/SpaSM.jl:262-270
     _fields_ = [
         ("r", C.c_int32),
@@ -90,6 +103,7 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
 EXPECTED_LAYOUT = {
     "Field": (32, {"p": 0, "halfp": 8, "mhalfp": 16, "dinvp": 24}),
     "CsrStruct": (72, {"nzmax": 0, "n": 8, "m": 12, "p": 16, "j": 24, "x": 32, "field": 40}),
+    "TripletStruct": (80, {"nzmax": 0, "nz": 8, "n": 16, "m": 20, "i": 24, "j": 32, "x": 40, "field": 48}),
     "LuStruct": (48, {"r": 0, "complete": 4, "L": 8, "U": 16, "qinv": 24, "p": 32, "Ltmp": 40}),
     "EchelonizeOptsStruct": (
         64,
@@ -125,6 +139,15 @@ SIGNATURES = {
     "spasm_get_thread_num": (C.c_int32, []),
     "spasm_field_init": (None, [C.c_int64, _P(Field)]),
     "spasm_transpose": (_P(CsrStruct), [_P(CsrStruct)]),
+    "spasm_triplet_alloc": (_P(TripletStruct), [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_bool]),
+    "spasm_triplet_realloc": (None, [_P(TripletStruct), C.c_int64]),
+    "spasm_triplet_free": (None, [_P(TripletStruct)]),
+    "spasm_add_entry": (None, [_P(TripletStruct), C.c_int32, C.c_int32, C.c_int64]),
+    "spasm_triplet_transpose": (None, [_P(TripletStruct)]),
+    "spasm_compress": (_P(CsrStruct), [_P(TripletStruct)]),
+    "spasm_triplet_load": (_P(TripletStruct), [C.c_void_p, C.c_int64, C.c_void_p]),
+    "spasm_triplet_save": (None, [_P(TripletStruct), C.c_void_p]),
+    "spasm_csr_save": (None, [_P(CsrStruct), C.c_void_p]),
     "spasm_echelonize_init_opts": (None, [_P(EchelonizeOptsStruct)]),
     "spasm_echelonize": (_P(LuStruct), [_P(CsrStruct), _P(EchelonizeOptsStruct)]),
     "spasm_kernel": (_P(CsrStruct), [_P(LuStruct)]),

@@ -372,3 +372,84 @@ def synth_csr(kind, n, m, density=0.0, row_nnz=0, prime=prime0, seed=0):
     if not ptr:
         raise SpasmError("spasm_amd_synth_csr failed: " + _abi.last_error())
     return CSR(ptr)
+
+
+# ---------------------------------------------------------------------------------------------
+# Triplets and the SMS wire format  (reference src/SpaSM.jl:234-260, :482-529, :1025-1086)
+# ---------------------------------------------------------------------------------------------
+_libc = C.CDLL(None)
+_libc.fopen.restype = C.c_void_p
+_libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+_libc.fclose.argtypes = [C.c_void_p]
+
+
+class Triplet:
+    """Spasm matrix in coordinate format; `push` then `compress` (reference src/SpaSM.jl:244-251, :482-493)."""
+
+    def __init__(self, n=0, m=0, nzmax=16, prime=prime0, ptr=None):
+        self.data = ptr if ptr is not None else _abi.lib().spasm_triplet_alloc(int(n), int(m), int(nzmax), int(prime), True)
+        if not self.data:
+            raise SpasmError("spasm_triplet_alloc failed: " + _abi.last_error())
+
+    def __del__(self):
+        if getattr(self, "data", None):
+            try:
+                _abi.lib().spasm_triplet_free(self.data)
+            except Exception:
+                pass
+            self.data = None
+
+    def push(self, i, j, x):
+        """push!(A, (i, j, x)) with 1-based indices (reference src/SpaSM.jl:482-488)."""
+        assert 1 <= i and 1 <= j
+        _abi.lib().spasm_add_entry(self.data, int(i) - 1, int(j) - 1, int(x))
+        return self
+
+    def transpose_(self):
+        _abi.lib().spasm_triplet_transpose(self.data)
+        return self
+
+    @property
+    def nz(self):
+        return int(self.data.contents.nz)
+
+    @property
+    def shape(self):
+        return (int(self.data.contents.n), int(self.data.contents.m))
+
+    def compress(self):
+        ptr = _abi.lib().spasm_compress(self.data)
+        if not ptr:
+            raise SpasmError("spasm_compress failed: " + _abi.last_error())
+        return CSR(ptr)
+
+
+def load(path, prime=prime0, csr=True, get_hash=False):
+    """load(File{format"SMS"}(path); prime, csr) (reference src/SpaSM.jl:498-512): Triplet, or CSR when csr=True."""
+    f = _libc.fopen(str(path).encode(), b"r")
+    if not f:
+        raise OSError(f"cannot open {path}")
+    try:
+        digest = (C.c_uint8 * 32)() if get_hash else None
+        ptr = _abi.lib().spasm_triplet_load(f, int(prime), digest)
+    finally:
+        _libc.fclose(f)
+    if not ptr:
+        raise SpasmError("spasm_triplet_load failed: " + _abi.last_error())
+    T = Triplet(ptr=ptr)
+    out = T.compress() if csr else T
+    return (out, bytes(digest)) if get_hash else out
+
+
+def save(path, A):
+    """save(File{format"SMS"}(path), A) for a CSR or a Triplet (reference src/SpaSM.jl:514-529)."""
+    f = _libc.fopen(str(path).encode(), b"w")
+    if not f:
+        raise OSError(f"cannot open {path}")
+    try:
+        if isinstance(A, Triplet):
+            _abi.lib().spasm_triplet_save(A.data, f)
+        else:
+            _abi.lib().spasm_csr_save(A.data, f)
+    finally:
+        _libc.fclose(f)

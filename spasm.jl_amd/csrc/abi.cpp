@@ -127,6 +127,224 @@ SPASM_API void spasm_lu_free(struct spasm_lu *N) // reference src/SpaSM.jl:463; 
     free(N);
 }
 
+// ------------------------------------------------------------------------------------------------
+// triplets and the SMS text format (reference src/SpaSM.jl:453-529; format :1029-1042, :1063-1086)
+// ------------------------------------------------------------------------------------------------
+SPASM_API struct spasm_triplet *spasm_triplet_alloc(int n, int m, i64 nzmax, i64 prime, bool with_values)
+{
+    struct spasm_triplet *T = (struct spasm_triplet *)malloc(sizeof *T);
+    if (!T) return nullptr;
+    const i64 cap = nzmax > 0 ? nzmax : 1;
+    T->nzmax = nzmax;
+    T->nz = 0;
+    T->n = n;
+    T->m = m;
+    T->i = (int *)malloc(sizeof(int) * (size_t)cap);
+    T->j = (int *)malloc(sizeof(int) * (size_t)cap);
+    T->x = with_values ? (spasm_ZZp *)malloc(sizeof(spasm_ZZp) * (size_t)cap) : nullptr;
+    spasm_field_init(prime, T->field);
+    return T;
+}
+
+SPASM_API void spasm_triplet_realloc(struct spasm_triplet *T, i64 nzmax)
+{
+    if (nzmax < 0) nzmax = T->nz;
+    const i64 cap = nzmax > 0 ? nzmax : 1;
+    T->i = (int *)realloc(T->i, sizeof(int) * (size_t)cap);
+    T->j = (int *)realloc(T->j, sizeof(int) * (size_t)cap);
+    if (T->x) T->x = (spasm_ZZp *)realloc(T->x, sizeof(spasm_ZZp) * (size_t)cap);
+    T->nzmax = nzmax;
+}
+
+SPASM_API void spasm_triplet_free(struct spasm_triplet *T)
+{
+    if (!T) return;
+    free(T->i); free(T->j); free(T->x); free(T);
+}
+
+// value reduced to its balanced representative (reference src/SpaSM.jl:955-958); zeros are not stored
+SPASM_API void spasm_add_entry(struct spasm_triplet *T, int i, int j, i64 x)
+{
+    const i64 p = T->field->p;
+    i64 v = x % p;
+    if (v < 0) v += p;
+    if (v > T->field->halfp) v -= p;
+    if (T->x && v == 0) return;
+    if (T->nz == T->nzmax) spasm_triplet_realloc(T, 2 * T->nzmax + 1);
+    T->i[T->nz] = i;
+    T->j[T->nz] = j;
+    if (T->x) T->x[T->nz] = (spasm_ZZp)v;
+    T->nz++;
+    if (i + 1 > T->n) T->n = i + 1;
+    if (j + 1 > T->m) T->m = j + 1;
+}
+
+SPASM_API void spasm_triplet_transpose(struct spasm_triplet *T)
+{
+    std::swap(T->i, T->j);
+    std::swap(T->n, T->m);
+}
+
+// triplet -> CSR: stable counting sort by row; entries repeating a position are summed, zero sums dropped
+SPASM_API struct spasm_csr *spasm_compress(const struct spasm_triplet *T)
+{
+    const int n = T->n, m = T->m;
+    const i64 nz = T->nz, p = T->field->p;
+    struct spasm_csr *A = spasm_csr_alloc(n, m, nz, p, T->x != nullptr);
+    if (!A) return nullptr;
+    std::vector<i64> w((size_t)n + 1, 0);
+    for (i64 k = 0; k < nz; k++) w[(size_t)T->i[k] + 1]++;
+    for (int i = 0; i < n; i++) w[(size_t)i + 1] += w[(size_t)i];
+    std::vector<i64> start(w.begin(), w.end());
+    for (i64 k = 0; k < nz; k++) {
+        const i64 q = w[(size_t)T->i[k]]++;
+        A->j[q] = T->j[k];
+        if (A->x) A->x[q] = T->x[k];
+    }
+    // merge duplicates inside each row (rows of a triplet file are short; a mark array keeps it linear)
+    std::vector<i64> mark((size_t)(m > 0 ? m : 1), -1);
+    i64 out = 0;
+    for (int i = 0; i < n; i++) {
+        const i64 lo = start[(size_t)i], hi = start[(size_t)i + 1], row_out = out;
+        for (i64 k = lo; k < hi; k++) {
+            const int c = A->j[k];
+            if (mark[(size_t)c] >= row_out) {
+                if (A->x) {
+                    i64 v = ((i64)A->x[mark[(size_t)c]] + (i64)A->x[k]) % p;
+                    if (v > T->field->halfp) v -= p; else if (v < T->field->mhalfp) v += p;
+                    A->x[mark[(size_t)c]] = (spasm_ZZp)v;
+                }
+            } else {
+                mark[(size_t)c] = out;
+                A->j[out] = c;
+                if (A->x) A->x[out] = A->x[k];
+                out++;
+            }
+        }
+        if (A->x) { // drop entries that cancelled
+            i64 keep = row_out;
+            for (i64 k = row_out; k < out; k++) {
+                if (A->x[k] != 0) { A->j[keep] = A->j[k]; A->x[keep] = A->x[k]; mark[(size_t)A->j[keep]] = keep; keep++; }
+                else mark[(size_t)A->j[k]] = -1;
+            }
+            out = keep;
+        }
+        A->p[i] = row_out;
+    }
+    A->p[n] = out;
+    return A;
+}
+
+namespace {
+// SHA-256 (FIPS 180-4), for the optional hash of spasm_triplet_load
+struct Sha256 {
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint8_t buf[64];
+    size_t fill = 0;
+    uint64_t total = 0;
+    static uint32_t rotr(uint32_t x, int k) { return (x >> k) | (x << (32 - k)); }
+    void block(const uint8_t *b)
+    {
+        static const uint32_t K[64] = {
+            0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+            0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+            0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+            0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+            0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+            0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = (uint32_t)b[4 * i] << 24 | (uint32_t)b[4 * i + 1] << 16 | (uint32_t)b[4 * i + 2] << 8 | b[4 * i + 3];
+        for (int i = 16; i < 64; i++) {
+            const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+            const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g), t1 = hh + S1 + ch + K[i] + w[i];
+            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & bb) ^ (a & c) ^ (bb & c), t2 = S0 + mj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const uint8_t *p, size_t n)
+    {
+        total += n;
+        while (n) {
+            const size_t k = std::min(n, 64 - fill);
+            memcpy(buf + fill, p, k);
+            fill += k; p += k; n -= k;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    void final(uint8_t *out)
+    {
+        const uint64_t bits = total * 8;
+        const uint8_t one = 0x80, zero = 0;
+        update(&one, 1);
+        while (fill != 56) update(&zero, 1);
+        uint8_t len[8];
+        for (int i = 0; i < 8; i++) len[i] = (uint8_t)(bits >> (56 - 8 * i));
+        update(len, 8);
+        for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+    }
+};
+} // namespace
+
+// SMS reader: header "n m M" (the letter is skipped, reference src/SpaSM.jl:1070), then "i j v" 1-based until "0 0 0"
+SPASM_API struct spasm_triplet *spasm_triplet_load(void *file, i64 prime, uint8_t *hash)
+{
+    spasm_clear_error();
+    FILE *f = (FILE *)file;
+    if (!f) { spasm_set_error("spasm_triplet_load: NULL file"); return nullptr; }
+    std::string text;
+    char chunk[1 << 16];
+    size_t got;
+    while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) text.append(chunk, got);
+    if (hash) { Sha256 s; s.update((const uint8_t *)text.data(), text.size()); s.final(hash); }
+    size_t pos = 0;
+    auto read_int = [&](i64 &v) -> bool { // reference read_Int (:1044-1061): skip to the next digit, honour '-'
+        bool neg = false;
+        while (pos < text.size() && !(text[pos] >= '0' && text[pos] <= '9')) { if (text[pos] == '-') neg = !neg; pos++; }
+        if (pos >= text.size()) return false;
+        v = 0;
+        while (pos < text.size() && text[pos] >= '0' && text[pos] <= '9') { v = 10 * v + (text[pos] - '0'); pos++; }
+        if (neg) v = -v;
+        return true;
+    };
+    i64 n, m;
+    if (!read_int(n) || !read_int(m) || n < 0 || m < 0 || n > 0x7fffffff || m > 0x7fffffff) { spasm_set_error("spasm_triplet_load: bad SMS header"); return nullptr; }
+    struct spasm_triplet *T = spasm_triplet_alloc((int)n, (int)m, 1024, prime, true);
+    if (!T) return nullptr;
+    for (;;) {
+        i64 i, j, v;
+        if (!read_int(i) || !read_int(j) || !read_int(v)) { spasm_set_error("spasm_triplet_load: missing \"0 0 0\" terminator"); spasm_triplet_free(T); return nullptr; }
+        if (i == 0) break;
+        if (i < 1 || j < 1 || i > n || j > m) { spasm_set_error("spasm_triplet_load: entry (%lld,%lld) outside %lld x %lld", (long long)i, (long long)j, (long long)n, (long long)m); spasm_triplet_free(T); return nullptr; }
+        spasm_add_entry(T, (int)(i - 1), (int)(j - 1), v);
+    }
+    T->n = (int)n; // the header rules even when trailing rows / columns are empty
+    T->m = (int)m;
+    return T;
+}
+
+SPASM_API void spasm_triplet_save(const struct spasm_triplet *T, void *file)
+{
+    FILE *f = (FILE *)file;
+    fprintf(f, "%d %d M\n", T->n, T->m);
+    for (i64 k = 0; k < T->nz; k++) fprintf(f, "%d %d %d\n", T->i[k] + 1, T->j[k] + 1, T->x ? T->x[k] : 1);
+    fprintf(f, "0 0 0\n");
+}
+
+SPASM_API void spasm_csr_save(const struct spasm_csr *A, void *file)
+{
+    FILE *f = (FILE *)file;
+    fprintf(f, "%d %d M\n", A->n, A->m);
+    for (int i = 0; i < A->n; i++)
+        for (i64 k = A->p[i]; k < A->p[i + 1]; k++) fprintf(f, "%d %d %d\n", i + 1, A->j[k] + 1, A->x ? A->x[k] : 1);
+    fprintf(f, "0 0 0\n");
+}
+
 SPASM_API int spasm_get_num_threads(void) { return 1; } // reference src/SpaSM.jl:470 (the engine's parallelism is on the device)
 SPASM_API int spasm_get_thread_num(void) { return 0; }  // reference src/SpaSM.jl:475
 
