@@ -167,6 +167,7 @@ int spasm_amd_set_device(int dev);
 /* Deterministic synthetic CSR (host memory, caller frees with spasm_csr_free):
  *   kind 0: every entry present with probability `density` (BASELINE config 2)
  *   kind 1: exactly `row_nnz` distinct uniform columns per row (BASELINE configs 3/4)
+ *   kind 2: Macaulay-like, rows are translates of n/2500 base patterns of 10..row_nnz terms (BASELINE config 5)
  * values uniform on the nonzero balanced residues; columns unsorted. */
 struct spasm_csr *spasm_amd_synth_csr(int kind, int n, int m, double density, int row_nnz,
                                       i64 prime, uint64_t seed);

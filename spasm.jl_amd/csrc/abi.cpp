@@ -445,14 +445,59 @@ void gen_row_cols(int kind, int m, double density, int row_nnz, Rng &rng, std::v
 }
 } // namespace
 
+// kind 2: Macaulay-like.  `nbase` = max(2, n / 2500) base polynomials with 10..row_nnz terms (column pattern
+// inside a window of m/8 columns, fixed coefficients); row i is base (i mod nbase) translated by a seeded offset, so most rows have
+// distinct leading columns (many Faugere-Lachartre pivots) and the Schur complement collapses to a small dense tail.
+static struct spasm_csr *synth_macaulay(int n, int m, int row_nnz, i64 prime, uint64_t seed)
+{
+    const int nbase = std::max(2, n / 2500);
+    const int window = std::max(row_nnz + 1, m / 8);
+    const int maxterms = std::max(10, row_nnz);
+    std::vector<std::vector<int>> bcols((size_t)nbase), bvals((size_t)nbase);
+    const i64 halfp = prime / 2;
+    for (int b = 0; b < nbase; b++) {
+        Rng rng(row_seed(seed ^ 0xBA5Eull, (uint64_t)b));
+        const int terms = 10 + (int)rng.below((uint64_t)(maxterms - 10 + 1));
+        std::vector<int> &c = bcols[(size_t)b];
+        while ((int)c.size() < std::min(terms, window)) {
+            const int x = (int)rng.below((uint64_t)window);
+            if (std::find(c.begin(), c.end(), x) == c.end()) c.push_back(x);
+        }
+        for (size_t k = 0; k < c.size(); k++) {
+            i64 v = 1 + (i64)rng.below((uint64_t)(prime - 1));
+            if (v > halfp) v -= prime;
+            bvals[(size_t)b].push_back((int)v);
+        }
+    }
+    std::vector<i64> rp((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) rp[(size_t)i + 1] = rp[(size_t)i] + (i64)bcols[(size_t)(i % nbase)].size();
+    struct spasm_csr *A = spasm_csr_alloc(n, m, rp[(size_t)n], prime, true);
+    if (!A) return nullptr;
+    memcpy(A->p, rp.data(), sizeof(i64) * ((size_t)n + 1));
+    const int span = std::max(1, m - window);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        Rng rng(row_seed(seed, (uint64_t)i));
+        const int off = (int)rng.below((uint64_t)span);
+        const std::vector<int> &c = bcols[(size_t)(i % nbase)];
+        const std::vector<int> &v = bvals[(size_t)(i % nbase)];
+        for (size_t k = 0; k < c.size(); k++) {
+            A->j[A->p[i] + (i64)k] = c[k] + off;
+            A->x[A->p[i] + (i64)k] = v[k];
+        }
+    }
+    return A;
+}
+
 extern "C" SPASM_API struct spasm_csr *spasm_amd_synth_csr(int kind, int n, int m, double density, int row_nnz,
                                                             i64 prime, uint64_t seed)
 {
     spasm_clear_error();
-    if (n < 0 || m < 0 || prime <= 2 || prime > 0xfffffffbLL || (kind != 0 && kind != 1)) {
+    if (n < 0 || m < 0 || prime <= 2 || prime > 0xfffffffbLL || kind < 0 || kind > 2) {
         spasm_set_error("spasm_amd_synth_csr: bad arguments");
         return nullptr;
     }
+    if (kind == 2) return synth_macaulay(n, m, row_nnz, prime, seed);
     std::vector<i64> rp((size_t)n + 1, 0);
     // pass 1: row lengths
 #pragma omp parallel

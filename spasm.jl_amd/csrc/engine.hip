@@ -805,7 +805,7 @@ void append_round_U(HostU &U, const Round &R, const DevMat &A, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 // dense tail: leftmost-pivot elimination of the live part of `M`; its pivot rows are appended to U
 // ------------------------------------------------------------------------------------------------
-const i64 kDenseMaxEntries = (i64)1 << 28; // 1 GiB of i32
+const i64 kDenseMaxEntries = (i64)1 << 31; // 8 GiB of i32 (288 GB of HBM per device)
 
 int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
 {
@@ -846,12 +846,45 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
     hipLaunchKernelGGL(k_dense_fill, dim3(cdiv((i64)R * 64, 256)), dim3(256), 0, s, R, rows.p, M.start.p, M.len.p, M.ent.p, cmap.p, D.p, (i64d)ldc);
     HIPCHK(hipGetLastError());
     const int rc = std::max(R, C);
-    for (int c = 0; c < C; c++) {
-        hipLaunchKernelGGL(k_dense_find, dim3(1), dim3(1024), 0, s, c, R, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, st.p);
-        hipLaunchKernelGGL(k_dense_scale, dim3(cdiv(rc, 256)), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, st.p);
-        hipLaunchKernelGGL(k_dense_store_prow, dim3(cdiv(C, 256)), dim3(256), 0, s, c, C, D.p, (i64d)ldc, prow.p, st.p);
-        hipLaunchKernelGGL(k_dense_elim, dim3(cdiv(C - c, 256), R), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, prow.p, fcol.p, st.p);
-        if ((c & 255) == 255) HIPCHK(hipGetLastError());
+    if (F.p <= ((i64)1 << 24)) {
+        // blocked: panels of DPB columns, f64-MFMA trailing update (exact: 64 * (p/2)^2 < 2^53)
+        const i64 R64 = ((i64)R + 63) / 64 * 64, ldu = ldc;
+        DevBuf<double> Lm, Upan;
+        DevBuf<int> pan_row, pan_inv;
+        Lm.alloc((size_t)R64 * DPB);
+        Upan.alloc((size_t)DPB * (size_t)ldu);
+        pan_row.alloc(DPB);
+        pan_inv.alloc(DPB);
+        for (int c0 = 0; c0 < C; c0 += DPB) {
+            const int c1 = std::min(c0 + DPB, C);
+            Lm.zero(s);
+            Upan.zero(s);
+            hipLaunchKernelGGL(k_panel_begin, dim3(1), dim3(1), 0, s, st.p);
+            for (int c = c0; c < c1; c++) {
+                hipLaunchKernelGGL(k_dense_find, dim3(1), dim3(1024), 0, s, c, R, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, st.p);
+                hipLaunchKernelGGL(k_panel_scale, dim3(cdiv(rc, 256)), dim3(256), 0, s, c, c1, R, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, Lm.p,
+                                   pan_row.p, pan_inv.p, st.p);
+                hipLaunchKernelGGL(k_panel_store_prow, dim3(cdiv(C, 256)), dim3(256), 0, s, c, c1, D.p, (i64d)ldc, prow.p, st.p);
+                hipLaunchKernelGGL(k_panel_elim, dim3(R), dim3(64), 0, s, c, c1, F, D.p, (i64d)ldc, prow.p, fcol.p, st.p);
+            }
+            HIPCHK(hipGetLastError());
+            if (c1 < C) {
+                hipLaunchKernelGGL(k_panel_trsm, dim3(cdiv(C - c1, 256)), dim3(256), 0, s, c1, C, F, D.p, (i64d)ldc, Lm.p, pan_row.p, pan_inv.p, Upan.p,
+                                   (i64d)ldu, st.p);
+                hipLaunchKernelGGL(k_dense_gemm, dim3(cdiv(C - c1, 64), (unsigned)(R64 / 64)), dim3(256), 0, s, c1, R, C, F, D.p, (i64d)ldc, Lm.p,
+                                   Upan.p, (i64d)ldu, is_piv.p, st.p);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        HIPCHK(hipStreamSynchronize(s)); // Lm / Upan go out of scope
+    } else {
+        for (int c = 0; c < C; c++) {
+            hipLaunchKernelGGL(k_dense_find, dim3(1), dim3(1024), 0, s, c, R, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, st.p);
+            hipLaunchKernelGGL(k_dense_scale, dim3(cdiv(rc, 256)), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, st.p);
+            hipLaunchKernelGGL(k_dense_store_prow, dim3(cdiv(C, 256)), dim3(256), 0, s, c, C, D.p, (i64d)ldc, prow.p, st.p);
+            hipLaunchKernelGGL(k_dense_elim, dim3(cdiv(C - c, 256), R), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, prow.p, fcol.p, st.p);
+            if ((c & 255) == 255) HIPCHK(hipGetLastError());
+        }
     }
     HIPCHK(hipGetLastError());
     // extract the pivot rows

@@ -1533,6 +1533,8 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
 struct DenseState {
     int cur;       // pivot row of the column being eliminated, -1 if the column has none
     int npiv;      // pivots found so far
+    int npp;       // pivots found in the current panel (blocked variant)
+    int pad;
 };
 
 __global__ void k_flag_cols(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent, int *__restrict__ flag)
@@ -1587,6 +1589,7 @@ __global__ __launch_bounds__(1024) void k_dense_find(int c, int R, const int *__
         if (b != INT_MAX) {
             st->cur = b;
             st->npiv += 1;
+            st->npp += 1;
             is_piv[b] = 1;
             pivrow_of_col[c] = b;
         } else {
@@ -1791,4 +1794,112 @@ __global__ void k_hdr_len64(int n, const int2 *__restrict__ hdr, i64d *__restric
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = hdr[k].y;
     if (k == n) out[k] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DENSE TAIL, blocked (p <= 2^24).  Panels of DPB columns are eliminated column by column exactly as
+// above but only inside the panel, recording the elimination factors Lm[row][t] of the panel's t-th
+// pivot.  The columns to the right are then brought up to date in two steps:
+//   TRSM  u_t = inv_t * (row_{p_t} - sum_{s<t} Lm[p_t][s] u_s)        (the panel's pivot rows, sequential in t)
+//   GEMM  row_i -= sum_t Lm[i][t] u_t  for every non-pivotal row i    (f64 MFMA: integers below 2^53 are exact)
+// ------------------------------------------------------------------------------------------------
+#define DPB 64
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ void k_panel_begin(DenseState *st) { st->npp = 0; }
+
+__global__ void k_panel_scale(int c, int c1, int R, ZpField F, const int *__restrict__ D, i64d ldc, const int *__restrict__ is_piv,
+                              int *__restrict__ prow, int *__restrict__ fcol, double *__restrict__ Lm, int *__restrict__ pan_row,
+                              int *__restrict__ pan_inv, const DenseState *__restrict__ st)
+{
+    const int p = st->cur;
+    if (p < 0) return;
+    const int t = st->npp - 1;
+    const int inv = zp_inverse(F, D[(i64d)p * ldc + c]);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c && i < c1) prow[i] = zp_mul(F, inv, D[(i64d)p * ldc + i]);
+    if (i < R) {
+        const int f = is_piv[i] ? 0 : D[(i64d)i * ldc + c];
+        fcol[i] = f;
+        Lm[(size_t)i * DPB + t] = (double)f;
+    }
+    if (i == 0) { pan_row[t] = p; pan_inv[t] = inv; }
+}
+
+__global__ void k_panel_store_prow(int c, int c1, int *__restrict__ D, i64d ldc, const int *__restrict__ prow, const DenseState *__restrict__ st)
+{
+    const int p = st->cur;
+    if (p < 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c && i < c1) D[(i64d)p * ldc + i] = prow[i];
+}
+
+__global__ __launch_bounds__(64) void k_panel_elim(int c, int c1, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ prow,
+                                                  const int *__restrict__ fcol, const DenseState *__restrict__ st)
+{
+    if (st->cur < 0) return;
+    const int i = blockIdx.x;
+    const int f = fcol[i];
+    if (f == 0) return;
+    const int nf = zp_neg(F, f);
+    const int j = c + threadIdx.x;
+    if (j < c1) {
+        int *d = D + (i64d)i * ldc + j;
+        *d = zp_axpy(F, nf, prow[j], *d);
+    }
+}
+
+// one thread per column to the right of the panel; Upan[t][j] (f64) and D[p_t][j] receive the normalised pivot rows
+__global__ void k_panel_trsm(int c1, int C, ZpField F, int *__restrict__ D, i64d ldc, const double *__restrict__ Lm, const int *__restrict__ pan_row,
+                             const int *__restrict__ pan_inv, double *__restrict__ Upan, i64d ldu, const DenseState *__restrict__ st)
+{
+    const int npp = st->npp;
+    const int j = c1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C) return;
+    for (int t = 0; t < npp; t++) {
+        const int p = pan_row[t];
+        long long acc = D[(i64d)p * ldc + j];
+        const double *lrow = Lm + (size_t)p * DPB;
+        for (int s = 0; s < t; s++) acc -= (long long)lrow[s] * (long long)Upan[(i64d)s * ldu + j]; // |.| <= 64 p^2/4 < 2^53
+        const int u = zp_mul(F, pan_inv[t], zp_reduce(F, acc));
+        Upan[(i64d)t * ldu + j] = (double)u;
+        D[(i64d)p * ldc + j] = u;
+    }
+}
+
+// D[i][j] -= sum_t Lm[i][t] * Upan[t][j] for the non-pivotal rows; workgroup tile 64 x 64, each wave 16 rows x 64 columns,
+// v_mfma_f64_16x16x4_f64: A[l&15][k = l>>4], B[k = l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg
+__global__ __launch_bounds__(256) void k_dense_gemm(int c1, int R, int C, ZpField F, int *__restrict__ D, i64d ldc, const double *__restrict__ Lm,
+                                                   const double *__restrict__ Upan, i64d ldu, const int *__restrict__ is_piv,
+                                                   const DenseState *__restrict__ st)
+{
+    if (st->npp == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 64 + wave * 16;
+    const int cb = c1 + blockIdx.x * 64;
+    v4f64 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const double *la = Lm + (size_t)(r0 + (lane & 15)) * DPB + (lane >> 4);   // Lm is padded to a multiple of 64 rows
+    const double *ub = Upan + (i64d)(lane >> 4) * ldu + cb + (lane & 15);      // Upan is padded to a multiple of 64 columns
+    for (int k0 = 0; k0 < DPB; k0 += 4) {
+        const double a = la[k0];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double b = ub[(i64d)k0 * ldu + q * 16];
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int col = cb + q * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = r0 + (lane >> 4) + 4 * r;
+            if (row < R && col < C && !is_piv[row]) {
+                int *d = D + (i64d)row * ldc + col;
+                *d = zp_reduce(F, (long long)*d - (long long)acc[q][r]);
+            }
+        }
+    }
 }

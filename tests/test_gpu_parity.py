@@ -113,6 +113,30 @@ def test_echelonize_kernel_vs_oracle_and_dense(S, O, n, m, p, density, seed, ena
     assert len(piv2) == fact.r
 
 
+@pytest.mark.parametrize("n,m,p,density,seed", [
+    (200, 300, 127, 0.3, 1), (260, 190, 65521, 0.25, 2), (150, 400, 16777213, 0.2, 3), (180, 180, 2147483647, 0.3, 4), (70, 500, 42013, 0.5, 5),
+])
+def test_dense_tail_multi_panel(S, O, n, m, p, density, seed):
+    """Dense inputs go straight to the dense tail: several 64-column panels, f64-MFMA trailing updates for p <= 2^24,
+    the rank-1 path above; rank, pivot columns and kernel against the oracle and the numpy eliminator."""
+    from test_oracle_golden import random_rows
+
+    rng = np.random.default_rng(seed)
+    D = random_rows(rng, n, m, p, density, rank_deficient=True)
+    D[:, 5] = 0          # a zero column and a repeated column: free columns inside the panels
+    D[:, 70] = D[:, 3]
+    A = S.CSR(D.T.copy(), prime=p)
+    fact = S.echelonize(A)
+    olu = O.echelonize(A)
+    assert fact.r == olu.r
+    assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()
+    Kd, piv = O.dense_kernel_normal_form(D, p)
+    assert sorted(np.nonzero(np.asarray(fact.qinv) >= 0)[0].tolist()) == piv
+    K = S.kernel(fact)
+    assert (K.todense() == Kd).all()
+    check_lu(S, A, fact, D, p)
+
+
 def test_kernel_accepts_foreign_factorizations(S, O):
     """spasm_kernel on a factorization this engine did not produce: U rows in arbitrary order, pivot not the
     first entry of its row (reference src/SpaSM.jl:711 allows both); here the oracle's LU, rows shuffled."""
@@ -193,6 +217,24 @@ def test_config2_random_10k(S, O):
     Ks = sp.csr_matrix((K.x[:nk].astype(np.int64), K.j[:nk].astype(np.int64), K.p.astype(np.int64)), shape=K.shape)
     prod = (As @ Ks.T).tocoo()
     assert (prod.data % 42013 == 0).all()
+
+
+def test_config5_macaulay_style_scaled_down(S, O):
+    """BASELINE config 5 at 1/250 scale: Macaulay-like 20000 x 8000, p = 127: many FL pivots, small dense tail."""
+    A = S.synth_csr(2, 20000, 8000, row_nnz=40, prime=127, seed=0x5A5A0005)
+    fact = S.echelonize(A)
+    rounds = S.last_rounds()
+    assert rounds and rounds[0]["npiv"] > 0.5 * min(A.n, A.m) * 0.5  # the first round elects most pivots
+    olu = O.echelonize(A)
+    assert fact.r == olu.r
+    assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()
+    K = S.kernel(fact)
+    oK = O.kernel(olu)
+    assert K.shape == (oK.n, oK.m) and (K.p == oK.p).all()
+    for f in range(0, K.n, max(1, K.n // 200)):  # spot-check kernel vectors entry for entry
+        lo, hi = int(K.p[f]), int(K.p[f + 1])
+        lo2, hi2 = int(oK.p[f]), int(oK.p[f + 1])
+        assert sorted(zip(K.j[lo:hi].tolist(), K.x[lo:hi].tolist())) == sorted(zip(oK.j[lo2:hi2].tolist(), oK.x[lo2:hi2].tolist()))
 
 
 # ---- one Schur round (the benchmark's unit of work) vs the oracle -------------------------------
