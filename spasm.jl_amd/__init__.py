@@ -3,7 +3,8 @@
 The directory name carries a dot, so import it as `spasm_jl_amd` (the loader module of that name
 at the repository root registers this package).
 """
-from . import _abi
+from . import _abi, blocks
+from .blocks import Block
 from .api import (
     CSR,
     LU,
@@ -27,6 +28,6 @@ from .api import (
 )
 
 __all__ = [
-    "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "kernel",
+    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "kernel",
     "last_rounds", "nnz", "prime0", "rank", "sparse", "synth_csr", "transpose",
 ]
