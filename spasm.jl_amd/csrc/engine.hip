@@ -306,7 +306,7 @@ struct Round {
         if (big_npiv == npiv && big_blocks > 0) return;
         // the dense fallback keeps npiv * 20 bytes per workgroup; stay under ~2 GB
         const i64 per = std::max<i64>((i64)npiv, 1) * 20;
-        big_blocks = (int)std::max<i64>(1, std::min<i64>(64, ((i64)2 << 30) / per));
+        big_blocks = (int)std::max<i64>(1, std::min<i64>(num_cu, ((i64)2 << 30) / per));
         big_npiv = npiv;
         const size_t nw = ((size_t)std::max(npiv, 1) + 31) / 32;
         xdense.alloc((size_t)big_blocks * (size_t)std::max(npiv, 1));
@@ -328,6 +328,29 @@ struct Round {
             hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(cdiv((i64)nrows * TEAM, TPB)), dim3(TPB), 0, stream, a);
             HIPCHK(hipGetLastError());
         }
+        BigSolveArgs b;
+        b.npiv = std::max(npiv, 1);
+        b.nwords = (std::max(npiv, 1) + 31) / 32;
+        b.xdense = xdense.p;
+        b.bitmap = bitmap.p;
+        b.scratch = bigscratch.p;
+        const size_t lds_dense = (size_t)b.npiv * 4 + (size_t)b.nwords * 4;
+        if (lds_dense <= 150 * 1024) {
+            // second class: one workgroup per row, dense multiplier vector + pending bitmap in LDS (unbounded reach)
+            b.s = a;
+            b.s.retry = overflow_list.p;
+            b.s.retry_count = &ctr.p->solve_overflow;
+            b.s.overflow_list = nullptr;
+            b.s.overflow_count = nullptr;
+            static bool attr_done = false;
+            if (!attr_done) {
+                HIPCHK(hipFuncSetAttribute((const void *)k_solve_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(k_solve_big<true>, dim3(big_blocks), dim3(256), lds_dense, stream, b);
+            HIPCHK(hipGetLastError());
+            return;
+        }
         a.retry = overflow_list.p;
         a.retry_count = &ctr.p->solve_overflow;
         a.overflow_list = fail_list.p;
@@ -337,18 +360,12 @@ struct Round {
             hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(std::min(nrows, 5 * num_cu)), dim3(TPB), 0, stream, a);
             HIPCHK(hipGetLastError());
         }
-        BigSolveArgs b;
         b.s = a;
         b.s.retry = fail_list.p;
         b.s.retry_count = &ctr.p->solve_failed;
         b.s.overflow_list = nullptr;
         b.s.overflow_count = nullptr;
-        b.npiv = std::max(npiv, 1);
-        b.nwords = (std::max(npiv, 1) + 31) / 32;
-        b.xdense = xdense.p;
-        b.bitmap = bitmap.p;
-        b.scratch = bigscratch.p;
-        hipLaunchKernelGGL(k_solve_big, dim3(big_blocks), dim3(256), 0, stream, b);
+        hipLaunchKernelGGL(k_solve_big<false>, dim3(big_blocks), dim3(256), 0, stream, b);
         HIPCHK(hipGetLastError());
     }
 

@@ -1422,17 +1422,27 @@ struct BigSolveArgs {
     int4 *scratch;           // [gridDim.x][npiv]
 };
 
+// LDSX = true: the value vector and the bitmap live in LDS (dynamic shared memory: 4*npiv + 4*nwords bytes, so only
+// for rounds with up to ~30000 pivots): the same algorithm at LDS latency, the class that takes over from the
+// small sorted lists when it fits.
+template <bool LDSX>
 __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
 {
     const SolveArgs &a = b.s;
     __shared__ int s_word;       // index of the word holding the next pending pivot, INT_MAX if none in the window
     __shared__ int s_nN;
     __shared__ u64d s_base;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const int tid = threadIdx.x;
     const ZpField F = a.F;
-    int *x = b.xdense + (size_t)blockIdx.x * b.npiv;
-    unsigned *bm = b.bitmap + (size_t)blockIdx.x * b.nwords;
+    int *x = LDSX ? (int *)s_dyn : b.xdense + (size_t)blockIdx.x * b.npiv;
+    unsigned *bm = LDSX ? (unsigned *)(s_dyn + (size_t)b.npiv * 4) : b.bitmap + (size_t)blockIdx.x * b.nwords;
     int4 *out = b.scratch + (size_t)blockIdx.x * b.npiv;
+    if (LDSX) {
+        for (int i = tid; i < b.npiv; i += 256) x[i] = 0;
+        for (int i = tid; i < b.nwords; i += 256) bm[i] = 0;
+        __syncthreads();
+    }
     const int total = *a.retry_count;
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int t = a.retry[w];

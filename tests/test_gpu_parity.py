@@ -271,16 +271,17 @@ def test_schur_round_vs_oracle(S, O, n, k, p, seed):
     assert Sc.rows() == So.rows()
 
 
-def test_schur_round_deep_chains(S, O):
-    """Pivot rows that chain through thousands of other pivots: the reach of a row exceeds every LDS
-    class of the solve kernel (and Uinv is too dense to build), so the fallback classes run."""
+@pytest.mark.parametrize("N,nprobe", [(6000, 40), (40000, 6)], ids=["lds_dense_class", "global_memory_class"])
+def test_schur_round_deep_chains(S, O, N, nprobe):
+    """Pivot rows that chain through thousands of other pivots: the reach of a row exceeds the sorted-list class of
+    the solve kernel (and Uinv is too dense to build), so the dense-vector classes run: in LDS up to ~30000 pivots
+    per round, in global memory beyond."""
     p = 65521
-    N = 6000
     rng = np.random.default_rng(5)
     rows = []
     for i in range(N):  # bidiagonal pivot rows: pivot i chains into i+1, i+2, ...
         rows.append([(i, int(rng.integers(1, p))), (i + 1, int(rng.integers(1, p))), (N + 1 + int(rng.integers(0, 500)), int(rng.integers(1, p)))])
-    for k in range(40):  # probe rows entering the chain at various depths, heavier than the pivot rows
+    for k in range(nprobe):  # probe rows entering the chain at various depths, heavier than the pivot rows
         c = int(rng.integers(0, N - 1)) if k else 0
         cols = sorted(set([c] + [int(x) for x in rng.integers(c, N + 501, size=6)]))
         rows.append([(cc, int(rng.integers(1, p))) for cc in cols])
