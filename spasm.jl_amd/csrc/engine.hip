@@ -94,14 +94,14 @@ inline size_t scatter_lds_bytes(const ScatterClass &c, bool small)
     return c.tpr == 64 ? slot * (size_t)c.wpb : slot;
 }
 
-template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL> void launch_scatter(const ScatterArgs &a, int grid, size_t lds, hipStream_t s)
+template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW = 1> void launch_scatter(const ScatterArgs &a, int grid, size_t lds, hipStream_t s)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_scatter<LOGT, TPR, WPB, MAXR, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_scatter<LOGT, TPR, WPB, MAXR, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_scatter<LOGT, TPR, WPB, MAXR, SMALL>), dim3(grid), dim3(WPB * 64), lds, s, a);
+    hipLaunchKernelGGL((k_scatter<LOGT, TPR, WPB, MAXR, SMALL, MINW>), dim3(grid), dim3(WPB * 64), lds, s, a);
     HIPCHK(hipGetLastError());
 }
 
@@ -110,8 +110,8 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
     switch (cls) {
     case 0: launch_scatter<8, 64, 4, 1, SMALL>(a, grid, lds, s); break;
     case 1: launch_scatter<9, 64, 4, 2, SMALL>(a, grid, lds, s); break;
-    case 2: launch_scatter<10, 64, 4, 4, SMALL>(a, grid, lds, s); break;
-    case 3: launch_scatter<11, 128, 2, 4, SMALL>(a, grid, lds, s); break;
+    case 2: launch_scatter<10, 64, 4, 4, SMALL, 5>(a, grid, lds, s); break;   // 8 KiB tables: 19 rows per CU fit, keep the registers under 96
+    case 3: launch_scatter<11, 128, 2, 4, SMALL, 5>(a, grid, lds, s); break;  // 16 KiB tables: 10 workgroups of 2 waves per CU
     case 4: launch_scatter<12, 256, 4, 4, SMALL>(a, grid, lds, s); break;
     case 5: launch_scatter<13, 256, 4, 5, SMALL>(a, grid, lds, s); break;
     case 6: if (SMALL) launch_scatter<14, 256, 4, 5, true>(a, grid, lds, s); break;
@@ -154,6 +154,7 @@ struct Round {
     u64d region_cap = 0;
     DevBuf<i64d> Lstart, bound, sstart;
     DevBuf<int> Llen, overflow_list, overflow2_list, fail_list;
+    DevBuf<long long> pmask;        // per row slot: which own entries sit on pivot columns (solve -> scatter)
     // last-resort solve (dense vector + bitmap over the pivot indices, per workgroup)
     int big_blocks = 0, big_npiv = -1;
     DevBuf<int> xdense;
@@ -287,6 +288,7 @@ struct Round {
         overflow_list.ensure((size_t)nrows + 1);
         fail_list.ensure((size_t)nrows + 1);
         overflow2_list.ensure((size_t)nrows + 1);
+        pmask.ensure((size_t)nrows + 1);
         region_cap = ((u64d)lpool_entries + NPOOL - 1) / NPOOL;
         Lpool.ensure((size_t)(region_cap * NPOOL) + 1);
         pool_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
@@ -464,6 +466,7 @@ struct Round {
         HIPCHK(hipMemsetAsync(pool_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
         HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(bound.p + nrows, 0, sizeof(i64d), stream));
+        HIPCHK(hipMemsetAsync(pmask.p, 0xff, ((size_t)nrows + 1) * sizeof(long long), stream)); // -1: no mask
         if (nrows == 0) return;
         SolveArgs a;
         a.nrows = nrows;
@@ -509,6 +512,7 @@ struct Round {
             c.Lstart = Lstart.p;
             c.Llen = Llen.p;
             c.bound = bound.p;
+            c.pmask = pmask.p;
             c.free_cols = free_cols;
             c.retry = nullptr;
             c.retry_count = nullptr;
@@ -604,6 +608,7 @@ struct Round {
         b.orig = M.orig.p;
         b.Lstart = Lstart.p;
         b.sstart = sstart.p;
+        b.pmask = pmask.p;
         b.desc = class_desc.p;
         hipLaunchKernelGGL(k_bin, dim3(cdiv(nrows, 1024)), dim3(256), 0, stream, b);
         HIPCHK(hipGetLastError());

@@ -472,6 +472,7 @@ struct __attribute__((aligned(16))) RowDesc {
     int llen;
     int t;            // row slot (index of the Schur row)
     int orig;
+    long long pmask;  // bit k set <=> own entry k sits on a pivot column (from the solve kernel); < 0: not available
 };
 
 // A descriptor fetched with VECTOR loads (every lane reads the same 48 bytes): a scalar load would sit on
@@ -498,6 +499,7 @@ __device__ __forceinline__ RowDesc desc_unpack(const DescRegs &r)
     d.llen = __builtin_amdgcn_readfirstlane(r.b.w);
     d.t = __builtin_amdgcn_readfirstlane(r.c.x);
     d.orig = __builtin_amdgcn_readfirstlane(r.c.y);
+    d.pmask = (long long)(((u64d)(unsigned)__builtin_amdgcn_readfirstlane(r.c.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(r.c.z));
     return d;
 }
 
@@ -511,6 +513,7 @@ struct BinArgs {
     const int *orig;
     const i64d *Lstart;
     const i64d *sstart;
+    const long long *pmask;  // per row slot, from the solve kernel (NULL: none)
     RowDesc *desc;           // [NCLASS][nrows]
     i64d cap[NCLASS];        // class c takes rows with bound <= cap[c]; the last class takes the rest
     int *class_count;        // [NCLASS]
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a)
             d.llen = a.Llen[t];
             d.t = t;
             d.orig = a.orig[row];
+            d.pmask = a.pmask ? a.pmask[t] : -1;
             a.desc[slot] = d;
         }
 }
@@ -705,8 +709,9 @@ __device__ __forceinline__ u64d stamp_now()
 //       round r hands pivot row gg + r*NG of the row's multiplier list to the 8-lane group gg.
 // Software pipeline across the rows of a team: descriptor two rows ahead, multiplier records and own
 // entries one row ahead (issued before the sweep), so a row exposes one global-load latency.
-template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL>
-__global__ __launch_bounds__(WPB * 64) void k_scatter(ScatterArgs a)
+// MINW = waves per SIMD the register allocator must leave room for (occupancy cliffs at 64/72/80/96/128 VGPRs)
+template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW>
+__global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
 {
     typedef typename ZpAcc<SMALL>::type Acc;
     typedef RowTable<LOGT, SMALL> Tab;
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(WPB * 64) void k_scatter(ScatterArgs a)
 #endif
     // ---- pipeline registers
     RowDesc d, dn;
-    d.ent_start = d.l_start = d.s_start = 0; d.len = d.llen = d.t = d.orig = 0;
+    d.ent_start = d.l_start = d.s_start = 0; d.len = d.llen = d.t = d.orig = 0; d.pmask = -1;
     dn = d;
     int2 own = make_int2(0, 0);
     int4 rec[MAXR];
@@ -768,7 +773,8 @@ __global__ __launch_bounds__(WPB * 64) void k_scatter(ScatterArgs a)
         // (B) every load of the current row: qinv of the own entry, entries of the pivot rows
         const int ln = d.len, ll = d.llen;
         int q_own = 0;
-        if (rtid < ln) q_own = a.qinv_r[own.x];
+        if (d.pmask >= 0) q_own = ((d.pmask >> rtid) & 1) ? 0 : -1; // the solve kernel already classified the own entries (rows of <= 32)
+        else if (rtid < ln) q_own = a.qinv_r[own.x];
         int2 u[MAXR][3];
         int npn[MAXR];
 #pragma unroll
@@ -884,7 +890,10 @@ __global__ __launch_bounds__(WPB * 64) void k_scatter(ScatterArgs a)
 #pragma unroll
             for (int q = 0; q < U; q++) {
                 if (vv[q] != 0 && !(a.dbg & 4)) {
-                    if (!(a.dbg & 1)) a.Sent[ss + pos + __popcll(mm[q] & lanemask_lt())] = make_int2(cc[q], vv[q]);
+                    if (!(a.dbg & 1)) { // streamed out, never re-read here: keep it from evicting the pivot rows
+                        const long long pk = ((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q];
+                        __builtin_nontemporal_store(pk, (long long *)&a.Sent[ss + pos + __popcll(mm[q] & lanemask_lt())]);
+                    }
                     mylead = min(mylead, cc[q]);
                 }
                 pos += __popcll(mm[q]);
@@ -1186,6 +1195,7 @@ struct CombineArgs {
     i64d *Lstart;
     int *Llen;
     i64d *bound;
+    long long *pmask;          // out: per row slot, bit k <=> own entry k is on a pivot column (rows of <= 32 entries), else -1
     int free_cols;
     int *overflow_list;
     int *overflow_count;
@@ -1305,6 +1315,10 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
             int4 ci_a = make_int4(-1, 0, 0, 0), ci_b = ci_a;
             if (va) ci_a = a.colinfo[own_a.x];
             if (vb) ci_b = a.colinfo[own_b.x];
+            {
+                const u64d mA = team_ballot<TEAM>(va && ci_a.x >= 0), mB = team_ballot<TEAM>(vb && ci_b.x >= 0);
+                if (a.pmask && tl == 0) a.pmask[t] = (ln <= 32 && 2 * TEAM >= ln) ? (long long)(mA | (TEAM < 32 ? (mB << (TEAM & 31)) : 0ull)) : -1;
+            }
             process(own_a, ci_a, va);
             if (ln > TEAM && ok) process(own_b, ci_b, vb);
         }
