@@ -347,3 +347,49 @@ def test_schur_round_is_idempotent_on_rerun(S):
         assert outs[0] == outs[1] == outs[2]
     finally:
         lib.spasm_amd_schur_plan_free(plan)
+
+
+# ---- randomized differential campaign: tiny primes make cancellations, zero multipliers and empty Schur rows common ----
+
+@pytest.mark.parametrize("enable_dense", [False, True], ids=["sparse_rounds_only", "dense_tail"])
+def test_fuzz_small_primes_vs_dense_elimination(S, O, enable_dense):
+    rng = np.random.default_rng(20260930 + int(enable_dense))
+    cases = 0
+    for trial in range(90):
+        p = int(rng.choice([3, 5, 7, 11, 127, 251]))
+        n, m = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        density = float(rng.choice([0.03, 0.08, 0.2, 0.5]))
+        D = (rng.random((n, m)) < density) * rng.integers(1, p, size=(n, m))
+        if n > 3 and rng.random() < 0.5:  # planted dependencies and duplicate rows
+            D[n - 1] = (D[0] + 2 * D[1]) % p
+            D[n - 2] = D[2]
+        if m > 4 and rng.random() < 0.3:
+            D[:, m - 1] = 0
+        A = S.CSR(D.T.copy(), prime=p)
+        fact = S.echelonize(A, enable_dense=enable_dense)
+        Kd, piv = O.dense_kernel_normal_form(D, p)
+        assert fact.r == len(piv), (trial, p, n, m)
+        assert sorted(np.nonzero(np.asarray(fact.qinv) >= 0)[0].tolist()) == piv, (trial, p, n, m)
+        K = S.kernel(fact)
+        assert (K.todense() == Kd).all(), (trial, p, n, m)
+        # U: unit pivots and rows inside the row space of A
+        Ud = fact.U.todense() % p
+        for a in range(fact.r):
+            assert Ud[a, [j for j in range(m) if fact.qinv[j] == a][0]] == 1
+        assert len(O.dense_rref(np.vstack([D % p, Ud]), p)[1]) == fact.r
+        cases += 1
+    assert cases == 90
+
+
+def test_fuzz_schur_round_small_primes(S, O):
+    """One Schur round against the oracle on matrices where multipliers and accumulators cancel to zero often."""
+    rng = np.random.default_rng(77)
+    for trial in range(25):
+        p = int(rng.choice([3, 5, 7]))
+        n, m, k = int(rng.integers(50, 400)), int(rng.integers(50, 400)), int(rng.integers(2, 9))
+        A = S.synth_csr(1, n, m, row_nnz=min(k, m), prime=p, seed=1000 + trial)
+        Sc, st, p_out = run_plan(S, A)
+        So, info = O.schur_round(A)
+        assert (st["npiv"], st["applications"], st["nnz_reduced"], st["nnz_out"]) == \
+               (info["npiv"], info["applications"], info["nnz_reduced"], info["nnz_out"]), (trial, p, n, m, k)
+        assert Sc.rows() == So.rows(), (trial, p, n, m, k)
