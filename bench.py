@@ -69,7 +69,10 @@ def main():
     t_gen = time.time()
     A = S.synth_csr(1, n, m, row_nnz=args.row_nnz, prime=args.prime, seed=seed)
     t_gen = time.time() - t_gen
-    lo, hi = rank * n // world, (rank + 1) * n // world
+    # rank r of G reduces rows r, r+G, r+2G, ...: contiguous blocks would be unbalanced (all rows have the same length, so the
+    # election's tie-break puts the pivots in the first rows of the matrix)
+    lo, hi, stride = rank, n, world
+    my_rows = len(range(lo, hi, stride))
 
     t_setup = time.time()
     exchange = None
@@ -80,7 +83,7 @@ def main():
         from spasm_jl_amd import sharded
 
         try:
-            engine = sharded.GpuShardEngine(A, lo, hi)
+            engine = sharded.GpuShardEngine(A, lo, hi, stride=stride)
             t_x = time.time()
             npiv_x, exchange = sharded.exchange_pivot_rows(engine)
             torch.cuda.synchronize()
@@ -97,11 +100,11 @@ def main():
                 engine.close()
                 engine = None
             exchange = exchange if "error" in exchange else {"error": "another rank failed", "fallback": "matrix replicated on every rank"}
-            plan = lib.spasm_amd_schur_plan_create(A.data, lo, hi)
+            plan = lib.spasm_amd_schur_plan_create_strided(A.data, lo, hi, stride)
             if not plan:
                 raise SystemExit("plan_create failed: " + S._abi.last_error())
     else:
-        plan = lib.spasm_amd_schur_plan_create(A.data, lo, hi)
+        plan = lib.spasm_amd_schur_plan_create_strided(A.data, lo, hi, stride)
         if not plan:
             raise SystemExit("plan_create failed: " + S._abi.last_error())
     t_setup = time.time() - t_setup
@@ -117,6 +120,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    lib.spasm_amd_schur_plan_class_timing(plan, 0)  # the timed steps carry no per-class event records
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -134,11 +138,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # one more step, outside the timed region, with an event pair around every scatter class (roofline of the dominant kernel)
+    lib.spasm_amd_schur_plan_class_timing(plan, 1)
+    step()
+    torch.cuda.synchronize()
     st = S._abi.RoundStats()
     if lib.spasm_amd_schur_plan_stats(plan, C.byref(st)) != 0:
         raise SystemExit("plan_stats failed: " + S._abi.last_error())
     d = st.as_dict()
-    counters = torch.tensor([d["nnz_reduced"], d["applications"], d["nnz_out"], d["read_bytes"], hi - lo], dtype=torch.int64, device="cuda")
+    counters = torch.tensor([d["nnz_reduced"], d["applications"], d["nnz_out"], d["read_bytes"], my_rows], dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     nnz_reduced, applications, nnz_out, read_bytes, rows_total = [int(v) for v in counters.tolist()]

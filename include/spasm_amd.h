@@ -177,9 +177,15 @@ struct spasm_csr *spasm_amd_synth_csr(int kind, int n, int m, double density, in
  * pivots of the WHOLE matrix (so that every shard sees the same U), builds U on the device.
  * Returns NULL on failure. */
 spasm_amd_schur_plan *spasm_amd_schur_plan_create(const struct spasm_csr *A, int row_lo, int row_hi);
+/* Same with the plan's rows taken as row_lo, row_lo + stride, ... < row_hi.  Strided shards (rank r of G: row_lo = r,
+ * stride = G) are balanced; contiguous blocks are not when the election's tie-break puts the pivots in the first rows. */
+spasm_amd_schur_plan *spasm_amd_schur_plan_create_strided(const struct spasm_csr *A, int row_lo, int row_hi, int stride);
 /* Run the round once on `stream` (a hipStream_t, NULL = default): solve + scatter kernels.
  * Returns 0 on success. Safe to call repeatedly (outputs are overwritten). */
 int spasm_amd_schur_plan_run(spasm_amd_schur_plan *plan, void *stream);
+/* Per-class event pairs around the scatter launches (stats->ms_class) are recorded when `on` (default); they cost a
+ * few microseconds of launch gap each, so throughput runs switch them off and profile one extra run with them on. */
+void spasm_amd_schur_plan_class_timing(spasm_amd_schur_plan *plan, int on);
 /* Block until the plan's last run has finished and fill `stats` (counters + event timings). */
 int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spasm_amd_round_stats *stats);
 /* Copy the Schur complement of the last run back to host CSR (n_shard_nonpivot x m). p_out (may be
@@ -201,6 +207,7 @@ void spasm_amd_schur_plan_free(spasm_amd_schur_plan *plan);
  *                     plan_stats / plan_fetch work on the returned plan for this shard's non-pivot rows. */
 typedef struct spasm_amd_shard spasm_amd_shard;
 spasm_amd_shard *spasm_amd_shard_create(const struct spasm_csr *A, int row_lo, int row_hi);
+spasm_amd_shard *spasm_amd_shard_create_strided(const struct spasm_csr *A, int row_lo, int row_hi, int stride);
 int spasm_amd_shard_elect(spasm_amd_shard *sh, int64_t *keys_dev);
 int spasm_amd_shard_set_keys(spasm_amd_shard *sh, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned);
 int spasm_amd_shard_export(spasm_amd_shard *sh, int *hdr_dev, int *ent_dev);

@@ -156,12 +156,15 @@ SIGNATURES = {
     "spasm_amd_set_device": (C.c_int32, [C.c_int32]),
     "spasm_amd_synth_csr": (_P(CsrStruct), [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int64, C.c_uint64]),
     "spasm_amd_schur_plan_create": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32]),
+    "spasm_amd_schur_plan_create_strided": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),
     "spasm_amd_schur_plan_run": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "spasm_amd_schur_plan_class_timing": (None, [C.c_void_p, C.c_int32]),
     "spasm_amd_schur_plan_stats": (C.c_int32, [C.c_void_p, _P(RoundStats)]),
     "spasm_amd_schur_plan_fetch": (_P(CsrStruct), [C.c_void_p, _P(C.c_int32)]),
     "spasm_amd_schur_plan_free": (None, [C.c_void_p]),
     "spasm_amd_last_rounds": (C.c_int32, [_P(RoundStats), C.c_int32]),
     "spasm_amd_shard_create": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32]),
+    "spasm_amd_shard_create_strided": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),
     "spasm_amd_shard_elect": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "spasm_amd_shard_set_keys": (C.c_int32, [C.c_void_p, C.c_void_p, _P(C.c_int32), _P(C.c_int64)]),
     "spasm_amd_shard_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -180,6 +180,7 @@ struct Round {
     hipEvent_t ev_cls[NCLASS + 1];
     int hclass_count[NCLASS];
     int nhash_used = 0;
+    bool class_timing = true;       // record an event pair around every scatter class (costs a few microseconds of gap each)
 
     Round()
     {
@@ -198,14 +199,14 @@ struct Round {
     }
 
     // ---- (1a) local candidates: best[j] = min over local rows with leftmost column j of (len, global row)
-    void elect_local(const DevMat &A, int row_base)
+    void elect_local(const DevMat &A, int row_base, int row_stride = 1)
     {
         m = A.m;
         best.ensure((size_t)m + 1);
         hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best.p);
         HIPCHK(hipGetLastError());
         if (A.n > 0) {
-            hipLaunchKernelGGL(k_elect, dim3(cdiv(A.n, 256)), dim3(256), 0, stream, A.n, row_base, A.len.p, A.lead.p, best.p);
+            hipLaunchKernelGGL(k_elect, dim3(cdiv(A.n, 256)), dim3(256), 0, stream, A.n, row_base, row_stride, A.len.p, A.lead.p, best.p);
             HIPCHK(hipGetLastError());
         }
     }
@@ -230,7 +231,8 @@ struct Round {
     }
 
     // ---- (1c) local non-pivot, non-empty rows
-    void mark_local(const DevMat &A, int row_base, int lo = 0, int hi = INT_MAX)
+    // row_stride: local row i is global row row_base + i * row_stride; (lo, hi, step): which LOCAL rows this plan reduces
+    void mark_local(const DevMat &A, int row_base, int lo = 0, int hi = INT_MAX, int row_stride = 1, int step = 1)
     {
         is_piv.ensure((size_t)A.n + 1);
         rowflag.ensure((size_t)A.n + 1);
@@ -238,10 +240,10 @@ struct Round {
         np_rows.ensure((size_t)A.n + 1);
         HIPCHK(hipMemsetAsync(is_piv.p, 0, ((size_t)A.n + 1) * sizeof(int), stream));
         if (npiv > 0) {
-            hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, row_base, A.n, pivrow.p, is_piv.p);
+            hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, row_base, row_stride, A.n, pivrow.p, is_piv.p);
             HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_row_flags, dim3(cdiv((i64)A.n + 1, 256)), dim3(256), 0, stream, A.n, lo, hi, is_piv.p, A.len.p, rowflag.p);
+        hipLaunchKernelGGL(k_row_flags, dim3(cdiv((i64)A.n + 1, 256)), dim3(256), 0, stream, A.n, lo, hi, step, is_piv.p, A.len.p, rowflag.p);
         HIPCHK(hipGetLastError());
         scan.exclusive(rowflag.p, rowscan.p, (size_t)A.n + 1, stream);
         HIPCHK(hipMemcpyAsync(&nnp, rowscan.p + A.n, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -293,7 +295,7 @@ struct Round {
         Lpool.ensure((size_t)(region_cap * NPOOL) + 1);
         pool_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
         alloc_big();
-        ctr.ensure(1);
+        ctr.ensure(NCTR);
         class_count.ensure(NCLASS);
         class_list.ensure((size_t)NCLASS * (size_t)(nrows > 0 ? nrows : 1));
         class_desc.ensure((size_t)NCLASS * (size_t)(nrows > 0 ? nrows : 1));
@@ -388,7 +390,7 @@ struct Round {
         ubound.ensure((size_t)npiv + 1);
         overflow_list.ensure((size_t)npiv + 1);
         fail_list.ensure((size_t)npiv + 1);
-        ctr.ensure(1);
+        ctr.ensure(NCTR);
         alloc_big();
         hipLaunchKernelGGL(k_unit_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, pivcol.p, E.start.p, E.len.p, E.ent.p);
         HIPCHK(hipGetLastError());
@@ -398,7 +400,7 @@ struct Round {
             const u64d ucap = ((u64d)pool + NPOOL - 1) / NPOOL;
             UinvPool.ensure((size_t)(ucap * NPOOL) + 1);
             pool_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
-            HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(RoundCounters), stream));
+            HIPCHK(hipMemsetAsync(ctr.p, 0, NCTR * sizeof(RoundCounters), stream));
             HIPCHK(hipMemsetAsync(pool_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
             SolveArgs a;
             a.nrows = npiv;
@@ -439,8 +441,7 @@ struct Round {
                 hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(std::min(npiv, 5 * num_cu)), dim3(TPB), 0, stream, a);
                 HIPCHK(hipGetLastError());
             }
-            RoundCounters c;
-            HIPCHK(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, stream));
+            RoundCounters c = read_counters();
             const u64d used = pool_used(); // synchronises
             if (c.solve_failed) return;                       // some pivot reaches > 4096 others: chains it is
             if (c.lpool_overflow) {
@@ -462,7 +463,7 @@ struct Round {
 
     void run_solve(const DevMat &M, const int *rows, const int *self_idx, int nrows)
     {
-        HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(RoundCounters), stream));
+        HIPCHK(hipMemsetAsync(ctr.p, 0, NCTR * sizeof(RoundCounters), stream));
         HIPCHK(hipMemsetAsync(pool_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
         HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(bound.p + nrows, 0, sizeof(i64d), stream));
@@ -544,6 +545,26 @@ struct Round {
         }
     }
 
+    // sum of the NCTR statistic copies (synchronises)
+    RoundCounters read_counters()
+    {
+        std::vector<RoundCounters> h(NCTR);
+        HIPCHK(hipMemcpyAsync(h.data(), ctr.p, NCTR * sizeof(RoundCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        RoundCounters c = h[0];
+        for (int i = 1; i < NCTR; i++) {
+            c.applications += h[i].applications;
+            c.nnz_reduced += h[i].nnz_reduced;
+            c.segments += h[i].segments;
+            c.lpool_overflow += h[i].lpool_overflow;
+            c.scatter_overflow += h[i].scatter_overflow;
+            c.nonempty_out += h[i].nonempty_out;
+            c.nnz_out += h[i].nnz_out;
+            for (int k = 0; k < 8; k++) { c.class_ent[k] += h[i].class_ent[k]; c.class_seg[k] += h[i].class_seg[k]; }
+        }
+        return c;
+    }
+
     // entries handed out by the fullest region times NPOOL (what a balanced pool would need); synchronises
     u64d pool_used()
     {
@@ -563,8 +584,7 @@ struct Round {
             alloc_solve(nrows, pool);
             run_solve(M, rows, self_idx, nrows);
             run_bounds(nrows);
-            RoundCounters c;
-            HIPCHK(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, stream));
+            const RoundCounters c = read_counters();
             const i64 tot = fetch_total_bound(nrows); // synchronises
             if (c.lpool_overflow) { pool = std::max<i64>(pool * 2, (i64)(pool_used() * 5 / 4) + 1024); continue; }
             return tot;
@@ -637,7 +657,7 @@ struct Round {
 #endif
         nhash_used = nhash;
         for (int c = 0; c < nhash; c++) {
-            HIPCHK(hipEventRecord(ev_cls[c], stream));
+            if (class_timing) HIPCHK(hipEventRecord(ev_cls[c], stream));
             a.cls = c;
             a.class_count = class_count.p + c;
             a.desc = class_desc.p + (size_t)c * nrows;
@@ -649,7 +669,7 @@ struct Round {
             if (F.small) launch_scatter_class<true>(c, a, grid, lds, stream);
             else launch_scatter_class<false>(c, a, grid, lds, stream);
         }
-        HIPCHK(hipEventRecord(ev_cls[nhash], stream));
+        if (class_timing) HIPCHK(hipEventRecord(ev_cls[nhash], stream));
         {
             // rows that fit no LDS table: the last class, through the global-memory kernel
             if (bigsc_m != m) {
@@ -684,7 +704,7 @@ struct Round {
 
     void fetch_counters()
     {
-        HIPCHK(hipMemcpyAsync(&hctr, ctr.p, sizeof(RoundCounters), hipMemcpyDeviceToHost, stream));
+        hctr = read_counters();
         int *cc = hclass_count;
         HIPCHK(hipMemcpyAsync(cc, class_count.p, NCLASS * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -710,6 +730,8 @@ struct Round {
 // ------------------------------------------------------------------------------------------------
 // host CSR -> device matrix
 // ------------------------------------------------------------------------------------------------
+void upload_csr_strided(const struct spasm_csr *A, int row_lo, int row_hi, int stride, DevMat &M, hipStream_t s);
+
 void upload_csr(const struct spasm_csr *A, int row_lo, int row_hi, DevMat &M, hipStream_t s)
 {
     const int n = row_hi - row_lo;
@@ -738,13 +760,57 @@ void upload_csr(const struct spasm_csr *A, int row_lo, int row_hi, DevMat &M, hi
         HIPCHK(hipGetLastError());
     }
     if (n > 0) {
-        hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, n, row_lo, dp.p, M.start.p, M.len.p, M.orig.p);
+        hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, n, row_lo, 1, dp.p, M.start.p, M.len.p, M.orig.p);
         HIPCHK(hipGetLastError());
         constexpr int TEAM = 8;
         hipLaunchKernelGGL((k_row_lead<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p, M.lead.p);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(s)); // hp and the staging buffers go out of scope
+}
+
+// rows row_lo, row_lo + stride, ... < row_hi of A, gathered on the host and uploaded as one matrix
+void upload_csr_strided(const struct spasm_csr *A, int row_lo, int row_hi, int stride, DevMat &M, hipStream_t s)
+{
+    if (stride <= 1) { upload_csr(A, row_lo, row_hi, M, s); return; }
+    const int n = row_hi > row_lo ? (row_hi - row_lo + stride - 1) / stride : 0;
+    std::vector<i64d> hp((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) { const int g = row_lo + i * stride; hp[(size_t)i + 1] = hp[(size_t)i] + (A->p[g + 1] - A->p[g]); }
+    const i64 nnz = hp[(size_t)n];
+    std::vector<int> hj((size_t)nnz + 1), hx((size_t)nnz + 1);
+    for (int i = 0; i < n; i++) {
+        const int g = row_lo + i * stride;
+        const i64 len = A->p[g + 1] - A->p[g];
+        memcpy(hj.data() + hp[(size_t)i], A->j + A->p[g], sizeof(int) * (size_t)len);
+        if (A->x) memcpy(hx.data() + hp[(size_t)i], A->x + A->p[g], sizeof(int) * (size_t)len);
+    }
+    M.n = n;
+    M.m = A->m;
+    M.start.ensure((size_t)n + 1);
+    M.len.ensure((size_t)n + 1);
+    M.lead.ensure((size_t)n + 1);
+    M.orig.ensure((size_t)n + 1);
+    M.ent.ensure((size_t)nnz + 1);
+    DevBuf<i64d> dp;
+    DevBuf<int> dj, dx;
+    dp.alloc((size_t)n + 1);
+    dj.alloc((size_t)nnz + 1);
+    dx.alloc((size_t)nnz + 1);
+    HIPCHK(hipMemcpyAsync(dp.p, hp.data(), ((size_t)n + 1) * sizeof(i64d), hipMemcpyHostToDevice, s));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpyAsync(dj.p, hj.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
+        if (A->x) HIPCHK(hipMemcpyAsync(dx.p, hx.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pack_entries, dim3(std::min<i64>(cdiv(nnz, 256), 65536)), dim3(256), 0, s, (i64d)nnz, dj.p, A->x ? dx.p : nullptr, M.ent.p);
+        HIPCHK(hipGetLastError());
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, n, row_lo, stride, dp.p, M.start.p, M.len.p, M.orig.p);
+        HIPCHK(hipGetLastError());
+        constexpr int TEAM = 8;
+        hipLaunchKernelGGL((k_row_lead<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p, M.lead.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(s));
 }
 
 void require_device()
@@ -784,7 +850,7 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     if (hipEventElapsedTime(&ms, R.ev[2], R.ev[3]) == hipSuccess) st.ms_scatter = ms;
     if (hipEventElapsedTime(&ms, R.ev[0], R.ev[3]) == hipSuccess) st.ms_total = ms;
     for (int c = 0; c < R.nhash_used && c < 8; c++) {
-        if (hipEventElapsedTime(&ms, R.ev_cls[c], R.ev_cls[c + 1]) == hipSuccess) st.ms_class[c] = ms;
+        if (R.class_timing && hipEventElapsedTime(&ms, R.ev_cls[c], R.ev_cls[c + 1]) == hipSuccess) st.ms_class[c] = ms;
         st.rows_class[c] = R.hclass_count[c];
         st.ent_class[c] = (i64)R.hctr.class_ent[c];
         st.seg_class[c] = (i64)R.hctr.class_seg[c];
@@ -1313,7 +1379,7 @@ struct spasm_amd_schur_plan {
     DevMat PM;          // sharded runs: the imported pivot rows
     DevBuf<int> rowsrc; // sharded runs: pivot index -> row of PM
     Round R;
-    int lo = 0, hi = 0;
+    int lo = 0, hi = 0, stride = 1;  // the plan's rows: lo, lo + stride, ... < hi (global row ids)
     i64 nnz_in = 0;
     i64 prime = 0;
     bool ran = false;
@@ -1336,19 +1402,21 @@ struct spasm_amd_shard {
 
 namespace {
 
-spasm_amd_shard *shard_create(const struct spasm_csr *A, int lo, int hi)
+spasm_amd_shard *shard_create(const struct spasm_csr *A, int lo, int hi, int stride = 1)
 {
     require_device();
     check_input(A, "spasm_amd_shard_create");
-    if (lo < 0 || hi > A->n || lo > hi) throw EngineError("spasm_amd_shard_create: bad row range");
+    if (lo < 0 || hi > A->n || lo > hi || stride < 1) throw EngineError("spasm_amd_shard_create: bad row range");
     std::unique_ptr<spasm_amd_shard> S(new spasm_amd_shard());
     std::unique_ptr<spasm_amd_schur_plan> P(new spasm_amd_schur_plan());
     P->lo = lo;
     P->hi = hi;
+    P->stride = stride;
     P->prime = A->field->p;
-    P->nnz_in = A->p[hi] - A->p[lo];
+    P->nnz_in = 0;
+    for (int g = lo; g < hi; g += stride) P->nnz_in += A->p[g + 1] - A->p[g];
     hipStream_t s = nullptr;
-    upload_csr(A, lo, hi, P->A, s); // only this shard's rows; orig = global row ids
+    upload_csr_strided(A, lo, hi, stride, P->A, s); // only this shard's rows; orig = global row ids
     P->R.F = zp_field_make(P->prime);
     P->R.stream = s;
     S->n_total = A->n;
@@ -1359,7 +1427,7 @@ spasm_amd_shard *shard_create(const struct spasm_csr *A, int lo, int hi)
 void shard_elect(spasm_amd_shard *S, int64_t *keys_dev)
 {
     Round &R = S->plan->R;
-    R.elect_local(S->plan->A, S->plan->lo);
+    R.elect_local(S->plan->A, S->plan->lo, S->plan->stride);
     HIPCHK(hipMemcpyAsync(keys_dev, R.best.p, (size_t)S->plan->A.m * sizeof(u64d), hipMemcpyDeviceToDevice, R.stream));
     HIPCHK(hipStreamSynchronize(R.stream));
 }
@@ -1374,13 +1442,13 @@ int shard_set_keys(spasm_amd_shard *S, const int64_t *keys_dev, int *n_owned, i6
     R.best.ensure((size_t)m + 1);
     HIPCHK(hipMemcpyAsync(R.best.p, keys_dev, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice, s));
     R.assign_pivots();
-    R.mark_local(P->A, P->lo); // local non-pivot rows; pivrow holds global ids
+    R.mark_local(P->A, P->lo, 0, INT_MAX, P->stride, 1); // local non-pivot rows; pivrow holds global ids
     S->npiv = R.npiv;
     // owned pivot rows, in ascending pivot index
     const int np = R.npiv;
     S->oflag.alloc((size_t)np + 1);
     S->oscan.alloc((size_t)np + 1);
-    hipLaunchKernelGGL(k_owned_flags, dim3(cdiv((i64)np + 1, 256)), dim3(256), 0, s, np, P->lo, P->hi, R.pivrow.p, S->oflag.p);
+    hipLaunchKernelGGL(k_owned_flags, dim3(cdiv((i64)np + 1, 256)), dim3(256), 0, s, np, P->lo, P->stride, P->A.n, R.pivrow.p, S->oflag.p);
     HIPCHK(hipGetLastError());
     R.scan.exclusive(S->oflag.p, S->oscan.p, (size_t)np + 1, s);
     HIPCHK(hipMemcpyAsync(&S->nown, S->oscan.p + np, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1390,7 +1458,7 @@ int shard_set_keys(spasm_amd_shard *S, const int64_t *keys_dev, int *n_owned, i6
     S->ooff.alloc((size_t)S->nown + 1);
     HIPCHK(hipMemsetAsync(S->olen.p + S->nown, 0, sizeof(i64d), s));
     if (np > 0) {
-        hipLaunchKernelGGL(k_export_hdr, dim3(cdiv(np, 256)), dim3(256), 0, s, np, P->lo, S->oflag.p, S->oscan.p, R.pivrow.p, P->A.len.p, S->ohdr.p, S->olen.p);
+        hipLaunchKernelGGL(k_export_hdr, dim3(cdiv(np, 256)), dim3(256), 0, s, np, P->lo, P->stride, S->oflag.p, S->oscan.p, R.pivrow.p, P->A.len.p, S->ohdr.p, S->olen.p);
         HIPCHK(hipGetLastError());
     }
     R.scan.exclusive(S->olen.p, S->ooff.p, (size_t)S->nown + 1, s);
@@ -1411,7 +1479,7 @@ void shard_export(spasm_amd_shard *S, int *hdr_dev, int *ent_dev)
     if (S->nown > 0) {
         HIPCHK(hipMemcpyAsync(hdr_dev, S->ohdr.p, (size_t)S->nown * sizeof(int2), hipMemcpyDeviceToDevice, s));
         constexpr int TEAM = 16;
-        hipLaunchKernelGGL((k_export_rows<TEAM>), dim3(cdiv((i64)S->nown * TEAM, 256)), dim3(256), 0, s, S->nown, P->lo, S->ohdr.p, S->ooff.p, R.pivrow.p,
+        hipLaunchKernelGGL((k_export_rows<TEAM>), dim3(cdiv((i64)S->nown * TEAM, 256)), dim3(256), 0, s, S->nown, P->lo, P->stride, S->ohdr.p, S->ooff.p, R.pivrow.p,
                            P->A.start.p, P->A.ent.p, (int2 *)ent_dev);
         HIPCHK(hipGetLastError());
     }
@@ -1451,7 +1519,7 @@ spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries
     if (n_entries > 0) HIPCHK(hipMemcpyAsync(PM.ent.p, ent_dev, (size_t)n_entries * sizeof(int2), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipEventRecord(R.ev[0], s));
     R.build_U(PM, P->rowsrc.p);
-    R.prepare_uinv(R.nnp);
+    R.prepare_uinv(); // a plan is run many times: Uinv always pays
     HIPCHK(hipEventRecord(R.ev[1], s));
     const i64 tb = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, 4 * std::max<i64>(P->nnz_in, 1 << 14));
     R.S.ent.ensure((size_t)tb + 1);
@@ -1460,16 +1528,18 @@ spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries
     return P;
 }
 
-spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi)
+spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi, int stride = 1)
 {
     require_device();
     check_input(A, "spasm_amd_schur_plan_create");
-    if (lo < 0 || hi > A->n || lo > hi) throw EngineError("spasm_amd_schur_plan_create: bad row range");
+    if (lo < 0 || hi > A->n || lo > hi || stride < 1) throw EngineError("spasm_amd_schur_plan_create: bad row range");
     std::unique_ptr<spasm_amd_schur_plan> P(new spasm_amd_schur_plan());
     P->lo = lo;
     P->hi = hi;
+    P->stride = stride;
     P->prime = A->field->p;
-    P->nnz_in = A->p[hi] - A->p[lo];
+    P->nnz_in = 0;
+    for (int g = lo; g < hi; g += stride) P->nnz_in += A->p[g + 1] - A->p[g];
     hipStream_t s = nullptr;
     // the whole matrix is resident on every device: the election sees all rows, so every shard builds the same U
     upload_csr(A, 0, A->n, P->A, s);
@@ -1479,9 +1549,9 @@ spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi)
     HIPCHK(hipEventRecord(R.ev[0], s));
     R.elect_local(P->A, 0);
     R.assign_pivots();
-    R.mark_local(P->A, 0, lo, hi);
+    R.mark_local(P->A, 0, lo, hi, 1, stride);
     R.build_U(P->A, R.pivrow.p);
-    R.prepare_uinv(R.nnp);
+    R.prepare_uinv(); // a plan is run many times: Uinv always pays
     HIPCHK(hipEventRecord(R.ev[1], s));
     // dry run of the solve sizes the multiplier pool and the Schur slots once
     const i64 tot = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, 4 * spasm_nnz(A));
@@ -1605,6 +1675,28 @@ SPASM_API spasm_amd_schur_plan *spasm_amd_schur_plan_create(const struct spasm_c
     }
 }
 
+SPASM_API spasm_amd_schur_plan *spasm_amd_schur_plan_create_strided(const struct spasm_csr *A, int row_lo, int row_hi, int stride)
+{
+    spasm_clear_error();
+    try {
+        return plan_create(A, row_lo, row_hi, stride);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_schur_plan_create_strided: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API spasm_amd_shard *spasm_amd_shard_create_strided(const struct spasm_csr *A, int row_lo, int row_hi, int stride)
+{
+    spasm_clear_error();
+    try {
+        return shard_create(A, row_lo, row_hi, stride);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_create_strided: %s", e.what());
+        return nullptr;
+    }
+}
+
 SPASM_API int spasm_amd_schur_plan_run(spasm_amd_schur_plan *plan, void *stream)
 {
     try {
@@ -1616,12 +1708,17 @@ SPASM_API int spasm_amd_schur_plan_run(spasm_amd_schur_plan *plan, void *stream)
     }
 }
 
+SPASM_API void spasm_amd_schur_plan_class_timing(spasm_amd_schur_plan *plan, int on)
+{
+    if (plan) plan->R.class_timing = on != 0;
+}
+
 SPASM_API int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spasm_amd_round_stats *stats)
 {
     try {
         if (!plan->ran) throw EngineError("run the plan first");
         plan->R.fetch_counters();
-        fill_stats(*stats, plan->R, 0, plan->hi - plan->lo, plan->nnz_in);
+        fill_stats(*stats, plan->R, 0, plan->hi > plan->lo ? (plan->hi - plan->lo + plan->stride - 1) / plan->stride : 0, plan->nnz_in);
         return 0;
     } catch (const std::exception &e) {
         spasm_set_error("spasm_amd_schur_plan_stats: %s", e.what());

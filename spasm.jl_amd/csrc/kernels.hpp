@@ -44,6 +44,13 @@ struct __attribute__((aligned(16))) UHdr {
 #define NPOOL 1024
 #define POOL_STRIDE 16   // u64 words between two counters (128 bytes)
 
+// Statistics are accumulated in NCTR copies of RoundCounters (one per workgroup id mod NCTR, summed on the host):
+// tens of thousands of waves adding to ONE address at the end of a kernel serialise at ~5 ns each (0.3-0.5 ms per
+// kernel, measured).  The *_overflow counters that hand out list positions stay in copy 0.
+#define NCTR 256
+struct RoundCounters;
+__device__ __forceinline__ RoundCounters *ctr_shard(RoundCounters *base);
+
 struct RoundCounters {
     u64d applications;   // (row, pivot row) eliminations with nonzero multiplier
     u64d nnz_reduced;    // reference scatter trip count: sum nnz(A_i) + sum nnz(U_r) over applications
@@ -69,6 +76,8 @@ __device__ __forceinline__ u64d pool_alloc(u64d *counters, u64d region_cap, u64d
     if (pos + n > region_cap) return ~0ull;
     return (u64d)region * region_cap + pos;
 }
+
+__device__ __forceinline__ RoundCounters *ctr_shard(RoundCounters *base) { return base + (blockIdx.x & (NCTR - 1)); }
 
 template <int TEAM> __device__ __forceinline__ u64d team_ballot(bool pred)
 {
@@ -112,13 +121,15 @@ __global__ void k_pack_entries(i64d nnz, const int *__restrict__ j, const int *_
     for (; k < nnz; k += stride) ent[k] = make_int2(j[k], x ? x[k] : 1);
 }
 
-__global__ void k_pack_rows(int n, int row_lo, const i64d *__restrict__ p, i64d *__restrict__ start, int *__restrict__ len, int *__restrict__ orig)
+// local row i of a shard is global row row_lo + i * row_stride (stride 1: a contiguous block; stride G: every G-th row,
+// which balances the shards when the pivots concentrate at low row indices)
+__global__ void k_pack_rows(int n, int row_lo, int row_stride, const i64d *__restrict__ p, i64d *__restrict__ start, int *__restrict__ len, int *__restrict__ orig)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     start[i] = p[i];
     len[i] = (int)(p[i + 1] - p[i]);
-    orig[i] = row_lo + i;
+    orig[i] = row_lo + i * row_stride;
 }
 
 // leftmost column of every row (INT_MAX for an empty row); TEAM lanes per row
@@ -141,13 +152,13 @@ __global__ void k_row_lead(int n, const i64d *__restrict__ start, const int *__r
 // candidate wins, ties to the lowest row: atomicMin on (len << 32 | row).
 // `row_base` makes the row id global when rows are sharded over devices.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_elect(int n, int row_base, const int *__restrict__ len, const int *__restrict__ lead, u64d *__restrict__ best)
+__global__ void k_elect(int n, int row_base, int row_stride, const int *__restrict__ len, const int *__restrict__ lead, u64d *__restrict__ best)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int ln = len[i];
     if (ln <= 0) return;
-    atomicMin(&best[lead[i]], ((u64d)(unsigned)ln << 32) | (u64d)(unsigned)(row_base + i));
+    atomicMin(&best[lead[i]], ((u64d)(unsigned)ln << 32) | (u64d)(unsigned)(row_base + i * row_stride));
 }
 
 __global__ void k_fill_u64(i64d n, u64d v, u64d *__restrict__ out)
@@ -181,18 +192,27 @@ __global__ void k_col_assign(int m, const u64d *__restrict__ best, const int *__
     }
 }
 
-__global__ void k_mark_rows(int npiv, int row_lo, int n, const int *__restrict__ pivrow, int *__restrict__ is_piv)
+// local index of global row g in the shard (row_lo, row_stride, n rows), or -1
+__device__ __forceinline__ int shard_local(int g, int row_lo, int row_stride, int n)
+{
+    const int r = g - row_lo;
+    if (r < 0 || r % row_stride != 0) return -1;
+    const int q = r / row_stride;
+    return q < n ? q : -1;
+}
+
+__global__ void k_mark_rows(int npiv, int row_lo, int row_stride, int n, const int *__restrict__ pivrow, int *__restrict__ is_piv)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npiv) return;
-    const int r = pivrow[idx] - row_lo;
-    if (r >= 0 && r < n) is_piv[r] = 1;
+    const int r = shard_local(pivrow[idx], row_lo, row_stride, n);
+    if (r >= 0) is_piv[r] = 1;
 }
 
-__global__ void k_row_flags(int n, int lo, int hi, const int *__restrict__ is_piv, const int *__restrict__ len, int *__restrict__ flag)
+__global__ void k_row_flags(int n, int lo, int hi, int step, const int *__restrict__ is_piv, const int *__restrict__ len, int *__restrict__ flag)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (i >= lo && i < hi && !is_piv[i] && len[i] > 0) ? 1 : 0;
+    if (i < n) flag[i] = (i >= lo && i < hi && (i - lo) % step == 0 && !is_piv[i] && len[i] > 0) ? 1 : 0;
     if (i == n) flag[i] = 0;
 }
 
@@ -424,7 +444,7 @@ __global__ __launch_bounds__(TPB) void k_solve(SolveArgs a)
             if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)cnt);
             base = __shfl(base, 0, TEAM);
             if (base == ~0ull) {
-                if (tl == 0) { atomicAdd(&a.ctr->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
+                if (tl == 0) { atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
             } else {
                 if (a.Lpool2) {
                     for (int i = tl; i < cnt; i += TEAM) a.Lpool2[base + i] = make_int2(key[i], val[i]);
@@ -452,9 +472,9 @@ __global__ __launch_bounds__(TPB) void k_solve(SolveArgs a)
         c_seg += __shfl_xor(c_seg, o);
     }
     if ((threadIdx.x & 63) == 0 && (c_app | c_red | c_seg)) {
-        atomicAdd(&a.ctr->applications, c_app);
-        atomicAdd(&a.ctr->nnz_reduced, c_red);
-        atomicAdd(&a.ctr->segments, c_seg);
+        atomicAdd(&ctr_shard(a.ctr)->applications, c_app);
+        atomicAdd(&ctr_shard(a.ctr)->nnz_reduced, c_red);
+        atomicAdd(&ctr_shard(a.ctr)->segments, c_seg);
     }
 }
 
@@ -662,7 +682,7 @@ __device__ __forceinline__ void table_add_n(RowTable<LOGT, SMALL> &tab, const in
             }
         }
     }
-    if (pending) atomicAdd(&ctr->scatter_overflow, 1);
+    if (pending) atomicAdd(&ctr_shard(ctr)->scatter_overflow, 1);
 }
 
 template <int LOGT, bool SMALL>
@@ -733,11 +753,12 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
     const int gg = rtid / G, gl = rtid % G;
     const ZpField F = a.F;
 
+    const int count = *a.class_count;
+    if ((WAVE_ROW ? (int)blockIdx.x * WPB : (int)blockIdx.x) >= count) return; // nothing for this workgroup: skip even the table reset
     for (int s = rtid; s < T; s += TPR) tab.clear(s);
     if (rtid == 0) { s_misc[0] = 0; s_misc[1] = INT_MAX; }
     __syncthreads();
 
-    const int count = *a.class_count;
     const int first = WAVE_ROW ? (int)blockIdx.x * WPB + wave : (int)blockIdx.x;
     const int stride = WAVE_ROW ? (int)gridDim.x * WPB : (int)gridDim.x;
     u64d c_nnz = 0, c_ent = 0, c_seg = 0;
@@ -939,11 +960,11 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         c_rows += __shfl_xor(c_rows, o);
     }
     if (lane == 0) {
-        if (c_nnz) atomicAdd(&a.ctr->nnz_out, c_nnz);
-        if (c_rows) atomicAdd(&a.ctr->nonempty_out, c_rows);
+        if (c_nnz) atomicAdd(&ctr_shard(a.ctr)->nnz_out, c_nnz);
+        if (c_rows) atomicAdd(&ctr_shard(a.ctr)->nonempty_out, c_rows);
         if (c_ent | c_seg) {
-            atomicAdd(&a.ctr->class_ent[a.cls], c_ent);
-            atomicAdd(&a.ctr->class_seg[a.cls], c_seg);
+            atomicAdd(&ctr_shard(a.ctr)->class_ent[a.cls], c_ent);
+            atomicAdd(&ctr_shard(a.ctr)->class_seg[a.cls], c_seg);
         }
     }
 }
@@ -1024,8 +1045,8 @@ __global__ __launch_bounds__(256) void k_scatter_big(BigScatterArgs b)
             a.Slen[d.t] = s_nout;
             a.Slead[d.t] = s_lead;
             a.Sorig[d.t] = d.orig;
-            atomicAdd(&a.ctr->nnz_out, (u64d)s_nout);
-            if (s_nout > 0) atomicAdd(&a.ctr->nonempty_out, 1);
+            atomicAdd(&ctr_shard(a.ctr)->nnz_out, (u64d)s_nout);
+            if (s_nout > 0) atomicAdd(&ctr_shard(a.ctr)->nonempty_out, 1);
             c_ent += (u64d)d.len;
             c_seg += 1;
         }
@@ -1033,8 +1054,8 @@ __global__ __launch_bounds__(256) void k_scatter_big(BigScatterArgs b)
     }
     for (int o = 32; o > 0; o >>= 1) { c_ent += __shfl_xor(c_ent, o); c_seg += __shfl_xor(c_seg, o); }
     if (lane == 0 && (c_ent | c_seg)) {
-        atomicAdd(&a.ctr->class_ent[a.cls & 7], c_ent);
-        atomicAdd(&a.ctr->class_seg[a.cls & 7], c_seg);
+        atomicAdd(&ctr_shard(a.ctr)->class_ent[a.cls & 7], c_ent);
+        atomicAdd(&ctr_shard(a.ctr)->class_seg[a.cls & 7], c_seg);
     }
 }
 
@@ -1398,7 +1419,7 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         if (tl == 0) {
             *cnt = 0;
             if (!room) {
-                atomicAdd(&a.ctr->lpool_overflow, 1);
+                atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1);
                 a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0;
             } else {
                 a.Lstart[t] = (i64d)base;
@@ -1416,9 +1437,9 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         c_seg += __shfl_xor(c_seg, o);
     }
     if ((threadIdx.x & 63) == 0 && (c_app | c_red | c_seg)) {
-        atomicAdd(&a.ctr->applications, c_app);
-        atomicAdd(&a.ctr->nnz_reduced, c_red);
-        atomicAdd(&a.ctr->segments, c_seg);
+        atomicAdd(&ctr_shard(a.ctr)->applications, c_app);
+        atomicAdd(&ctr_shard(a.ctr)->nnz_reduced, c_red);
+        atomicAdd(&ctr_shard(a.ctr)->segments, c_seg);
     }
 }
 
@@ -1524,7 +1545,7 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
         __syncthreads();
         const u64d base = s_base;
         if (base == ~0ull) {
-            if (tid == 0) { atomicAdd(&a.ctr->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
+            if (tid == 0) { atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
         } else {
             for (int i = tid; i < cnt; i += 256) {
                 const int4 r = out[i];
@@ -1536,9 +1557,9 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
                 a.Lstart[t] = (i64d)base;
                 a.Llen[t] = cnt;
                 a.bound[t] = bound < (i64d)a.free_cols ? bound : (i64d)a.free_cols;
-                atomicAdd(&a.ctr->applications, r_app);
-                atomicAdd(&a.ctr->nnz_reduced, r_red);
-                atomicAdd(&a.ctr->segments, 1 + r_app);
+                atomicAdd(&ctr_shard(a.ctr)->applications, r_app);
+                atomicAdd(&ctr_shard(a.ctr)->nnz_reduced, r_red);
+                atomicAdd(&ctr_shard(a.ctr)->segments, 1 + r_app);
             }
         }
         __syncthreads();
@@ -1769,33 +1790,33 @@ __global__ void k_kfill(int nfree, const int *__restrict__ freecol, const int *_
 // every rank imports the concatenation (rank-major, each part in ascending pivot index)
 // ------------------------------------------------------------------------------------------------
 // owned[idx] = 1 when pivot idx is a local row
-__global__ void k_owned_flags(int npiv, int row_lo, int row_hi, const int *__restrict__ pivrow, int *__restrict__ flag)
+__global__ void k_owned_flags(int npiv, int row_lo, int row_stride, int n, const int *__restrict__ pivrow, int *__restrict__ flag)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < npiv) flag[idx] = pivrow[idx] >= row_lo && pivrow[idx] < row_hi;
+    if (idx < npiv) flag[idx] = shard_local(pivrow[idx], row_lo, row_stride, n) >= 0;
     if (idx == npiv) flag[idx] = 0;
 }
 
 // header (pivot index, length) of each owned pivot row, in ascending pivot index
-__global__ void k_export_hdr(int npiv, int row_lo, const int *__restrict__ flag, const int *__restrict__ scan, const int *__restrict__ pivrow,
+__global__ void k_export_hdr(int npiv, int row_lo, int row_stride, const int *__restrict__ flag, const int *__restrict__ scan, const int *__restrict__ pivrow,
                              const int *__restrict__ len, int2 *__restrict__ hdr, i64d *__restrict__ olen)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npiv || !flag[idx]) return;
-    const int l = len[pivrow[idx] - row_lo];
+    const int l = len[(pivrow[idx] - row_lo) / row_stride];
     hdr[scan[idx]] = make_int2(idx, l);
     olen[scan[idx]] = l;
 }
 
 template <int TEAM>
-__global__ void k_export_rows(int nown, int row_lo, const int2 *__restrict__ hdr, const i64d *__restrict__ ooff, const int *__restrict__ pivrow,
+__global__ void k_export_rows(int nown, int row_lo, int row_stride, const int2 *__restrict__ hdr, const i64d *__restrict__ ooff, const int *__restrict__ pivrow,
                               const i64d *__restrict__ start, const int2 *__restrict__ ent, int2 *__restrict__ out)
 {
     const int tl = threadIdx.x % TEAM;
     const int k = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
     if (k >= nown) return;
     const int2 h = hdr[k];
-    const i64d st = start[pivrow[h.x] - row_lo];
+    const i64d st = start[(pivrow[h.x] - row_lo) / row_stride];
     const i64d os = ooff[k];
     for (int i = tl; i < h.y; i += TEAM) out[os + i] = ent[st + i];
 }

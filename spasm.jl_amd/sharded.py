@@ -22,12 +22,13 @@ from . import _abi
 
 
 class GpuShardEngine:
-    def __init__(self, A, row_lo, row_hi, device=None):
+    def __init__(self, A, row_lo, row_hi, device=None, stride=1):
         self.lib = _abi.lib()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.m = A.m
         self.A = A  # keeps the host matrix alive
-        self.shard = self.lib.spasm_amd_shard_create(A.data, int(row_lo), int(row_hi))
+        # rows row_lo, row_lo + stride, ... < row_hi (rank r of G: row_lo = r, stride = G balances the shards)
+        self.shard = self.lib.spasm_amd_shard_create_strided(A.data, int(row_lo), int(row_hi), int(stride))
         if not self.shard:
             raise RuntimeError("spasm_amd_shard_create failed: " + _abi.last_error())
         self.plan = None

@@ -239,10 +239,10 @@ def test_config5_macaulay_style_scaled_down(S, O):
 
 # ---- one Schur round (the benchmark's unit of work) vs the oracle -------------------------------
 
-def run_plan(S, A, lo=0, hi=None):
+def run_plan(S, A, lo=0, hi=None, stride=1):
     lib = S._abi.lib()
     hi = A.n if hi is None else hi
-    plan = lib.spasm_amd_schur_plan_create(A.data, lo, hi)
+    plan = lib.spasm_amd_schur_plan_create_strided(A.data, lo, hi, stride)
     assert plan, S._abi.last_error()
     try:
         assert lib.spasm_amd_schur_plan_run(plan, None) == 0, S._abi.last_error()
@@ -329,6 +329,15 @@ def test_schur_round_sharded_rows(S, O):
     assert origs == p_full.tolist()
     assert parts == full.rows() == So.rows()
     assert red == info["nnz_reduced"]
+    # strided shards (rank r of 3: rows r, r+3, ...): balanced, and together the same rows again
+    by_orig = {}
+    red = 0
+    for r in range(3):
+        Sc, st_s, p_out = run_plan(S, A, r, A.n, 3)
+        assert all(g % 3 == r for g in p_out.tolist())
+        by_orig.update(zip(p_out.tolist(), Sc.rows()))
+        red += st_s["nnz_reduced"]
+    assert [by_orig[g] for g in p_full.tolist()] == So.rows() and red == info["nnz_reduced"]
 
 
 def test_schur_round_is_idempotent_on_rerun(S):

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, p, seed, q):
+def _worker(rank, world, port, n, k, p, seed, strided, q):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,13 +34,13 @@ def _worker(rank, world, port, n, k, p, seed, q):
         torch.cuda.set_device(0)
         lib = S._abi.lib()
         A = S.synth_csr(1, n, n, row_nnz=k, prime=p, seed=seed)
-        lo, hi = rank * n // world, (rank + 1) * n // world
-        eng = sharded.GpuShardEngine(A, lo, hi)
+        lo, hi, stride = (rank, n, world) if strided else (rank * n // world, (rank + 1) * n // world, 1)
+        eng = sharded.GpuShardEngine(A, lo, hi, stride=stride)
         npiv, info = sharded.exchange_pivot_rows(eng)
         assert lib.spasm_amd_schur_plan_run(eng.plan, None) == 0, S._abi.last_error()
         st = S._abi.RoundStats()
         assert lib.spasm_amd_schur_plan_stats(eng.plan, C.byref(st)) == 0, S._abi.last_error()
-        p_out = np.empty(max(hi - lo, 1), dtype=np.int32)
+        p_out = np.empty(max(n, 1), dtype=np.int32)
         ptr = lib.spasm_amd_schur_plan_fetch(eng.plan, p_out.ctypes.data_as(C.POINTER(C.c_int32)))
         assert ptr, S._abi.last_error()
         Sc = S.CSR(ptr)
@@ -53,13 +53,13 @@ def _worker(rank, world, port, n, k, p, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,k,p", [(2, 6000, 10, 65521), (3, 3001, 7, 2147483647)])
-def test_sharded_round_with_exchange(S, O, world, n, k, p):
+@pytest.mark.parametrize("world,n,k,p,strided", [(2, 6000, 10, 65521, False), (3, 3001, 7, 2147483647, False), (3, 5000, 9, 65521, True)])
+def test_sharded_round_with_exchange(S, O, world, n, k, p, strided):
     seed = 31
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, k, p, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, k, p, seed, strided, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     results = [q.get(timeout=240) for _ in range(world)]
@@ -74,6 +74,9 @@ def test_sharded_round_with_exchange(S, O, world, n, k, p):
     assert sum(r[2]["owned_rows"] for r in results) == info["npiv"]
     assert sum(r[3] for r in results) == info["nnz_reduced"]
     assert sum(r[4] for r in results) == info["applications"]
-    origs = [g for r in results for g in r[5]]
-    assert origs == sorted(origs)  # global row ids, shard order = row order
-    assert [row for r in results for row in r[6]] == So.rows()
+    pairs = sorted((g, row) for r in results for g, row in zip(r[5], r[6]))  # (global row id, Schur row)
+    assert len(pairs) == So.n and len(set(g for g, _ in pairs)) == So.n
+    assert [row for _, row in pairs] == So.rows()
+    if not strided:
+        origs = [g for r in results for g in r[5]]
+        assert origs == sorted(origs)  # contiguous shards keep the row order
