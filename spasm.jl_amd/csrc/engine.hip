@@ -90,8 +90,9 @@ const int kNumHashClasses = 7;
 
 inline size_t scatter_lds_bytes(const ScatterClass &c, bool small)
 {
-    const size_t slot = ((size_t)1 << c.logt) * (small ? 8 : 12) + 16;
-    return c.tpr == 64 ? slot * (size_t)c.wpb : slot;
+    const size_t retry = small ? RetryList<true>::BYTES : RetryList<false>::BYTES; // one list per wave
+    const size_t table = ((size_t)1 << c.logt) * (small ? 8 : 12) + 16;
+    return c.tpr == 64 ? (table + retry) * (size_t)c.wpb : table + retry * (size_t)c.wpb;
 }
 
 template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW = 1> void launch_scatter(const ScatterArgs &a, int grid, size_t lds, hipStream_t s)

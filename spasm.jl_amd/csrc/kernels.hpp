@@ -693,6 +693,102 @@ __device__ __forceinline__ void table_add(RowTable<LOGT, SMALL> &tab, int c, typ
     table_add_n<LOGT, 1, SMALL>(tab, cc, vv, 1u, ctr);
 }
 
+// ------------------------------------------------------------------------------------------------
+// First probe for everyone, retries together.  A loop "probe until all 64 lanes x N entries are in" runs as long as the
+// unluckiest entry and does so with a handful of live lanes after the first trip (about 3/4 of the entries land on
+// their first probe).  Instead every entry gets ONE probe, and the losers are appended to a list of the wave in LDS;
+// the list is drained 64 entries at a time by a one-entry-per-lane probe loop whose lanes all have work.
+// ------------------------------------------------------------------------------------------------
+constexpr int RCAP = 192; // entries of a wave's retry list = the worst case of one table_try_n<3>
+
+template <bool SMALL> struct RetryList;
+template <> struct RetryList<true> {
+    static constexpr size_t BYTES = (size_t)RCAP * 8;
+    int2 *buf;
+    int cnt; // wave-uniform
+    __device__ __forceinline__ void bind(unsigned char *p) { buf = (int2 *)p; cnt = 0; }
+    // |v| <= 0.51 p < 2^15.1 and h < 2^14 (largest table) share a word
+    __device__ __forceinline__ void put(int i, int c, int v, unsigned h) { buf[i] = make_int2(c, (int)(((unsigned)v << 14) | h)); }
+    __device__ __forceinline__ void get(int i, int &c, int &v, unsigned &h) const { const int2 e = buf[i]; c = e.x; v = e.y >> 14; h = (unsigned)e.y & 0x3fffu; }
+};
+template <> struct RetryList<false> {
+    static constexpr size_t BYTES = (size_t)RCAP * 16;
+    int4 *buf;
+    int cnt;
+    __device__ __forceinline__ void bind(unsigned char *p) { buf = (int4 *)p; cnt = 0; }
+    __device__ __forceinline__ void put(int i, int c, long long v, unsigned h) { buf[i] = make_int4(c, (int)h, (int)(unsigned)(v & 0xffffffffll), (int)(v >> 32)); }
+    __device__ __forceinline__ void get(int i, int &c, long long &v, unsigned &h) const
+    {
+        const int4 e = buf[i];
+        c = e.x; h = (unsigned)e.y; v = ((long long)e.w << 32) | (long long)(unsigned)e.z;
+    }
+};
+
+// empty the list: one entry per lane, probing on from where its first probe left off
+template <int LOGT, bool SMALL>
+__device__ __forceinline__ void retry_drain(RowTable<LOGT, SMALL> &tab, RetryList<SMALL> &rl, RoundCounters *ctr)
+{
+    typedef typename ZpAcc<SMALL>::type Acc;
+    constexpr unsigned T = 1u << LOGT;
+    const int lane = threadIdx.x & 63;
+    for (int b = 0; b < rl.cnt; b += 64) {
+        bool pending = b + lane < rl.cnt;
+        int c = 0;
+        Acc v = 0;
+        unsigned h = 0, st = 1;
+        if (pending) {
+            rl.get(b + lane, c, v, h);
+            unsigned h0;
+            hash2<LOGT>(c, h0, st);
+        }
+        for (unsigned round = 0; round < T && __ballot(pending) != 0; round++) {
+            if (pending) {
+                const int k = atomicCAS(tab.keyp(h), EMPTY_KEY, c);
+                if (k == EMPTY_KEY || k == c) { tab.add(h, v); pending = false; }
+                else h = (h + st) & (T - 1);
+            }
+        }
+        if (pending) atomicAdd(&ctr_shard(ctr)->scatter_overflow, 1);
+    }
+    rl.cnt = 0;
+}
+
+// one probe for each of the N entries of this lane; entries that met a foreign key go to the retry list
+template <int LOGT, int N, bool SMALL>
+__device__ __forceinline__ void table_try_n(RowTable<LOGT, SMALL> &tab, RetryList<SMALL> &rl, const int (&c)[N],
+                                            const typename ZpAcc<SMALL>::type (&v)[N], unsigned valid, RoundCounters *ctr)
+{
+    static_assert(N * 64 <= RCAP, "the retry list must hold one batch");
+    constexpr unsigned T = 1u << LOGT;
+    unsigned h[N], st[N];
+    int k[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) hash2<LOGT>(c[j], h[j], st[j]);
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        k[j] = c[j];
+        if (valid & (1u << j)) k[j] = atomicCAS(tab.keyp(h[j]), EMPTY_KEY, c[j]);
+    }
+    u64d fm[N];
+    int nfail = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const bool ok = (k[j] == EMPTY_KEY) || (k[j] == c[j]); // lanes without an entry read back c[j]: "ok", nothing to add
+        if (ok && (valid & (1u << j))) tab.add(h[j], v[j]);
+        fm[j] = __ballot(!ok);
+        nfail += __popcll(fm[j]);
+    }
+    if (nfail == 0) return;
+    if (rl.cnt + nfail > RCAP) retry_drain<LOGT, SMALL>(tab, rl, ctr);
+    int pos = rl.cnt;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if ((fm[j] >> (threadIdx.x & 63)) & 1) rl.put(pos + __popcll(fm[j] & lanemask_lt()), c[j], v[j], (h[j] + st[j]) & (T - 1));
+        pos += __popcll(fm[j]);
+    }
+    rl.cnt = pos;
+}
+
 // final reduction of a lazy accumulator to the balanced residue
 template <bool SMALL> __device__ __forceinline__ int acc_reduce(const ZpField &F, typename ZpAcc<SMALL>::type acc);
 template <> __device__ __forceinline__ int acc_reduce<true>(const ZpField &F, int acc)
@@ -705,6 +801,19 @@ template <> __device__ __forceinline__ int acc_reduce<true>(const ZpField &F, in
     return r;
 }
 template <> __device__ __forceinline__ int acc_reduce<false>(const ZpField &F, long long acc) { return zp_reduce(F, acc); }
+
+// the same for an accumulator that summed at most 2^20 lazy terms (|term| <= 0.51 p): the quotient is then below 2^20,
+// a 24-bit operand, its float estimate is off by < 3 * 2^-24 * 2^20 < 0.2 before rounding, so |r| < 0.7 p and ONE
+// correction lands in the balanced range.  Every row of the LDS classes qualifies (their multiplier lists are far shorter).
+template <bool SMALL> __device__ __forceinline__ int acc_reduce_short(const ZpField &F, typename ZpAcc<SMALL>::type acc);
+template <> __device__ __forceinline__ int acc_reduce_short<true>(const ZpField &F, int acc)
+{
+    const int p = (int)F.p, hp = (int)F.halfp, mhp = (int)F.mhalfp;
+    int r = acc - __mul24(__float2int_rn((float)acc * F.finvp), p);
+    if (r > hp) r -= p; else if (r < mhp) r += p;
+    return r;
+}
+template <> __device__ __forceinline__ int acc_reduce_short<false>(const ZpField &F, long long acc) { return zp_reduce(F, acc); }
 
 // Diagnostic build only (-DSPASM_STAMPS): per-phase cycle sums of the scatter kernel, written to a buffer of
 // their own (ScatterArgs::stamps) that nothing else reads.  Never compiled into the shipped library.
@@ -740,7 +849,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
     constexpr int T = 1 << LOGT;
     constexpr int G = 8;            // lanes streaming one pivot row: 64 contiguous bytes per step
     constexpr int NG = TPR / G;     // pivot rows per round
-    constexpr size_t SLOT = Tab::BYTES + 16;
+    constexpr size_t RB = RetryList<SMALL>::BYTES;
+    constexpr size_t SLOT = Tab::BYTES + 16 + RB; // wave-per-row: table, 16 spare bytes, retry list of the wave
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -750,6 +860,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
     Tab tab;
     tab.bind(base);
     int *s_misc = (int *)(base + Tab::BYTES);           // block-per-row only: [0] = entries written, [1] = leftmost column
+    RetryList<SMALL> rl;                                // block-per-row: the lists of the waves follow the shared table
+    rl.bind(base + Tab::BYTES + 16 + (WAVE_ROW ? 0 : (size_t)wave * RB));
     const int gg = rtid / G, gl = rtid % G;
     const ZpField F = a.F;
 
@@ -814,12 +926,16 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         STAMP(2); // waiting for them
 #endif
         // (C) accumulate: the own entry, then per round the (up to) 3 entries of this lane as one batch
-        if (rtid < ln && q_own < 0) table_add<LOGT, SMALL>(tab, own.x, (Acc)own.y, a.ctr);
+        {
+            const int oc[1] = {own.x};
+            const Acc ov[1] = {(Acc)own.y};
+            table_try_n<LOGT, 1, SMALL>(tab, rl, oc, ov, (rtid < ln && q_own < 0) ? 1u : 0u, a.ctr);
+        }
         STAMP(3); // own entries
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
-            if (npn[r] > 0) {
-                if (gl == 0) { c_ent += (u64d)npn[r]; c_seg += 1; }
+            if (__ballot(npn[r] > 0) != 0) { // wave-uniform: the retry list is bookkept per wave
+                if (gl == 0 && npn[r] > 0) { c_ent += (u64d)npn[r]; c_seg += 1; }
                 const int nm = zp_neg(F, rec[r].y);
                 int bc[3];
                 Acc bv[3];
@@ -831,7 +947,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
                     if (gl + j * G < npn[r]) valid |= 1u << j;
                 }
                 if (a.dbg & 2) asm volatile("" ::"v"(bc[0]), "v"(bv[0]));
-                else table_add_n<LOGT, 3, SMALL>(tab, bc, bv, valid, a.ctr);
+                else table_try_n<LOGT, 3, SMALL>(tab, rl, bc, bv, valid, a.ctr);
                 const int2 *up = a.UPN + (unsigned)rec[r].z;
                 for (int k = gl + 3 * G; k < npn[r]; k += G) { // pivot rows longer than 24 entries
                     const int2 uu = up[k];
@@ -865,7 +981,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
             const int2 e = a.ent[d.ent_start + k];
             if (a.qinv_r[e.x] < 0) table_add<LOGT, SMALL>(tab, e.x, (Acc)e.y, a.ctr);
         }
-        STAMP(5); // remainder loops
+        retry_drain<LOGT, SMALL>(tab, rl, a.ctr);
+        STAMP(5); // remainder loops + retries
         // (A') stage-1 data of the NEXT row (its own entries and multiplier records) straight into the pipeline
         // registers, which are dead from here on: these loads fly during the sweep
         const int ln_cur = ln;
@@ -898,7 +1015,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
             int tot = 0;
 #pragma unroll
             for (int q = 0; q < U; q++) {
-                vv[q] = acc_reduce<SMALL>(F, aa[q]);
+                vv[q] = acc_reduce_short<SMALL>(F, aa[q]);
                 mm[q] = __ballot(vv[q] != 0 && !(a.dbg & 4));
                 tot += __popcll(mm[q]);
             }
