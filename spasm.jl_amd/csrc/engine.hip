@@ -91,7 +91,7 @@ const int kNumHashClasses = 7;
 inline size_t scatter_lds_bytes(const ScatterClass &c, bool small)
 {
     const size_t retry = small ? RetryList<true>::BYTES : RetryList<false>::BYTES; // one list per wave
-    const size_t table = ((size_t)1 << c.logt) * (small ? 8 : 12) + 16;
+    const size_t table = ((size_t)1 << c.logt) * (small ? 8 : 12) + 32; // + s_misc
     return c.tpr == 64 ? (table + retry) * (size_t)c.wpb : table + retry * (size_t)c.wpb;
 }
 
@@ -111,9 +111,9 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
     switch (cls) {
     case 0: launch_scatter<8, 64, 4, 1, SMALL>(a, grid, lds, s); break;
     case 1: launch_scatter<9, 64, 4, 2, SMALL>(a, grid, lds, s); break;
-    case 2: launch_scatter<10, 64, 4, 4, SMALL, 5>(a, grid, lds, s); break;   // 8 KiB tables: 19 rows per CU fit, keep the registers under 96
-    case 3: launch_scatter<11, 128, 2, 4, SMALL, 5>(a, grid, lds, s); break;  // 16 KiB tables: 10 workgroups of 2 waves per CU
-    case 4: launch_scatter<12, 256, 4, 4, SMALL>(a, grid, lds, s); break;
+    case 2: launch_scatter<10, 64, 4, 4, SMALL, 4>(a, grid, lds, s); break;   // 8 KiB tables: 19 rows per CU fit, keep the registers under 96
+    case 3: launch_scatter<11, 128, 2, 4, SMALL, 4>(a, grid, lds, s); break;  // 16 KiB tables: 10 workgroups of 2 waves per CU
+    case 4: launch_scatter<12, 256, 4, 4, SMALL, 4>(a, grid, lds, s); break;
     case 5: launch_scatter<13, 256, 4, 5, SMALL>(a, grid, lds, s); break;
     case 6: if (SMALL) launch_scatter<14, 256, 4, 5, true>(a, grid, lds, s); break;
     default: break;

@@ -818,6 +818,7 @@ template <> __device__ __forceinline__ int acc_reduce_short<false>(const ZpField
 // Diagnostic build only (-DSPASM_STAMPS): per-phase cycle sums of the scatter kernel, written to a buffer of
 // their own (ScatterArgs::stamps) that nothing else reads.  Never compiled into the shipped library.
 #ifdef SPASM_STAMPS
+#define SCATTER_DBG(a, bit) ((a).dbg & (bit)) // timing ablations (env SPASM_DBG), diagnostic build only
 #define NSTAMP 8
 __device__ __forceinline__ u64d stamp_now()
 {
@@ -829,6 +830,7 @@ __device__ __forceinline__ u64d stamp_now()
 }
 #define STAMP(i) do { const u64d _n = stamp_now(); st_sum[i] += _n - st_last; st_last = _n; } while (0)
 #else
+#define SCATTER_DBG(a, bit) false
 #define STAMP(i) do { } while (0)
 #endif
 
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
     constexpr int G = 8;            // lanes streaming one pivot row: 64 contiguous bytes per step
     constexpr int NG = TPR / G;     // pivot rows per round
     constexpr size_t RB = RetryList<SMALL>::BYTES;
-    constexpr size_t SLOT = Tab::BYTES + 16 + RB; // wave-per-row: table, 16 spare bytes, retry list of the wave
+    constexpr size_t SLOT = Tab::BYTES + 32 + RB; // wave-per-row: table, 32 bytes of s_misc, retry list of the wave
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -859,16 +861,16 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
     unsigned char *base = s_raw + (WAVE_ROW ? (size_t)wave * SLOT : 0);
     Tab tab;
     tab.bind(base);
-    int *s_misc = (int *)(base + Tab::BYTES);           // block-per-row only: [0] = entries written, [1] = leftmost column
+    int *s_misc = (int *)(base + Tab::BYTES);           // block-per-row only: [0..3] entries written (per wave, or [0] shared), [4..7] leftmost columns
     RetryList<SMALL> rl;                                // block-per-row: the lists of the waves follow the shared table
-    rl.bind(base + Tab::BYTES + 16 + (WAVE_ROW ? 0 : (size_t)wave * RB));
+    rl.bind(base + Tab::BYTES + 32 + (WAVE_ROW ? 0 : (size_t)wave * RB));
     const int gg = rtid / G, gl = rtid % G;
     const ZpField F = a.F;
 
     const int count = *a.class_count;
     if ((WAVE_ROW ? (int)blockIdx.x * WPB : (int)blockIdx.x) >= count) return; // nothing for this workgroup: skip even the table reset
     for (int s = rtid; s < T; s += TPR) tab.clear(s);
-    if (rtid == 0) { s_misc[0] = 0; s_misc[1] = INT_MAX; }
+    if (rtid == 0) { s_misc[0] = 0; s_misc[4] = INT_MAX; }
     __syncthreads();
 
     const int first = WAVE_ROW ? (int)blockIdx.x * WPB + wave : (int)blockIdx.x;
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 u[r][j] = make_int2(0, 0);
-                if (gl + j * G < npn[r] && !(a.dbg & 8)) u[r][j] = up[gl + j * G];
+                if (gl + j * G < npn[r] && !SCATTER_DBG(a, 8)) u[r][j] = up[gl + j * G];
             }
         }
 #ifdef SPASM_STAMPS
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
                     bv[j] = ZpAcc<SMALL>::mul_lazy(F, nm, u[r][j].y);
                     if (gl + j * G < npn[r]) valid |= 1u << j;
                 }
-                if (a.dbg & 2) asm volatile("" ::"v"(bc[0]), "v"(bv[0]));
+                if (SCATTER_DBG(a, 2)) asm volatile("" ::"v"(bc[0]), "v"(bv[0]));
                 else table_try_n<LOGT, 3, SMALL>(tab, rl, bc, bv, valid, a.ctr);
                 const int2 *up = a.UPN + (unsigned)rec[r].z;
                 for (int k = gl + 3 * G; k < npn[r]; k += G) { // pivot rows longer than 24 entries
@@ -996,56 +998,111 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
                 if (gg + r * NG < dn.llen) rec[r] = a.Lpool[dn.l_start + gg + r * NG];
         }
         if (WAVE_ROW) __builtin_amdgcn_wave_barrier(); else lds_barrier();
-        // (E) sweep: reduce, compact, write; reset the table on the way.  U slot groups are read (64-bit) and
-        // cleared up front, the rest is branch-free: an empty slot holds accumulator 0, hence reduces to 0.
-        const i64d ss = d.s_start;
+        // (E) sweep: reduce, compact, write; reset the table on the way.  Branch-free per slot: an empty slot holds
+        // accumulator 0, hence reduces to 0.  Output addresses are row base (scalar) + 32-bit lane offset.
+        unsigned char *const rowp = (unsigned char *)(a.Sent + d.s_start);
         int mylead = INT_MAX;
-        int wbase = 0; // wave-per-row: running count of entries written
+        int n_out, lead_out;
         constexpr int NIT = T / TPR;
-        constexpr int U = NIT >= 4 ? 4 : NIT;
-        for (int it0 = 0; it0 < NIT; it0 += U) {
-            int cc[U];
-            Acc aa[U];
-#pragma unroll
-            for (int q = 0; q < U; q++) tab.read((it0 + q) * TPR + rtid, cc[q], aa[q]);
-#pragma unroll
-            for (int q = 0; q < U; q++) tab.clear((it0 + q) * TPR + rtid);
-            int vv[U];
-            u64d mm[U];
+        if constexpr (NIT <= 16) {
+            // every slot group of this wave is held in registers: count first, so that a workgroup sharing the row
+            // needs ONE exchange (counts + leftmost columns through s_misc, no atomics) before the stores
+            int cc[NIT], vv[NIT];
+            u64d mm[NIT];
             int tot = 0;
 #pragma unroll
-            for (int q = 0; q < U; q++) {
-                vv[q] = acc_reduce_short<SMALL>(F, aa[q]);
-                mm[q] = __ballot(vv[q] != 0 && !(a.dbg & 4));
-                tot += __popcll(mm[q]);
-            }
-            if (tot == 0) continue;
-            int pos = wbase;
-            if (!WAVE_ROW) { // one reservation per U slot groups and wave
-                if (lane == 0) pos = atomicAdd(&s_misc[0], tot);
-                pos = __builtin_amdgcn_readfirstlane(pos);
-            }
+            for (int q0 = 0; q0 < NIT; q0 += 4) {
+                Acc aa[4];
 #pragma unroll
-            for (int q = 0; q < U; q++) {
-                if (vv[q] != 0 && !(a.dbg & 4)) {
-                    if (!(a.dbg & 1)) { // streamed out, never re-read here: keep it from evicting the pivot rows
-                        const long long pk = ((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q];
-                        __builtin_nontemporal_store(pk, (long long *)&a.Sent[ss + pos + __popcll(mm[q] & lanemask_lt())]);
-                    }
-                    mylead = min(mylead, cc[q]);
+                for (int q = q0; q < q0 + 4 && q < NIT; q++) tab.read(q * TPR + rtid, cc[q], aa[q - q0]);
+#pragma unroll
+                for (int q = q0; q < q0 + 4 && q < NIT; q++) tab.clear(q * TPR + rtid);
+#pragma unroll
+                for (int q = q0; q < q0 + 4 && q < NIT; q++) {
+                    vv[q] = acc_reduce_short<SMALL>(F, aa[q - q0]);
+                    const bool nz = vv[q] != 0 && !SCATTER_DBG(a, 4);
+                    mm[q] = __ballot(nz);
+                    tot += __popcll(mm[q]);
+                    if (nz) mylead = min(mylead, cc[q]);
                 }
-                pos += __popcll(mm[q]);
             }
-            wbase += tot;
-        }
-        mylead = wave_min_i32(mylead);
-        int n_out = wbase, lead_out = mylead;
-        if (!WAVE_ROW) {
-            if (lane == 0 && mylead != INT_MAX) atomicMin(&s_misc[1], mylead);
-            lds_barrier();
-            n_out = s_misc[0];
-            lead_out = s_misc[1];
-            lds_barrier();
+            mylead = wave_min_i32(mylead);
+            int pos = 0;
+            n_out = tot;
+            lead_out = mylead;
+            if (!WAVE_ROW) {
+                if (lane == 0) { s_misc[wave] = tot; s_misc[4 + wave] = mylead; }
+                lds_barrier();
+                n_out = 0;
+                lead_out = INT_MAX;
+#pragma unroll
+                for (int w2 = 0; w2 < WPB; w2++) {
+                    const int cw = s_misc[w2];
+                    n_out += cw;
+                    if (w2 < wave) pos += cw;
+                    lead_out = min(lead_out, s_misc[4 + w2]);
+                }
+            }
+            if (tot != 0) {
+#pragma unroll
+                for (int q = 0; q < NIT; q++) {
+                    if (((mm[q] >> lane) & 1) && !SCATTER_DBG(a, 1)) { // streamed out, never re-read here: keep it from evicting the pivot rows
+                        const unsigned off = (unsigned)(pos + __popcll(mm[q] & lanemask_lt())) << 3;
+                        const long long pk = ((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q];
+                        __builtin_nontemporal_store(pk, (long long *)(rowp + off));
+                    }
+                    pos += __popcll(mm[q]);
+                }
+            }
+        } else {
+            // tables of more than 16 slot groups per wave: 4 groups at a time, one LDS reservation per batch
+            int wbase = 0;
+            for (int it0 = 0; it0 < NIT; it0 += 4) {
+                int cc[4], vv[4];
+                Acc aa[4];
+                u64d mm[4];
+                int tot = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) tab.read((it0 + q) * TPR + rtid, cc[q], aa[q]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) tab.clear((it0 + q) * TPR + rtid);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    vv[q] = acc_reduce_short<SMALL>(F, aa[q]);
+                    mm[q] = __ballot(vv[q] != 0 && !SCATTER_DBG(a, 4));
+                    tot += __popcll(mm[q]);
+                }
+                if (tot == 0) continue;
+                int pos = wbase;
+                if (!WAVE_ROW) {
+                    if (lane == 0) pos = atomicAdd(&s_misc[0], tot);
+                    pos = __builtin_amdgcn_readfirstlane(pos);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if ((mm[q] >> lane) & 1) {
+                        if (!SCATTER_DBG(a, 1)) {
+                            const unsigned off = (unsigned)(pos + __popcll(mm[q] & lanemask_lt())) << 3;
+                            const long long pk = ((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q];
+                            __builtin_nontemporal_store(pk, (long long *)(rowp + off));
+                        }
+                        mylead = min(mylead, cc[q]);
+                    }
+                    pos += __popcll(mm[q]);
+                }
+                wbase += tot;
+            }
+            mylead = wave_min_i32(mylead);
+            n_out = wbase;
+            lead_out = mylead;
+            if (!WAVE_ROW) {
+                if (lane == 0 && mylead != INT_MAX) atomicMin(&s_misc[4], mylead);
+                lds_barrier();
+                n_out = s_misc[0];
+                lead_out = s_misc[4];
+                lds_barrier();
+                if (rtid == 0) { s_misc[0] = 0; s_misc[4] = INT_MAX; }
+            }
         }
         if (rtid == 0) {
             a.Slen[d.t] = n_out;
@@ -1055,7 +1112,6 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
             c_rows += n_out > 0;
             c_ent += (u64d)ln_cur;
             c_seg += 1;
-            if (!WAVE_ROW) { s_misc[0] = 0; s_misc[1] = INT_MAX; }
         }
         if (WAVE_ROW) __builtin_amdgcn_wave_barrier(); else lds_barrier();
         STAMP(6); // prefetch issue + sweep + stores
