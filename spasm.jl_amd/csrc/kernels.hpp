@@ -808,17 +808,21 @@ template <> __device__ __forceinline__ int acc_reduce<false>(const ZpField &F, l
 template <bool SMALL> __device__ __forceinline__ int acc_reduce_short(const ZpField &F, typename ZpAcc<SMALL>::type acc);
 template <> __device__ __forceinline__ int acc_reduce_short<true>(const ZpField &F, int acc)
 {
-    const int p = (int)F.p, hp = (int)F.halfp, mhp = (int)F.mhalfp;
-    int r = acc - __mul24(__float2int_rn((float)acc * F.finvp), p);
-    if (r > hp) r -= p; else if (r < mhp) r += p;
-    return r;
+    // u = r - mhalfp lies in [0, p) when r is balanced; of u - p, u, u + p exactly one does, and it is the unsigned minimum
+    const int p = (int)F.p, mhp = (int)F.mhalfp;
+    const unsigned u = (unsigned)(zp_small_lazy(acc, -F.finvp, p) - mhp);
+    return (int)min(min(u, u - (unsigned)p), u + (unsigned)p) + mhp;
 }
 template <> __device__ __forceinline__ int acc_reduce_short<false>(const ZpField &F, long long acc) { return zp_reduce(F, acc); }
 
 // Diagnostic build only (-DSPASM_STAMPS): per-phase cycle sums of the scatter kernel, written to a buffer of
 // their own (ScatterArgs::stamps) that nothing else reads.  Never compiled into the shipped library.
+#if defined(SPASM_STAMPS) || defined(SPASM_ABLATE)
+#define SCATTER_DBG(a, bit) ((a).dbg & (bit)) // timing ablations (env SPASM_DBG), diagnostic builds only
+#else
+#define SCATTER_DBG(a, bit) false
+#endif
 #ifdef SPASM_STAMPS
-#define SCATTER_DBG(a, bit) ((a).dbg & (bit)) // timing ablations (env SPASM_DBG), diagnostic build only
 #define NSTAMP 8
 __device__ __forceinline__ u64d stamp_now()
 {
@@ -830,7 +834,6 @@ __device__ __forceinline__ u64d stamp_now()
 }
 #define STAMP(i) do { const u64d _n = stamp_now(); st_sum[i] += _n - st_last; st_last = _n; } while (0)
 #else
-#define SCATTER_DBG(a, bit) false
 #define STAMP(i) do { } while (0)
 #endif
 
@@ -915,11 +918,14 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
             npn[r] = (gg + r * NG < ll && rec[r].y != 0) ? rec[r].w : 0;
+            // unconditional loads, clamped into the pivot row (lanes past its end re-read its last entry, groups without a
+            // row read UPN[0]; the insert masks them out): a predicated load costs a compare, two exec updates and a branch
             const int2 *up = a.UPN + (unsigned)rec[r].z;
+            const int last = max(npn[r] - 1, 0);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 u[r][j] = make_int2(0, 0);
-                if (gl + j * G < npn[r] && !SCATTER_DBG(a, 8)) u[r][j] = up[gl + j * G];
+                if (!SCATTER_DBG(a, 8)) u[r][j] = up[min(gl + j * G, last)];
             }
         }
 #ifdef SPASM_STAMPS
@@ -1046,7 +1052,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
             if (tot != 0) {
 #pragma unroll
                 for (int q = 0; q < NIT; q++) {
-                    if (((mm[q] >> lane) & 1) && !SCATTER_DBG(a, 1)) { // streamed out, never re-read here: keep it from evicting the pivot rows
+                    if (vv[q] != 0 && !SCATTER_DBG(a, 4) && !SCATTER_DBG(a, 1)) { // streamed out, never re-read here: keep it from evicting the pivot rows
                         const unsigned off = (unsigned)(pos + __popcll(mm[q] & lanemask_lt())) << 3;
                         const long long pk = ((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q];
                         __builtin_nontemporal_store(pk, (long long *)(rowp + off));
@@ -1080,7 +1086,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    if ((mm[q] >> lane) & 1) {
+                    if (vv[q] != 0 && !SCATTER_DBG(a, 4)) {
                         if (!SCATTER_DBG(a, 1)) {
                             const unsigned off = (unsigned)(pos + __popcll(mm[q] & lanemask_lt())) << 3;
                             const long long pk = ((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q];

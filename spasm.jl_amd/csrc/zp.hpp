@@ -94,15 +94,21 @@ ZP_HD int zp_inverse(const ZpField &F, int a)
 //                     so an i32 accumulator absorbs > 60000 terms before the final zp_reduce.
 //   general:          i64 product, double quotient, |r| <= 0.51 p < 2^31.1; accumulate in i64.
 template <bool SMALL> struct ZpAcc;
+// x - rn(x/p) * p for p < 2^16 and |x/p| < 2^22 in four full-rate instructions: the quotient is read off the mantissa of
+// x * (-1/p) + 1.5 * 2^23 (one rounding, to the integer grid), whose low 24 bits are 2^22 - q; the bias 2^22 * p is folded
+// into the addend (arithmetic mod 2^32).  |result| <= p/2 + |x/p| * p * 2^-22.
+ZP_D int zp_small_lazy(int x, float ninvp, int p)
+{
+    const float g = __fmaf_rn((float)x, ninvp, 12582912.0f);
+    return __mul24(__float_as_int(g), p) + (x - (int)((unsigned)p << 22)); // v_mad_i32_i24
+}
+
 template <> struct ZpAcc<true> {
     typedef int type;
     static ZP_D int mul_lazy(const ZpField &F, int a, int b)
     {
-        // balanced residues of a prime < 2^16 and the quotient (|q| <= p/4 + 1) are 24-bit operands: full-rate
-        // v_mul_i32_i24 instead of the quarter-rate 32-bit multiply
-        int prod = __mul24(a, b);
-        int q = __float2int_rn((float)prod * F.finvp);
-        return prod - __mul24(q, (int)F.p);
+        // balanced residues of a prime < 2^16 are 24-bit operands: full-rate v_mul_i32_i24, |quotient| <= p/4 + 1
+        return zp_small_lazy(__mul24(a, b), -F.finvp, (int)F.p);
     }
 };
 template <> struct ZpAcc<false> {

@@ -1,7 +1,7 @@
 # instruction mix per kernel: bash tools/pmc_insts.sh <tag> [env...]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/pmc_$tag
-env "$@" true
+for kv in "$@"; do export "$kv"; done
 for i in 1 2; do
   case $i in
     1) C="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES";;
