@@ -933,6 +933,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(2); // waiting for them
 #endif
+        int r_ent = 0, r_seg = 0; // this row's contribution to the counters, 32-bit until the row is done
         // (C) accumulate: the own entry, then per round the (up to) 3 entries of this lane as one batch
         {
             const int oc[1] = {own.x};
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
             if (__ballot(npn[r] > 0) != 0) { // wave-uniform: the retry list is bookkept per wave
-                if (gl == 0 && npn[r] > 0) { c_ent += (u64d)npn[r]; c_seg += 1; }
+                if (gl == 0) { r_ent += npn[r]; r_seg += npn[r] > 0; }
                 const int nm = zp_neg(F, rec[r].y);
                 int bc[3];
                 Acc bv[3];
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         for (int e = gg + MAXR * NG; e < ll; e += NG) {
             const int4 le = a.Lpool[d.l_start + e];
             if (le.y == 0) continue;
-            if (gl == 0) { c_ent += (u64d)le.w; c_seg += 1; }
+            if (gl == 0) { r_ent += le.w; r_seg += 1; }
             const int nm = zp_neg(F, le.y);
             const int2 *up = a.UPN + (unsigned)le.z;
             for (int k = gl; k < le.w; k += 3 * G) {
@@ -990,6 +991,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
             if (a.qinv_r[e.x] < 0) table_add<LOGT, SMALL>(tab, e.x, (Acc)e.y, a.ctr);
         }
         retry_drain<LOGT, SMALL>(tab, rl, a.ctr);
+        c_ent += (u64d)(unsigned)r_ent;
+        c_seg += (u64d)(unsigned)r_seg;
         STAMP(5); // remainder loops + retries
         // (A') stage-1 data of the NEXT row (its own entries and multiplier records) straight into the pipeline
         // registers, which are dead from here on: these loads fly during the sweep
@@ -999,9 +1002,11 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         for (int r = 0; r < MAXR; r++) rec[r] = make_int4(0, 0, 0, 0);
         if (w + stride < count) {
             if (rtid < dn.len) own = a.ent[dn.ent_start + rtid];
+            // clamped like the pivot-row loads: groups past the end of the list re-read its last record (or Lpool[0] for an
+            // empty list) and are masked out by the test against llen when the record is used
+            const int lastrec = max(dn.llen - 1, 0);
 #pragma unroll
-            for (int r = 0; r < MAXR; r++)
-                if (gg + r * NG < dn.llen) rec[r] = a.Lpool[dn.l_start + gg + r * NG];
+            for (int r = 0; r < MAXR; r++) rec[r] = a.Lpool[dn.l_start + min(gg + r * NG, lastrec)];
         }
         if (WAVE_ROW) __builtin_amdgcn_wave_barrier(); else lds_barrier();
         // (E) sweep: reduce, compact, write; reset the table on the way.  Branch-free per slot: an empty slot holds
@@ -1404,14 +1409,18 @@ struct CombineArgs {
 };
 
 template <int LOGC, bool SMALL>
-__device__ __forceinline__ bool team_table_add(int *key, typename ZpAcc<SMALL>::type *val, int *cnt, int idx, typename ZpAcc<SMALL>::type prod)
+__device__ __forceinline__ bool team_table_add(int *key, typename ZpAcc<SMALL>::type *val, int *cnt, unsigned short *slots, int idx,
+                                               typename ZpAcc<SMALL>::type prod)
 {
     constexpr int CAPS = 1 << LOGC;
     unsigned h = ((unsigned)idx * 0x9E3779B1u) >> (32 - LOGC);
     for (int probes = 0; probes < CAPS; probes++) {
         const int kk = atomicCAS(&key[h], EMPTY_KEY, idx);
         if (kk == EMPTY_KEY || kk == idx) {
-            if (kk == EMPTY_KEY) atomicAdd(cnt, 1);
+            if (kk == EMPTY_KEY) { // a new pivot index: remember its slot, the sweep then visits the occupied slots only
+                const int p = atomicAdd(cnt, 1);
+                if (p < CAPS / 2) slots[p] = (unsigned short)h;
+            }
             if (SMALL) atomicAdd((int *)&val[h], (int)prod);
             else atomicAdd((u64d *)&val[h], (u64d)prod);
             return true;
@@ -1432,11 +1441,13 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
     __shared__ Acc s_val[TEAMS * CAPS];
     __shared__ int s_key[TEAMS * CAPS];
     __shared__ int s_cnt[TEAMS];
+    __shared__ unsigned short s_slot[TEAMS * MAXD]; // slots of the distinct pivot indices, in order of arrival
     const int team = threadIdx.x / TEAM;
     const int tl = threadIdx.x % TEAM;
     int *key = s_key + team * CAPS;
     Acc *val = s_val + team * CAPS;
     int *cnt = &s_cnt[team];
+    unsigned short *slots = s_slot + team * MAXD;
     const ZpField F = a.F;
     for (int s = tl; s < CAPS; s += TEAM) { key[s] = EMPTY_KEY; val[s] = 0; }
     if (tl == 0) *cnt = 0;
@@ -1499,10 +1510,10 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
                 }
 #pragma unroll
                 for (int j = 0; j < MAXP; j++) {
-                    if (tl < ul[j] && !team_table_add<LOGC, SMALL>(key, val, cnt, wv[j].x, ZpAcc<SMALL>::mul_lazy(F, av[j], wv[j].y))) fail = true;
+                    if (tl < ul[j] && !team_table_add<LOGC, SMALL>(key, val, cnt, slots, wv[j].x, ZpAcc<SMALL>::mul_lazy(F, av[j], wv[j].y))) fail = true;
                     for (int i = tl + TEAM; i < ul[j]; i += TEAM) { // rows of Uinv longer than the team
                         const int2 w2 = a.UinvPool[(i64d)uo[j] + i];
-                        if (!team_table_add<LOGC, SMALL>(key, val, cnt, w2.x, ZpAcc<SMALL>::mul_lazy(F, av[j], w2.y))) fail = true;
+                        if (!team_table_add<LOGC, SMALL>(key, val, cnt, slots, w2.x, ZpAcc<SMALL>::mul_lazy(F, av[j], w2.y))) fail = true;
                     }
                 }
                 if (team_ballot<TEAM>(fail) != 0) ok = false;
@@ -1547,48 +1558,40 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)dcount);
         base = __shfl(base, 0, TEAM);
         const bool room = base != ~0ull;
-        // ---- sweep 1: reduce and compact the non-zero multipliers to the front of the team's arrays
+        // ---- one pass over the occupied slots (dcount <= MAXD of them): reduce, drop the zero multipliers, fetch the
+        // headers of the applied pivot rows (gathers of a batch in flight together), records out
         int nout = 0;
-        for (int s0 = 0; s0 < CAPS; s0 += TEAM) {
-            const int s = s0 + tl;
-            const int kk = key[s];
-            int v = 0;
-            if (kk != EMPTY_KEY) v = acc_reduce<SMALL>(F, val[s]);
-            key[s] = EMPTY_KEY;
-            val[s] = 0;
-            const bool nz = v != 0;
-            const u64d m = team_ballot<TEAM>(nz);
-            if (nz) { // nout + rank <= s0 + rank <= s: only slots already consumed are overwritten
-                const int pos = nout + __popcll(m & ((1ull << tl) - 1ull));
-                key[pos] = kk;
-                val[pos] = (Acc)v;
-            }
-            nout += __popcll(m);
-        }
-        // ---- sweep 2: headers of the applied pivot rows (gathers in flight together), records out
         i64d bound = 0;
         u64d r_red = 0;
-        for (int i0 = 0; i0 < nout; i0 += 4 * TEAM) {
-            int kk[4], vv[4];
+        for (int i0 = 0; i0 < dcount; i0 += 4 * TEAM) {
+            int kk[4], vv[4], pos[4];
             UHdr hh[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int i = i0 + j * TEAM + tl;
                 kk[j] = 0; vv[j] = 0;
                 hh[j].off = 0; hh[j].npp = 0; hh[j].npn = 0; hh[j].len = 0;
-                if (i < nout) { kk[j] = key[i]; vv[j] = (int)val[i]; hh[j] = a.uhdr[kk[j]]; }
+                if (i < dcount) {
+                    const int s = slots[i];
+                    kk[j] = key[s];
+                    vv[j] = acc_reduce_short<SMALL>(F, val[s]);
+                    key[s] = EMPTY_KEY;
+                    val[s] = 0;
+                }
+                const u64d m = team_ballot<TEAM>(vv[j] != 0);
+                pos[j] = nout + __popcll(m & ((1ull << tl) - 1ull));
+                nout += __popcll(m);
+                if (vv[j] != 0) hh[j] = a.uhdr[kk[j]];
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int i = i0 + j * TEAM + tl;
-                if (i < nout) {
-                    if (room) a.Lpool[base + i] = make_int4(kk[j], vv[j], (int)hh[j].off, hh[j].npn);
+                if (vv[j] != 0) {
+                    if (room) a.Lpool[base + pos[j]] = make_int4(kk[j], vv[j], (int)hh[j].off, hh[j].npn);
                     bound += hh[j].npn;
                     r_red += (u64d)hh[j].len;
                 }
             }
         }
-        for (int i = tl; i < nout; i += TEAM) { key[i] = EMPTY_KEY; val[i] = 0; }
         for (int o = TEAM / 2; o > 0; o >>= 1) {
             bound += __shfl_xor(bound, o, TEAM);
             r_red += __shfl_xor(r_red, o, TEAM);
