@@ -770,12 +770,14 @@ __device__ __forceinline__ void table_try_n(RowTable<LOGT, SMALL> &tab, RetryLis
         if (valid & (1u << j)) k[j] = atomicCAS(tab.keyp(h[j]), EMPTY_KEY, c[j]);
     }
     u64d fm[N];
+    bool fail[N];
     int nfail = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) {
         const bool ok = (k[j] == EMPTY_KEY) || (k[j] == c[j]); // lanes without an entry read back c[j]: "ok", nothing to add
         if (ok && (valid & (1u << j))) tab.add(h[j], v[j]);
-        fm[j] = __ballot(!ok);
+        fail[j] = !ok;
+        fm[j] = __ballot(fail[j]);
         nfail += __popcll(fm[j]);
     }
     if (nfail == 0) return;
@@ -783,7 +785,7 @@ __device__ __forceinline__ void table_try_n(RowTable<LOGT, SMALL> &tab, RetryLis
     int pos = rl.cnt;
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        if ((fm[j] >> (threadIdx.x & 63)) & 1) rl.put(pos + __popcll(fm[j] & lanemask_lt()), c[j], v[j], (h[j] + st[j]) & (T - 1));
+        if (fail[j]) rl.put(pos + __popcll(fm[j] & lanemask_lt()), c[j], v[j], (h[j] + st[j]) & (T - 1));
         pos += __popcll(fm[j]);
     }
     rl.cnt = pos;
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         for (int r = 0; r < MAXR; r++) {
             if (__ballot(npn[r] > 0) != 0) { // wave-uniform: the retry list is bookkept per wave
                 if (gl == 0) { r_ent += npn[r]; r_seg += npn[r] > 0; }
-                const int nm = zp_neg(F, rec[r].y);
+                const int nm = -rec[r].y; // congruent to the canonical negative; the lazy product does not need more
                 int bc[3];
                 Acc bv[3];
                 unsigned valid = 0;
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
             const int4 le = a.Lpool[d.l_start + e];
             if (le.y == 0) continue;
             if (gl == 0) { r_ent += le.w; r_seg += 1; }
-            const int nm = zp_neg(F, le.y);
+            const int nm = -le.y;
             const int2 *up = a.UPN + (unsigned)le.z;
             for (int k = gl; k < le.w; k += 3 * G) {
                 int bc[3];
