@@ -53,10 +53,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # SPASM_BENCH_REHEARSE=1: every rank shares cuda:0 and the collectives run over gloo -- the only way to exercise the
+    # N > 1 code path on a one-GPU box (the numbers of such a run mean nothing; the JSON says "rehearsal")
+    rehearse = os.environ.get("SPASM_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
+    cdev = "cpu" if rehearse else "cuda"  # where the few scalars of the timing protocol are reduced
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import spasm_jl_amd as S
 
@@ -92,7 +101,7 @@ def main():
         except Exception as exc:  # the exchange could only be rehearsed over gloo on a 1-GPU box: keep the run measurable
             exchange = {"error": repr(exc), "fallback": "matrix replicated on every rank"}
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int64, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int64, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:  # all ranks take the same path
             if engine is not None:
@@ -133,7 +142,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -145,7 +154,7 @@ def main():
     if lib.spasm_amd_schur_plan_stats(plan, C.byref(st)) != 0:
         raise SystemExit("plan_stats failed: " + S._abi.last_error())
     d = st.as_dict()
-    counters = torch.tensor([d["nnz_reduced"], d["applications"], d["nnz_out"], d["read_bytes"], my_rows], dtype=torch.int64, device="cuda")
+    counters = torch.tensor([d["nnz_reduced"], d["applications"], d["nnz_out"], d["read_bytes"], my_rows], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     nnz_reduced, applications, nnz_out, read_bytes, rows_total = [int(v) for v in counters.tolist()]
@@ -206,7 +215,8 @@ def main():
                 "nnz_reduced_per_step": nnz_reduced,
                 "applications_per_step": applications,
                 "nnz_out": nnz_out,
-                "parallelism": f"row-block x{world}, pivot rows exchanged by all-reduce(MIN)+all-gather" if world > 1 else "single GPU",
+                "parallelism": (f"rows r, r+{world}, ... on rank r (x{world}), pivot rows exchanged by all-reduce(MIN)+all-gather" if world > 1 else "single GPU")
+                + (" -- REHEARSAL: all ranks on one GPU over gloo, timings meaningless" if rehearse else ""),
             },
             "roofline": roofline,
             "setup_s": {"generate": round(t_gen, 2), "upload_elect_buildU": round(t_setup, 2)},
