@@ -146,6 +146,7 @@ struct Round {
     DevBuf<i64d> UinvStart, ubound;
     DevBuf<int> UinvLen;
     DevBuf<int4> colinfo;           // per column: pivot index + location of its Uinv row
+    DevBuf<unsigned> pbits;         // per column: one bit, set for pivot columns
     DevBuf<i64d> rstart;            // per processed row slot: start / length of its own entries
     DevBuf<int> rlen;
     i64 uinv_nnz = 0;
@@ -455,7 +456,8 @@ struct Round {
             use_uinv = uinv_nnz <= limit && uinv_nnz < (i64)0x7fffffff;
             if (use_uinv) {
                 colinfo.ensure((size_t)m + 1);
-                hipLaunchKernelGGL(k_colinfo, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, qinv_r.p, UinvStart.p, UinvLen.p, colinfo.p);
+                pbits.ensure((size_t)cdiv(m, 256) * 8 + 2);
+                hipLaunchKernelGGL(k_colinfo, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, qinv_r.p, UinvStart.p, UinvLen.p, colinfo.p, pbits.p);
                 HIPCHK(hipGetLastError());
             }
             return;
@@ -506,6 +508,7 @@ struct Round {
             c.rlen = rlen.p;
             c.ent = M.ent.p;
             c.colinfo = colinfo.p;
+            c.pbits = pbits.p;
             c.uhdr = uhdr.p;
             c.UinvPool = UinvPool.p;
             c.Lpool = Lpool.p;
@@ -521,6 +524,10 @@ struct Round {
             c.overflow_list = overflow2_list.p;
             c.overflow_count = &ctr.p->combine_overflow;
             c.ctr = ctr.p;
+            {
+                const char *dbg = getenv("SPASM_DBG"); // timing ablations (diagnostic builds only)
+                c.dbg = dbg ? atoi(dbg) : 0;
+            }
             c.F = F;
             {
                 constexpr int TEAM = 16, LOGC = 8, TPB = 256; // up to 128 distinct pivots per row

@@ -1364,14 +1364,18 @@ __global__ void k_unit_rows(int npiv, const int *__restrict__ pivcol, i64d *__re
 // per-column record for the combine: pivot index of the column (or -1) and where its row of Uinv lives
 // (len < 0: that row of Uinv is not available)
 __global__ void k_colinfo(int m, const int *__restrict__ qinv_r, const i64d *__restrict__ UinvStart, const int *__restrict__ UinvLen,
-                          int4 *__restrict__ colinfo)
+                          int4 *__restrict__ colinfo, unsigned *__restrict__ pbits)
 {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const int q = qinv_r[j];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x; // blockDim.x is a multiple of 64: whole waves, whole bitmap words
+    const int q = j < m ? qinv_r[j] : -1;
     int4 r = make_int4(q, 0, 0, 0);
     if (q >= 0) { r.y = (int)(unsigned)UinvStart[q]; r.z = UinvLen[q]; }
-    colinfo[j] = r;
+    if (j < m) colinfo[j] = r;
+    // one bit per column: is it a pivot column?  m/8 bytes stay in L2 (the 16-byte records do not: 16 m bytes), and five of
+    // six entries of a row sit on non-pivot columns and need nothing else
+    const u64d b = __ballot(q >= 0);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 31) == 0) pbits[j >> 5] = (unsigned)(b >> lane);
 }
 
 // (start,len) of the listed rows, gathered once so that a row team reads them with one load
@@ -1390,6 +1394,8 @@ struct CombineArgs {
     const int *retry;          // when non-NULL: row slots to process (those that overflowed the previous class)
     const int *retry_count;
     const int *self_idx;
+    const unsigned *pbits;     // bit j: column j is a pivot column of this round
+    int dbg;                   // timing ablations, diagnostic builds only: 16 = no Uinv loads, 32 = no inserts, 64 = no header gathers, 128 = no record stores
     const i64d *rstart;        // per row slot: start / length of the row's own entries
     const int *rlen;
     const int2 *ent;
@@ -1411,18 +1417,14 @@ struct CombineArgs {
 };
 
 template <int LOGC, bool SMALL>
-__device__ __forceinline__ bool team_table_add(int *key, typename ZpAcc<SMALL>::type *val, int *cnt, unsigned short *slots, int idx,
-                                               typename ZpAcc<SMALL>::type prod)
+__device__ __forceinline__ bool team_table_add(int *key, typename ZpAcc<SMALL>::type *val, int idx, typename ZpAcc<SMALL>::type prod, int &fresh_slot)
 {
     constexpr int CAPS = 1 << LOGC;
     unsigned h = ((unsigned)idx * 0x9E3779B1u) >> (32 - LOGC);
     for (int probes = 0; probes < CAPS; probes++) {
         const int kk = atomicCAS(&key[h], EMPTY_KEY, idx);
         if (kk == EMPTY_KEY || kk == idx) {
-            if (kk == EMPTY_KEY) { // a new pivot index: remember its slot, the sweep then visits the occupied slots only
-                const int p = atomicAdd(cnt, 1);
-                if (p < CAPS / 2) slots[p] = (unsigned short)h;
-            }
+            if (kk == EMPTY_KEY) fresh_slot = (int)h; // a new pivot index: the caller lists its slot
             if (SMALL) atomicAdd((int *)&val[h], (int)prod);
             else atomicAdd((u64d *)&val[h], (u64d)prod);
             return true;
@@ -1442,17 +1444,14 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
     constexpr int MAXP = 4;              // Uinv rows whose loads are issued together
     __shared__ Acc s_val[TEAMS * CAPS];
     __shared__ int s_key[TEAMS * CAPS];
-    __shared__ int s_cnt[TEAMS];
     __shared__ unsigned short s_slot[TEAMS * MAXD]; // slots of the distinct pivot indices, in order of arrival
     const int team = threadIdx.x / TEAM;
     const int tl = threadIdx.x % TEAM;
     int *key = s_key + team * CAPS;
     Acc *val = s_val + team * CAPS;
-    int *cnt = &s_cnt[team];
     unsigned short *slots = s_slot + team * MAXD;
     const ZpField F = a.F;
     for (int s = tl; s < CAPS; s += TEAM) { key[s] = EMPTY_KEY; val[s] = 0; }
-    if (tl == 0) *cnt = 0;
     __syncthreads();
 
     u64d c_app = 0, c_red = 0, c_seg = 0;
@@ -1485,6 +1484,17 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         const int self = a.self_idx ? a.self_idx[t] : -1;
         int nN = 0;
         bool ok = true;
+        // distinct pivot indices met so far: the same value in every lane of the team (the team's inserts are sequential, so
+        // no LDS counter is needed: a counter hit by 16 lanes at once serialises 16-fold)
+        int dcnt = 0;
+        auto note_fresh = [&](const int fs) {
+            const u64d m = team_ballot<TEAM>(fs >= 0);
+            if (fs >= 0) {
+                const int p = dcnt + __popcll(m & ((1ull << tl) - 1ull));
+                if (p < MAXD) slots[p] = (unsigned short)fs;
+            }
+            dcnt += __popcll(m);
+        };
         // one batch of TEAM own entries: entries on pivot columns pull their row of Uinv into the table
         auto process = [&](const int2 own, const int4 ci, const bool valid) {
             const bool isP = valid && ci.x >= 0 && ci.x != self;
@@ -1507,27 +1517,37 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
                         uo[j] = (unsigned)__shfl(ci.y, src, TEAM);
                         ul[j] = __shfl(ci.z, src, TEAM);
                         if (ul[j] < 0) fail = true;
-                        if (tl < ul[j]) wv[j] = a.UinvPool[(i64d)uo[j] + tl];
+                        if (tl < ul[j] && !SCATTER_DBG(a, 16)) wv[j] = a.UinvPool[(i64d)uo[j] + tl];
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < MAXP; j++) {
-                    if (tl < ul[j] && !team_table_add<LOGC, SMALL>(key, val, cnt, slots, wv[j].x, ZpAcc<SMALL>::mul_lazy(F, av[j], wv[j].y))) fail = true;
-                    for (int i = tl + TEAM; i < ul[j]; i += TEAM) { // rows of Uinv longer than the team
-                        const int2 w2 = a.UinvPool[(i64d)uo[j] + i];
-                        if (!team_table_add<LOGC, SMALL>(key, val, cnt, slots, w2.x, ZpAcc<SMALL>::mul_lazy(F, av[j], w2.y))) fail = true;
+                    int fs = -1;
+                    if (tl < ul[j] && !SCATTER_DBG(a, 32) && !team_table_add<LOGC, SMALL>(key, val, wv[j].x, ZpAcc<SMALL>::mul_lazy(F, av[j], wv[j].y), fs)) fail = true;
+                    note_fresh(fs);
+                    for (int i0 = TEAM; i0 < ul[j]; i0 += TEAM) { // rows of Uinv longer than the team (trip count uniform in the team)
+                        const int i = i0 + tl;
+                        fs = -1;
+                        if (i < ul[j]) {
+                            const int2 w2 = a.UinvPool[(i64d)uo[j] + i];
+                            if (!team_table_add<LOGC, SMALL>(key, val, w2.x, ZpAcc<SMALL>::mul_lazy(F, av[j], w2.y), fs)) fail = true;
+                        }
+                        note_fresh(fs);
                     }
                 }
                 if (team_ballot<TEAM>(fail) != 0) ok = false;
-                if (*(volatile int *)cnt > MAXD) ok = false; // read after this team's LDS atomics (in-order LDS)
+                if (dcnt > MAXD) ok = false;
             }
         };
         {
             // the two prefetched batches: both column-record gathers in flight together
             const bool va = tl < ln, vb = tl + TEAM < ln;
             int4 ci_a = make_int4(-1, 0, 0, 0), ci_b = ci_a;
-            if (va) ci_a = a.colinfo[own_a.x];
-            if (vb) ci_b = a.colinfo[own_b.x];
+            bool pa = false, pb = false;
+            if (va) pa = (a.pbits[(unsigned)own_a.x >> 5] >> (own_a.x & 31)) & 1u;
+            if (vb) pb = (a.pbits[(unsigned)own_b.x >> 5] >> (own_b.x & 31)) & 1u;
+            if (pa) ci_a = a.colinfo[own_a.x];
+            if (pb) ci_b = a.colinfo[own_b.x];
             {
                 const u64d mA = team_ballot<TEAM>(va && ci_a.x >= 0), mB = team_ballot<TEAM>(vb && ci_b.x >= 0);
                 if (a.pmask && tl == 0) a.pmask[t] = (ln <= 32 && 2 * TEAM >= ln) ? (long long)(mA | (TEAM < 32 ? (mB << (TEAM & 31)) : 0ull)) : -1;
@@ -1540,14 +1560,16 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
             const bool valid = k < ln;
             int2 own = make_int2(0, 0);
             int4 ci = make_int4(-1, 0, 0, 0);
-            if (valid) { own = a.ent[st + k]; ci = a.colinfo[own.x]; }
+            if (valid) {
+                own = a.ent[st + k];
+                if ((a.pbits[(unsigned)own.x >> 5] >> (own.x & 31)) & 1u) ci = a.colinfo[own.x];
+            }
             process(own, ci, valid);
         }
-        const int dcount = *(volatile int *)cnt;
+        const int dcount = dcnt;
         if (!ok) {
             for (int s = tl; s < CAPS; s += TEAM) { key[s] = EMPTY_KEY; val[s] = 0; }
             if (tl == 0) {
-                *cnt = 0;
                 a.Llen[t] = -1;
                 a.Lstart[t] = 0;
                 a.bound[t] = 0;
@@ -1583,12 +1605,12 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
                 const u64d m = team_ballot<TEAM>(vv[j] != 0);
                 pos[j] = nout + __popcll(m & ((1ull << tl) - 1ull));
                 nout += __popcll(m);
-                if (vv[j] != 0) hh[j] = a.uhdr[kk[j]];
+                if (vv[j] != 0 && !SCATTER_DBG(a, 64)) hh[j] = a.uhdr[kk[j]];
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (vv[j] != 0) {
-                    if (room) a.Lpool[base + pos[j]] = make_int4(kk[j], vv[j], (int)hh[j].off, hh[j].npn);
+                    if (room && !SCATTER_DBG(a, 128)) a.Lpool[base + pos[j]] = make_int4(kk[j], vv[j], (int)hh[j].off, hh[j].npn);
                     bound += hh[j].npn;
                     r_red += (u64d)hh[j].len;
                 }
@@ -1601,13 +1623,12 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         bound += nN;
         r_red += (u64d)ln;
         if (tl == 0) {
-            *cnt = 0;
             if (!room) {
                 atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1);
                 a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0;
             } else {
                 a.Lstart[t] = (i64d)base;
-                a.Llen[t] = nout;
+                a.Llen[t] = SCATTER_DBG(a, 128) ? 0 : nout; // ablation: the scatter must not read records that were never written
                 a.bound[t] = bound < (i64d)a.free_cols ? bound : (i64d)a.free_cols;
                 c_app += (u64d)nout;
                 c_red += r_red;
