@@ -53,7 +53,17 @@ template <class T> struct DevBuf {
     {
         release();
         if (count == 0) count = 1;
-        HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+        const hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            (void)hipGetLastError();
+            char b[256];
+            snprintf(b, sizeof b, "device allocation of %.2f GiB failed: %s (%.1f of %.1f GiB free)", (double)(count * sizeof(T)) / 1073741824.0,
+                     hipGetErrorString(e), (double)fr / 1073741824.0, (double)tot / 1073741824.0);
+            throw EngineError(b);
+        }
         n = count;
     }
     void ensure(size_t count) { if (count > n) alloc(count); }
@@ -153,6 +163,7 @@ struct Round {
     // solve
     DevBuf<int4> Lpool;
     DevBuf<u64d> pool_ctr;          // NPOOL sharded bump counters
+    int npool_active = NPOOL;       // regions in use by the current solve
     u64d region_cap = 0;
     DevBuf<i64d> Lstart, bound, sstart;
     DevBuf<int> Llen, overflow_list, overflow2_list, fail_list;
@@ -293,8 +304,9 @@ struct Round {
         fail_list.ensure((size_t)nrows + 1);
         overflow2_list.ensure((size_t)nrows + 1);
         pmask.ensure((size_t)nrows + 1);
-        region_cap = ((u64d)lpool_entries + NPOOL - 1) / NPOOL;
-        Lpool.ensure((size_t)(region_cap * NPOOL) + 1);
+        npool_active = std::min(NPOOL, std::max(1, nrows / 4));
+        region_cap = ((u64d)lpool_entries + npool_active - 1) / npool_active;
+        Lpool.ensure((size_t)(region_cap * npool_active) + 1);
         pool_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
         alloc_big();
         ctr.ensure(NCTR);
@@ -399,8 +411,9 @@ struct Round {
         i64 pool = std::max<i64>(24 * (i64)npiv, 1 << 16);
         const i64 limit = 96 * (i64)npiv + (1 << 16); // beyond this average reach the combine would cost more than the chains
         for (;;) {
-            const u64d ucap = ((u64d)pool + NPOOL - 1) / NPOOL;
-            UinvPool.ensure((size_t)(ucap * NPOOL) + 1);
+            npool_active = std::min(NPOOL, std::max(1, npiv / 4));
+            const u64d ucap = ((u64d)pool + npool_active - 1) / npool_active;
+            UinvPool.ensure((size_t)(ucap * npool_active) + 1);
             pool_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
             HIPCHK(hipMemsetAsync(ctr.p, 0, NCTR * sizeof(RoundCounters), stream));
             HIPCHK(hipMemsetAsync(pool_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
@@ -418,6 +431,7 @@ struct Round {
             a.Lpool2 = UinvPool.p;
             a.lpool_cap = ucap;
             a.pool_ctr = pool_ctr.p;
+            a.npool = npool_active;
             a.Lstart = UinvStart.p;
             a.Llen = UinvLen.p;
             a.bound = ubound.p;
@@ -488,6 +502,7 @@ struct Round {
         a.Lpool2 = nullptr;
         a.lpool_cap = region_cap;
         a.pool_ctr = pool_ctr.p;
+            a.npool = npool_active;
         a.Lstart = Lstart.p;
         a.Llen = Llen.p;
         a.bound = bound.p;
@@ -514,6 +529,7 @@ struct Round {
             c.Lpool = Lpool.p;
             c.lpool_cap = region_cap;
             c.pool_ctr = pool_ctr.p;
+            c.npool = npool_active;
             c.Lstart = Lstart.p;
             c.Llen = Llen.p;
             c.bound = bound.p;
@@ -580,21 +596,27 @@ struct Round {
         HIPCHK(hipMemcpyAsync(h.data(), pool_ctr.p, h.size() * sizeof(u64d), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         u64d mx = 0;
-        for (int r = 0; r < NPOOL; r++) mx = std::max(mx, h[(size_t)r * POOL_STRIDE]);
-        return mx * NPOOL;
+        for (int r = 0; r < npool_active; r++) mx = std::max(mx, h[(size_t)r * POOL_STRIDE]);
+        return mx * (u64d)npool_active;
     }
 
     // solve + bounds with automatic growth of the multiplier pool; returns the total bound of S
-    i64 solve_phase(const DevMat &M, const int *rows, const int *self_idx, int nrows, i64 lpool_guess)
+    // returns -1 when the multiplier records of these rows would need more than max_pool entries (the caller then
+    // processes fewer rows at a time)
+    i64 solve_phase(const DevMat &M, const int *rows, const int *self_idx, int nrows, i64 lpool_guess, i64 max_pool = ((i64)1 << 62))
     {
-        i64 pool = std::max<i64>(lpool_guess, 1 << 16);
+        i64 pool = std::min<i64>(std::max<i64>(lpool_guess, 1 << 16), max_pool);
         for (;;) {
             alloc_solve(nrows, pool);
             run_solve(M, rows, self_idx, nrows);
             run_bounds(nrows);
             const RoundCounters c = read_counters();
             const i64 tot = fetch_total_bound(nrows); // synchronises
-            if (c.lpool_overflow) { pool = std::max<i64>(pool * 2, (i64)(pool_used() * 5 / 4) + 1024); continue; }
+            if (c.lpool_overflow) {
+                if (pool >= max_pool) return -1;
+                pool = std::min<i64>(std::max<i64>(pool * 2, (i64)(pool_used() * 5 / 4) + 1024), max_pool);
+                continue;
+            }
             return tot;
         }
     }
@@ -1074,33 +1096,138 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         R->mark_local(*cur, 0);
         R->build_U(*cur, R->pivrow.p);
         R->prepare_uinv(R->nnp);
-        HIPCHK(hipEventRecord(R->ev[1], stream));
         const int nnp = R->nnp;
-        const i64 tot = R->solve_phase(*cur, R->np_rows.p, nullptr, nnp, 4 * cur_nnz);
-        HIPCHK(hipEventRecord(R->ev[2], stream));
-        R->S.ent.ensure((size_t)tot + 1);
-        R->run_scatter(*cur, R->np_rows.p, nnp);
-        HIPCHK(hipEventRecord(R->ev[3], stream));
-        R->fetch_counters();
+        // The multiplier records and the slots of the Schur rows of ALL non-pivot rows normally fit (config 3: 0.5 + 4.6 GB).
+        // Rounds whose rows reach tens of thousands of pivots (Macaulay-like) can need more than the device has: the rows
+        // are then reduced in batches, each appended compactly to the matrix of the next round.
+        size_t mem_free = 0, mem_total = 0;
+        HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
+        i64 avail = (i64)mem_free + (i64)(R->Lpool.n * sizeof(int4)) + (i64)(R->S.ent.n * sizeof(int2));
+        i64 floor_entries = 1 << 20;
+        if (const char *mb = getenv("SPASM_AMD_MEM_BUDGET_MB")) { // tests: pretend the device is this small
+            avail = std::max<i64>(atoll(mb), 1) << 20;
+            floor_entries = 1 << 10;
+        }
+        const i64 max_pool = std::max<i64>((i64)(0.40 * (double)avail) / (i64)sizeof(int4), floor_entries);
+        const i64 max_slots = std::max<i64>((i64)(0.30 * (double)avail) / (i64)sizeof(int2), floor_entries);
+        std::unique_ptr<DevMat> next(new DevMat());
+        next->n = nnp;
+        next->m = m;
+        RoundCounters acc;
+        memset(&acc, 0, sizeof acc);
+        int acc_class[NCLASS] = {0};
+        float ms_solve = 0, ms_scatter = 0;
+        i64 appended = 0; // entries of next->ent in use (batched rounds)
+        int off = 0, chunk = nnp, nbatch = 0;
+        float ms_pivots = 0;
+        DevBuf<i64d> app_scan;
+        // records and slots per row, measured on the first rows: a pool that turns out too small costs a whole solve
+        double rec_per_row = 4.0 * (double)cur_nnz / (double)std::max(nnp, 1), slots_per_row = 0;
+        if (nnp > 16384) {
+            const int probe = 2048;
+            const i64 tp = R->solve_phase(*cur, R->np_rows.p, nullptr, probe, 1 << 20, max_pool);
+            if (tp >= 0) {
+                rec_per_row = std::max(rec_per_row, 1.25 * (double)R->pool_used() / probe);
+                slots_per_row = 1.25 * (double)tp / probe;
+            } else {
+                rec_per_row = (double)max_pool / probe;
+            }
+            const double fit = std::min((double)max_pool / std::max(rec_per_row, 1.0), slots_per_row > 0 ? (double)max_slots / slots_per_row : 1e18);
+            if (fit < (double)nnp) chunk = std::max(1, (int)(0.8 * fit));
+        }
+        while (off < nnp || nnp == 0) {
+            const int cnt = std::min(chunk, nnp - off);
+            HIPCHK(hipEventRecord(R->ev[1], stream));
+            const i64 tot = R->solve_phase(*cur, R->np_rows.p + off, nullptr, cnt, std::max<i64>((i64)(rec_per_row * (double)cnt), 1 << 16), max_pool);
+            if (tot < 0 || tot > max_slots) {
+                if (cnt <= 1) throw EngineError("one row of the Schur complement does not fit the device memory");
+                chunk = std::max(1, cnt / 2);
+                spasm_logf("[echelonize] round %d: %d rows at a time do not fit the device memory, trying %d\n", round, cnt, chunk);
+                continue;
+            }
+            HIPCHK(hipEventRecord(R->ev[2], stream));
+            R->S.ent.ensure((size_t)tot + 1);
+            R->run_scatter(*cur, R->np_rows.p + off, cnt);
+            HIPCHK(hipEventRecord(R->ev[3], stream));
+            R->fetch_counters();
+            {
+                float ms = 0;
+                if (nbatch == 0 && hipEventElapsedTime(&ms, R->ev[0], R->ev[1]) == hipSuccess) ms_pivots = ms; // incl. the probe
+                if (hipEventElapsedTime(&ms, R->ev[1], R->ev[2]) == hipSuccess) ms_solve += ms;
+                if (hipEventElapsedTime(&ms, R->ev[2], R->ev[3]) == hipSuccess) ms_scatter += ms;
+            }
+            acc.applications += R->hctr.applications;
+            acc.nnz_reduced += R->hctr.nnz_reduced;
+            acc.segments += R->hctr.segments;
+            acc.nonempty_out += R->hctr.nonempty_out;
+            acc.nnz_out += R->hctr.nnz_out;
+            for (int c = 0; c < 8; c++) { acc.class_ent[c] += R->hctr.class_ent[c]; acc.class_seg[c] += R->hctr.class_seg[c]; }
+            for (int c = 0; c < NCLASS; c++) acc_class[c] += R->hclass_count[c];
+            nbatch++;
+            if (off == 0 && cnt == nnp) {
+                // the whole round at once: its slots become the next matrix as they are
+                next->start = std::move(R->S.start);
+                next->len = std::move(R->S.len);
+                next->lead = std::move(R->S.lead);
+                next->orig = std::move(R->S.orig);
+                next->ent = std::move(R->S.ent);
+            } else {
+                if (off == 0) {
+                    next->start.ensure((size_t)nnp + 1);
+                    next->len.ensure((size_t)nnp + 1);
+                    next->lead.ensure((size_t)nnp + 1);
+                    next->orig.ensure((size_t)nnp + 1);
+                }
+                const i64 add = (i64)R->hctr.nnz_out;
+                if ((size_t)(appended + add + 1) > next->ent.n) { // grow geometrically, keep what is there
+                    DevBuf<int2> bigger;
+                    bigger.alloc((size_t)std::max<i64>(appended + add + 1, (i64)((double)next->ent.n * 1.5)));
+                    if (appended > 0) HIPCHK(hipMemcpyAsync(bigger.p, next->ent.p, (size_t)appended * sizeof(int2), hipMemcpyDeviceToDevice, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                    next->ent = std::move(bigger);
+                }
+                app_scan.ensure((size_t)cnt + 2);
+                hipLaunchKernelGGL(k_copy_len64, dim3(cdiv((i64)cnt + 1, 256)), dim3(256), 0, stream, cnt, R->S.len.p, app_scan.p);
+                HIPCHK(hipGetLastError());
+                R->scan.exclusive(app_scan.p, app_scan.p, (size_t)cnt + 1, stream);
+                constexpr int TEAM = 16;
+                hipLaunchKernelGGL((k_append_rows<TEAM>), dim3(cdiv((i64)cnt * TEAM, 256)), dim3(256), 0, stream, cnt, R->S.start.p, R->S.len.p,
+                                   R->S.lead.p, R->S.orig.p, R->S.ent.p, app_scan.p, (i64d)appended, off, next->ent.p, next->start.p,
+                                   next->len.p, next->lead.p, next->orig.p);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(stream));
+                appended += add;
+            }
+            off += cnt;
+            if (nnp == 0) break;
+        }
+        if (nbatch > 1) {
+            // the pools of a batched round are as large as the device allows: give them back before the next round
+            R->Lpool.release();
+            R->S.ent.release();
+        }
+        R->hctr.applications = acc.applications;
+        R->hctr.nnz_reduced = acc.nnz_reduced;
+        R->hctr.segments = acc.segments;
+        R->hctr.nonempty_out = acc.nonempty_out;
+        R->hctr.nnz_out = acc.nnz_out;
+        for (int c = 0; c < 8; c++) { R->hctr.class_ent[c] = acc.class_ent[c]; R->hctr.class_seg[c] = acc.class_seg[c]; }
+        for (int c = 0; c < NCLASS; c++) R->hclass_count[c] = acc_class[c];
         append_round_U(U, *R, *cur, stream);
 
         spasm_amd_round_stats st;
         fill_stats(st, *R, round, cur->n, cur_nnz);
+        st.ms_pivots = ms_pivots;
+        st.ms_solve = ms_solve;
+        st.ms_scatter = ms_scatter;
+        st.ms_total = ms_pivots + ms_solve + ms_scatter;
         g_last_rounds.push_back(st);
         spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found [%.1fs]\n", round, R->npiv, st.ms_pivots * 1e-3);
-        spasm_logf("Schur complement: %d * %d [%lld nz / density= %.3f], %.1fs\n", nnp, m - (int)U.pivcol.size(),
+        spasm_logf("Schur complement: %d * %d [%lld nz / density= %.3f], %.1fs%s\n", nnp, m - (int)U.pivcol.size(),
                    (long long)st.nnz_out, nnp > 0 && m > 0 ? (double)st.nnz_out / ((double)nnp * (double)m) : 0.0,
-                   (st.ms_solve + st.ms_scatter) * 1e-3);
+                   (st.ms_solve + st.ms_scatter) * 1e-3, nbatch > 1 ? " (in batches of rows)" : "");
 
         // the Schur complement becomes the matrix of the next round
-        std::unique_ptr<DevMat> next(new DevMat());
-        next->n = nnp;
-        next->m = m;
-        next->start = std::move(R->S.start);
-        next->len = std::move(R->S.len);
-        next->lead = std::move(R->S.lead);
-        next->orig = std::move(R->S.orig);
-        next->ent = std::move(R->S.ent);
         cur = std::move(next);
         cur_nnz = st.nnz_out;
         cur_live = st.rows_out;

@@ -69,9 +69,9 @@ struct RoundCounters {
 
 // bump allocation of n entries from the region of this workgroup; returns the absolute offset in the pool,
 // or ~0 when the region is full (the host then grows the pool and reruns)
-__device__ __forceinline__ u64d pool_alloc(u64d *counters, u64d region_cap, u64d n)
+__device__ __forceinline__ u64d pool_alloc(u64d *counters, u64d region_cap, u64d n, int npool)
 {
-    const unsigned region = blockIdx.x % NPOOL;
+    const unsigned region = blockIdx.x % (unsigned)npool; // npool <= NPOOL regions are in use (fewer when there are few rows)
     const u64d pos = atomicAdd(&counters[(size_t)region * POOL_STRIDE], n);
     if (pos + n > region_cap) return ~0ull;
     return (u64d)region * region_cap + pos;
@@ -312,6 +312,7 @@ struct SolveArgs {
     int2 *Lpool2;              // when non-NULL the list is published as {pivot index, value} instead (rows of Uinv)
     u64d lpool_cap;            // entries per pool region
     u64d *pool_ctr;            // NPOOL bump counters, POOL_STRIDE words apart
+    int npool;                 // regions in use: min(NPOOL, rows / 4), so that a handful of rows can use the whole pool
     i64d *Lstart;
     int *Llen;
     i64d *bound;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(TPB) void k_solve(SolveArgs a)
         } else {
             // ---- publish the multipliers
             u64d base = 0;
-            if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)cnt);
+            if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)cnt, a.npool);
             base = __shfl(base, 0, TEAM);
             if (base == ~0ull) {
                 if (tl == 0) { atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
@@ -1328,6 +1329,28 @@ __global__ void k_copy_len64(int n, const int *__restrict__ len, i64d *__restric
     if (i == n) out[i] = 0;
 }
 
+// rows of a batch of the round appended compactly to the matrix of the next round: entries to dst + ostart[i],
+// row i of the batch becomes row row_off + i with start dst_off + ostart[i]
+template <int TEAM>
+__global__ void k_append_rows(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int *__restrict__ lead,
+                              const int *__restrict__ orig, const int2 *__restrict__ ent, const i64d *__restrict__ ostart, i64d dst_off,
+                              int row_off, int2 *__restrict__ dst, i64d *__restrict__ dstart, int *__restrict__ dlen, int *__restrict__ dlead,
+                              int *__restrict__ dorig)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i >= n) return;
+    const i64d st = start[i], os = dst_off + ostart[i];
+    const int ln = len[i];
+    for (int k = tl; k < ln; k += TEAM) dst[os + k] = ent[st + k];
+    if (tl == 0) {
+        dstart[row_off + i] = os;
+        dlen[row_off + i] = ln;
+        dlead[row_off + i] = lead[i];
+        dorig[row_off + i] = orig[i];
+    }
+}
+
 template <int TEAM>
 __global__ void k_compact_rows(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent,
                                const i64d *__restrict__ ostart, int *__restrict__ oj, int *__restrict__ ox)
@@ -1405,6 +1428,7 @@ struct CombineArgs {
     int4 *Lpool;
     u64d lpool_cap;            // entries per pool region
     u64d *pool_ctr;
+    int npool;
     i64d *Lstart;
     int *Llen;
     i64d *bound;
@@ -1579,7 +1603,7 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
             continue;
         }
         u64d base = 0;
-        if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)dcount);
+        if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)dcount, a.npool);
         base = __shfl(base, 0, TEAM);
         const bool room = base != ~0ull;
         // ---- one pass over the occupied slots (dcount <= MAXD of them): reduce, drop the zero multipliers, fetch the
@@ -1746,7 +1770,7 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
             wbase = found; // the same word may hold further pivots
         }
         // publish
-        if (tid == 0) s_base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)cnt);
+        if (tid == 0) s_base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)cnt, a.npool);
         __syncthreads();
         const u64d base = s_base;
         if (base == ~0ull) {

@@ -237,6 +237,31 @@ def test_config5_macaulay_style_scaled_down(S, O):
         assert sorted(zip(K.j[lo:hi].tolist(), K.x[lo:hi].tolist())) == sorted(zip(oK.j[lo2:hi2].tolist(), oK.x[lo2:hi2].tolist()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,m,kw,prime", [(1, 6000, 6000, dict(row_nnz=10), 65521), (2, 6000, 2400, dict(row_nnz=40), 127),
+                                              (0, 3000, 3000, dict(density=2e-3), 0xfffffffb)])
+def test_rounds_in_row_batches_when_memory_is_short(S, O, monkeypatch, kind, n, m, kw, prime):
+    """A round whose multiplier records / Schur slots exceed the device memory is reduced in batches of rows that are
+    appended to the next round's matrix. Forced here by a 32 MB budget; U, rank and kernel must not change."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xB47C4, **kw)
+    ref = S.echelonize(A, enable_dense=False)
+    ref_rounds = S.last_rounds()
+    monkeypatch.setenv("SPASM_AMD_MEM_BUDGET_MB", "32")
+    try:
+        got = S.echelonize(A, enable_dense=False)
+        got_rounds = S.last_rounds()
+    finally:
+        monkeypatch.delenv("SPASM_AMD_MEM_BUDGET_MB")
+    assert got.r == ref.r == O.echelonize(A).r
+    assert np.asarray(got.qinv).tolist() == np.asarray(ref.qinv).tolist()
+    assert len(got_rounds) == len(ref_rounds)
+    for a, b in zip(got_rounds, ref_rounds):  # same pivots, same eliminations, same Schur complements round by round
+        for key in ("npiv", "nnz_reduced", "applications", "nnz_out", "rows_out"):
+            assert a[key] == b[key], (key, a, b)
+    assert got.U.rows() == ref.U.rows()
+    assert S.kernel(got).rows() == S.kernel(ref).rows()
+
+
 # ---- one Schur round (the benchmark's unit of work) vs the oracle -------------------------------
 
 def run_plan(S, A, lo=0, hi=None, stride=1):

@@ -1,0 +1,15 @@
+"""Times echelonize of a Macaulay-like matrix (BASELINE config 5 shape at 1/SCALE) on the GPU, no oracle:
+   python tools/time_c5.py [scale=25]     (scale 1 = 5M x 2M)"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import spasm_jl_amd as S
+scale = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+n, m = 5_000_000 // scale, 2_000_000 // scale
+t0 = time.time(); A = S.synth_csr(2, n, m, row_nnz=40, prime=127, seed=0x5A5A0005); t1 = time.time()
+print(f"generated {n} x {m}, nnz {S.nnz(A)} in {t1-t0:.2f}s", flush=True)
+t0 = time.time(); fact = S.echelonize(A, verbose=("-v" in sys.argv)); t1 = time.time()
+print(f"echelonize {t1-t0:.3f}s rank {fact.r} nnz(U) {S.nnz(fact.U)}", flush=True)
+for r in S.last_rounds():
+    print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k in ("round","rows_in","nnz_in","npiv","rows_out","nnz_out","nnz_reduced","ms_pivots","ms_solve","ms_scatter","dense")}, flush=True)
+t0 = time.time(); K = S.kernel(fact); t1 = time.time()
+print(f"kernel {t1-t0:.3f}s dim {K.n} nnz(K) {S.nnz(K)}")
