@@ -238,15 +238,15 @@ def test_config5_macaulay_style_scaled_down(S, O):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,n,m,kw,prime", [(1, 6000, 6000, dict(row_nnz=10), 65521), (2, 6000, 2400, dict(row_nnz=40), 127),
-                                              (0, 3000, 3000, dict(density=2e-3), 0xfffffffb)])
+@pytest.mark.parametrize("kind,n,m,kw,prime", [(1, 2500, 2500, dict(row_nnz=10), 65521), (2, 4000, 1600, dict(row_nnz=40), 127),
+                                              (0, 2500, 2500, dict(density=2e-3), 0xfffffffb)])
 def test_rounds_in_row_batches_when_memory_is_short(S, O, monkeypatch, kind, n, m, kw, prime):
     """A round whose multiplier records / Schur slots exceed the device memory is reduced in batches of rows that are
-    appended to the next round's matrix. Forced here by a 32 MB budget; U, rank and kernel must not change."""
+    appended to the next round's matrix. Forced here by a 16 MB budget; U, rank and kernel must not change."""
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xB47C4, **kw)
     ref = S.echelonize(A, enable_dense=False)
     ref_rounds = S.last_rounds()
-    monkeypatch.setenv("SPASM_AMD_MEM_BUDGET_MB", "32")
+    monkeypatch.setenv("SPASM_AMD_MEM_BUDGET_MB", "16")
     try:
         got = S.echelonize(A, enable_dense=False)
         got_rounds = S.last_rounds()
