@@ -190,6 +190,8 @@ struct Round {
     int free_cols = 0;
     // timing
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side = nullptr;     // the few rows of the largest table classes run beside the others
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_cls[NCLASS + 1];
     int hclass_count[NCLASS];
     int nhash_used = 0;
@@ -209,6 +211,9 @@ struct Round {
     {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : ev_cls) if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
     }
 
     // ---- (1a) local candidates: best[j] = min over local rows with leftmost column j of (len, global row)
@@ -480,11 +485,14 @@ struct Round {
 
     void run_solve(const DevMat &M, const int *rows, const int *self_idx, int nrows)
     {
-        HIPCHK(hipMemsetAsync(ctr.p, 0, NCTR * sizeof(RoundCounters), stream));
-        HIPCHK(hipMemsetAsync(pool_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
-        HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
-        HIPCHK(hipMemsetAsync(bound.p + nrows, 0, sizeof(i64d), stream));
-        HIPCHK(hipMemsetAsync(pmask.p, 0xff, ((size_t)nrows + 1) * sizeof(long long), stream)); // -1: no mask
+        {
+            static_assert(sizeof(RoundCounters) % 4 == 0, "cleared word by word");
+            const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), npool_words = NPOOL * POOL_STRIDE;
+            const int span = std::max(std::max(nctr_words, npool_words), nrows + 1);
+            hipLaunchKernelGGL(k_solve_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, nrows, (unsigned *)ctr.p, nctr_words, pool_ctr.p,
+                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p);
+            HIPCHK(hipGetLastError());
+        }
         if (nrows == 0) return;
         SolveArgs a;
         a.nrows = nrows;
@@ -547,7 +555,7 @@ struct Round {
             c.F = F;
             {
                 constexpr int TEAM = 16, LOGC = 8, TPB = 256; // up to 128 distinct pivots per row
-                const int grid = std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 16);
+                const int grid = std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 8);
                 if (F.small) hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, true>), dim3(grid), dim3(TPB), 0, stream, c);
                 else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
                 HIPCHK(hipGetLastError());
@@ -686,8 +694,21 @@ struct Round {
         a.stamps = stamps.p;
 #endif
         nhash_used = nhash;
-        for (int c = 0; c < nhash; c++) {
-            if (class_timing) HIPCHK(hipEventRecord(ev_cls[c], stream));
+        // The classes with the largest tables hold few rows (config 3: 7829 and 51 of 830527), each a long serial job of one
+        // workgroup: launched after the others they are a tail on a nearly empty chip (0.27 of 4.1 ms; 74 of 760 us for a
+        // 1/8 shard).  They go first, on a side stream, and the wide classes fill the rest of the chip meanwhile.
+        const int first_side = 6;
+        const bool use_side = !class_timing && nhash > first_side;
+        if (use_side) {
+            if (!side) {
+                HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(ev_fork, stream));
+            HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
+        }
+        auto launch_class = [&](int c, hipStream_t s) {
             a.cls = c;
             a.class_count = class_count.p + c;
             a.desc = class_desc.p + (size_t)c * nrows;
@@ -696,11 +717,10 @@ struct Round {
             if (per_cu < 1) per_cu = 1;
             const int rows_per_block = kClasses[c].tpr == 64 ? kClasses[c].wpb : 1;
             const int grid = std::max(1, std::min(cdiv(nrows, rows_per_block), num_cu * per_cu));
-            if (F.small) launch_scatter_class<true>(c, a, grid, lds, stream);
-            else launch_scatter_class<false>(c, a, grid, lds, stream);
-        }
-        if (class_timing) HIPCHK(hipEventRecord(ev_cls[nhash], stream));
-        {
+            if (F.small) launch_scatter_class<true>(c, a, grid, lds, s);
+            else launch_scatter_class<false>(c, a, grid, lds, s);
+        };
+        auto launch_big = [&](hipStream_t s) {
             // rows that fit no LDS table: the last class, through the global-memory kernel
             if (bigsc_m != m) {
                 const i64 per = std::max<i64>((i64)m, 1) * 13; // bytes per workgroup: 8 accumulator + 4 list + bitmap
@@ -710,8 +730,8 @@ struct Round {
                 sc_xdense.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));
                 sc_bitmap.alloc((size_t)bigsc_blocks * nw);
                 sc_touched.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));
-                sc_xdense.zero(stream);
-                sc_bitmap.zero(stream);
+                sc_xdense.zero(s);
+                sc_bitmap.zero(s);
             }
             BigScatterArgs bb;
             bb.s = a;
@@ -723,8 +743,22 @@ struct Round {
             bb.xdense = sc_xdense.p;
             bb.bitmap = sc_bitmap.p;
             bb.touched = sc_touched.p;
-            hipLaunchKernelGGL(k_scatter_big, dim3(bigsc_blocks), dim3(256), 0, stream, bb);
+            hipLaunchKernelGGL(k_scatter_big, dim3(bigsc_blocks), dim3(256), 0, s, bb);
             HIPCHK(hipGetLastError());
+        };
+        if (use_side) {
+            for (int c = nhash - 1; c >= first_side; c--) launch_class(c, side); // longest rows first
+            launch_big(side);
+            HIPCHK(hipEventRecord(ev_join, side));
+            for (int c = 0; c < first_side; c++) launch_class(c, stream);
+            HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
+        } else {
+            for (int c = 0; c < nhash; c++) {
+                if (class_timing) HIPCHK(hipEventRecord(ev_cls[c], stream));
+                launch_class(c, stream);
+            }
+            if (class_timing) HIPCHK(hipEventRecord(ev_cls[nhash], stream));
+            launch_big(stream);
         }
         hipLaunchKernelGGL(k_scatter_mark_failed, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, Llen.p, S.len.p, S.lead.p);
         HIPCHK(hipGetLastError());
