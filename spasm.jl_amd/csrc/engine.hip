@@ -329,7 +329,9 @@ struct Round {
         if (big_npiv == npiv && big_blocks > 0) return;
         // the dense fallback keeps npiv * 20 bytes per workgroup; stay under ~2 GB
         const i64 per = std::max<i64>((i64)npiv, 1) * 20;
-        big_blocks = (int)std::max<i64>(1, std::min<i64>(num_cu, ((i64)2 << 30) / per));
+        // the kernel is a chain of dependent round trips per popped pivot: rows in flight are its throughput, so as many
+        // one-wave workgroups as the chip holds (32 per CU), within 16 GiB of scratch
+        big_blocks = (int)std::max<i64>(1, std::min<i64>((i64)num_cu * 32, ((i64)16 << 30) / per));
         big_npiv = npiv;
         const size_t nw = ((size_t)std::max(npiv, 1) + 31) / 32;
         xdense.alloc((size_t)big_blocks * (size_t)std::max(npiv, 1));
@@ -367,10 +369,11 @@ struct Round {
             b.s.overflow_count = nullptr;
             static bool attr_done = false;
             if (!attr_done) {
-                HIPCHK(hipFuncSetAttribute((const void *)k_solve_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                HIPCHK(hipFuncSetAttribute((const void *)k_solve_big<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 attr_done = true;
             }
-            hipLaunchKernelGGL(k_solve_big<true>, dim3(big_blocks), dim3(256), lds_dense, stream, b);
+            const int per_cu = (int)std::max<size_t>(1, (size_t)(160 * 1024) / (lds_dense + 64));
+            hipLaunchKernelGGL((k_solve_big<true, 256>), dim3(std::min(big_blocks, num_cu * per_cu)), dim3(256), lds_dense, stream, b);
             HIPCHK(hipGetLastError());
             return;
         }
@@ -388,7 +391,7 @@ struct Round {
         b.s.retry_count = &ctr.p->solve_failed;
         b.s.overflow_list = nullptr;
         b.s.overflow_count = nullptr;
-        hipLaunchKernelGGL(k_solve_big<false>, dim3(big_blocks), dim3(256), 0, stream, b);
+        hipLaunchKernelGGL((k_solve_big<false, 64>), dim3(big_blocks), dim3(64), 0, stream, b);
         HIPCHK(hipGetLastError());
     }
 
@@ -452,6 +455,14 @@ struct Round {
                 constexpr int TEAM = 8, CAP = 128, TPB = 256;
                 hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(cdiv((i64)npiv * TEAM, TPB)), dim3(TPB), 0, stream, a);
                 HIPCHK(hipGetLastError());
+            }
+            {
+                // pivots whose own reach exceeds the first class (128) already account for more than the budget of Uinv:
+                // do not spend seconds in the second class to find that out (Macaulay-like rounds)
+                int novf = 0;
+                HIPCHK(hipMemcpyAsync(&novf, &ctr.p->solve_overflow, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                if ((i64)novf * 128 > limit) return;
             }
             a.retry = overflow_list.p;
             a.retry_count = &ctr.p->solve_overflow;
@@ -724,7 +735,7 @@ struct Round {
             // rows that fit no LDS table: the last class, through the global-memory kernel
             if (bigsc_m != m) {
                 const i64 per = std::max<i64>((i64)m, 1) * 13; // bytes per workgroup: 8 accumulator + 4 list + bitmap
-                bigsc_blocks = (int)std::max<i64>(1, std::min<i64>(32, ((i64)1 << 30) / per));
+                bigsc_blocks = (int)std::max<i64>(1, std::min<i64>((i64)num_cu * 8, ((i64)16 << 30) / per)); // rows in flight are its throughput
                 bigsc_m = m;
                 const size_t nw = ((size_t)std::max(m, 1) + 31) / 32;
                 sc_xdense.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));

@@ -1702,8 +1702,10 @@ struct BigSolveArgs {
 // LDSX = true: the value vector and the bitmap live in LDS (dynamic shared memory: 4*npiv + 4*nwords bytes, so only
 // for rounds with up to ~30000 pivots): the same algorithm at LDS latency, the class that takes over from the
 // small sorted lists when it fits.
-template <bool LDSX>
-__global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
+// NT = threads per row: 256 for the LDS variant (one or two rows per CU anyway); 64 for the global one, where the work per
+// popped pivot is a handful of entries and the rows in flight (x4 with one wave per row) are the throughput
+template <bool LDSX, int NT>
+__global__ __launch_bounds__(NT) void k_solve_big(BigSolveArgs b)
 {
     const SolveArgs &a = b.s;
     __shared__ int s_word;       // index of the word holding the next pending pivot, INT_MAX if none in the window
@@ -1716,8 +1718,8 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
     unsigned *bm = LDSX ? (unsigned *)(s_dyn + (size_t)b.npiv * 4) : b.bitmap + (size_t)blockIdx.x * b.nwords;
     int4 *out = b.scratch + (size_t)blockIdx.x * b.npiv;
     if (LDSX) {
-        for (int i = tid; i < b.npiv; i += 256) x[i] = 0;
-        for (int i = tid; i < b.nwords; i += 256) bm[i] = 0;
+        for (int i = tid; i < b.npiv; i += NT) x[i] = 0;
+        for (int i = tid; i < b.nwords; i += NT) bm[i] = 0;
         __syncthreads();
     }
     const int total = *a.retry_count;
@@ -1730,7 +1732,7 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
         if (tid == 0) s_nN = 0;
         __syncthreads();
         int myN = 0;
-        for (int k = tid; k < ln; k += 256) {
+        for (int k = tid; k < ln; k += NT) {
             const int2 e = a.ent[st + k];
             const int q = a.qinv_r[e.x];
             if (q >= 0 && q != self) {
@@ -1744,7 +1746,7 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
         i64d bound = 0;
         u64d r_app = 0, r_red = (u64d)ln;
         while (wbase < b.nwords) {
-            // first non-zero word in [wbase, wbase + 256): lowest lane per wave, lowest wave through LDS
+            // first non-zero word in [wbase, wbase + NT): lowest lane per wave, lowest wave through LDS
             const int wi = wbase + tid;
             const unsigned wv = wi < b.nwords ? bm[wi] : 0u;
             if (tid == 0) s_word = INT_MAX;
@@ -1754,7 +1756,7 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
             __syncthreads();
             const int found = s_word;
             __syncthreads(); // s_word is reset by the next iteration
-            if (found == INT_MAX) { wbase += 256; continue; }
+            if (found == INT_MAX) { wbase += NT; continue; }
             const unsigned word = bm[found];
             const int bit = __ffs((int)word) - 1;
             const int idx = found * 32 + bit;
@@ -1773,7 +1775,7 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
                 r_red += (u64d)h.len;
                 bound += h.npn;
                 const int nm = zp_neg(F, mult);
-                for (int k = tid; k < h.npp; k += 256) {
+                for (int k = tid; k < h.npp; k += NT) {
                     const int2 e = a.UPP[(i64d)h.off + k];
                     x[e.x] = zp_axpy(F, nm, e.y, x[e.x]); // targets of one pivot row are distinct
                     atomicOr(&bm[e.x >> 5], 1u << (e.x & 31));
@@ -1789,7 +1791,7 @@ __global__ __launch_bounds__(256) void k_solve_big(BigSolveArgs b)
         if (base == ~0ull) {
             if (tid == 0) { atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1); a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0; }
         } else {
-            for (int i = tid; i < cnt; i += 256) {
+            for (int i = tid; i < cnt; i += NT) {
                 const int4 r = out[i];
                 if (a.Lpool2) a.Lpool2[base + i] = make_int2(r.x, r.y);
                 else a.Lpool[base + i] = r;
