@@ -1022,17 +1022,14 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
             const int c1 = std::min(c0 + DPB, C);
             Lm.zero(s);
             Upan.zero(s);
-            hipLaunchKernelGGL(k_panel_begin, dim3(1), dim3(1), 0, s, st.p);
             for (int c = c0; c < c1; c++) {
-                hipLaunchKernelGGL(k_dense_find, dim3(1), dim3(1024), 0, s, c, R, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, st.p);
-                hipLaunchKernelGGL(k_panel_scale, dim3(cdiv(rc, 256)), dim3(256), 0, s, c, c1, R, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, Lm.p,
+                hipLaunchKernelGGL(k_panel_find, dim3(1), dim3(1024), 0, s, c, c0, c1, R, F, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, prow.p,
                                    pan_row.p, pan_inv.p, st.p);
-                hipLaunchKernelGGL(k_panel_store_prow, dim3(cdiv(C, 256)), dim3(256), 0, s, c, c1, D.p, (i64d)ldc, prow.p, st.p);
-                hipLaunchKernelGGL(k_panel_elim, dim3(R), dim3(64), 0, s, c, c1, F, D.p, (i64d)ldc, prow.p, fcol.p, st.p);
+                hipLaunchKernelGGL(k_panel_elim2, dim3(R), dim3(64), 0, s, c, c1, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, Lm.p, st.p);
             }
             HIPCHK(hipGetLastError());
             if (c1 < C) {
-                hipLaunchKernelGGL(k_panel_trsm, dim3(cdiv(C - c1, 256)), dim3(256), 0, s, c1, C, F, D.p, (i64d)ldc, Lm.p, pan_row.p, pan_inv.p, Upan.p,
+                hipLaunchKernelGGL(k_panel_trsm2, dim3(cdiv(C - c1, 64)), dim3(64), 0, s, c1, C, F, D.p, (i64d)ldc, Lm.p, pan_row.p, pan_inv.p, Upan.p,
                                    (i64d)ldu, st.p);
                 hipLaunchKernelGGL(k_dense_gemm, dim3(cdiv(C - c1, 64), (unsigned)(R64 / 64)), dim3(256), 0, s, c1, R, C, F, D.p, (i64d)ldc, Lm.p,
                                    Upan.p, (i64d)ldu, is_piv.p, st.p);

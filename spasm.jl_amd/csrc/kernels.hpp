@@ -2123,6 +2123,105 @@ __global__ void k_panel_store_prow(int c, int c1, int *__restrict__ D, i64d ldc,
     if (i >= c && i < c1) D[(i64d)p * ldc + i] = prow[i];
 }
 
+// Two launches per column of a panel (were five: a launch costs ~4.5 us and a 6091-column tail has 6091 of each).
+// (1) one workgroup: first live row with a non-zero in column c (leftmost-pivot rule, row order; the scan stops at the
+//     first hit), then the panel part of that row scaled to a unit pivot -- 64 entries, the only part of the old
+//     "scale" pass that does not need the whole column;
+// (2) one workgroup per row: its multiplier (recorded in fcol / Lm for the TRSM + GEMM) and the elimination of the panel
+//     part of the row.  Pivot rows are skipped, so nobody reads the row that (1) rewrote except through prow.
+__global__ __launch_bounds__(1024) void k_panel_find(int c, int c0, int c1, int R, ZpField F, int *__restrict__ D, i64d ldc, int *__restrict__ is_piv,
+                                                     int *__restrict__ pivrow_of_col, int *__restrict__ prow, int *__restrict__ pan_row,
+                                                     int *__restrict__ pan_inv, DenseState *__restrict__ st)
+{
+    __shared__ int s_best;
+    if (threadIdx.x == 0) s_best = INT_MAX;
+    __syncthreads();
+    int best = INT_MAX;
+    for (int i = threadIdx.x; i < R && i < best; i += 1024)
+        if (!is_piv[i] && D[(i64d)i * ldc + c] != 0) { best = i; break; }
+    best = wave_min_i32(best);
+    if ((threadIdx.x & 63) == 0 && best != INT_MAX) atomicMin(&s_best, best);
+    __syncthreads();
+    const int p = s_best;
+    const int npp = (c == c0 ? 0 : st->npp) + (p != INT_MAX ? 1 : 0); // the panel's pivot count restarts with its first column
+    int inv = 0, scaled = 0;
+    const int j = c + (int)threadIdx.x;
+    if (p != INT_MAX) {
+        inv = zp_inverse(F, D[(i64d)p * ldc + c]);
+        if (j < c1) scaled = zp_mul(F, inv, D[(i64d)p * ldc + j]);
+    }
+    __syncthreads(); // every thread has read st->npp and the unscaled pivot entry
+    if (p != INT_MAX && j < c1) { prow[j] = scaled; D[(i64d)p * ldc + j] = scaled; }
+    if (threadIdx.x == 0) {
+        st->npp = npp;
+        if (p != INT_MAX) {
+            st->cur = p;
+            st->npiv += 1;
+            is_piv[p] = 1;
+            pivrow_of_col[c] = p;
+            pan_row[npp - 1] = p;
+            pan_inv[npp - 1] = inv;
+        } else {
+            st->cur = -1;
+            pivrow_of_col[c] = -1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_panel_elim2(int c, int c1, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ is_piv,
+                                                   const int *__restrict__ prow, int *__restrict__ fcol, double *__restrict__ Lm,
+                                                   const DenseState *__restrict__ st)
+{
+    if (st->cur < 0) return;
+    const int i = blockIdx.x;
+    const int f = is_piv[i] ? 0 : D[(i64d)i * ldc + c]; // read by every lane before lane 0 overwrites it below (same wave, in order)
+    if (threadIdx.x == 0) {
+        fcol[i] = f;
+        Lm[(size_t)i * DPB + (st->npp - 1)] = (double)f;
+    }
+    if (f == 0) return;
+    const int nf = zp_neg(F, f);
+    const int j = c + threadIdx.x;
+    if (j < c1) {
+        int *d = D + (i64d)i * ldc + j;
+        *d = zp_axpy(F, nf, prow[j], *d);
+    }
+}
+
+// TRSM of a panel: Upan[t][j] = inv_t * (D[p_t][j] - sum_{s<t} Lm[p_t][s] * Upan[s][j]) for the columns j right of the panel.
+// One thread per column; the panel's 64 x 64 multipliers sit in LDS, the column's 64 results stay in registers, the sums are
+// exact in f64 (64 (p/2)^2 < 2^53 for p <= 2^24).  The former version re-read Upan from global memory 2016 times per thread.
+__global__ __launch_bounds__(64) void k_panel_trsm2(int c1, int C, ZpField F, int *__restrict__ D, i64d ldc, const double *__restrict__ Lm,
+                                                   const int *__restrict__ pan_row, const int *__restrict__ pan_inv, double *__restrict__ Upan, i64d ldu,
+                                                   const DenseState *__restrict__ st)
+{
+    __shared__ double s_l[DPB * DPB];
+    __shared__ int s_row[DPB], s_inv[DPB];
+    const int npp = st->npp;
+    for (int e = threadIdx.x; e < npp * DPB; e += 64) {
+        const int t = e / DPB, s = e % DPB;
+        s_l[e] = Lm[(size_t)pan_row[t] * DPB + s];
+    }
+    if ((int)threadIdx.x < npp) { s_row[threadIdx.x] = pan_row[threadIdx.x]; s_inv[threadIdx.x] = pan_inv[threadIdx.x]; }
+    __syncthreads();
+    const int j = c1 + blockIdx.x * 64 + threadIdx.x;
+    if (j >= C) return;
+    double u[DPB];
+#pragma unroll
+    for (int t = 0; t < DPB; t++) {
+        u[t] = 0.0;
+        if (t < npp) { // uniform
+            double acc = (double)D[(i64d)s_row[t] * ldc + j];
+#pragma unroll
+            for (int s = 0; s < t; s++) acc = fma(-s_l[t * DPB + s], u[s], acc);
+            const int v = zp_mul(F, s_inv[t], zp_reduce(F, (long long)acc));
+            u[t] = (double)v;
+            Upan[(i64d)t * ldu + j] = u[t];
+            D[(i64d)s_row[t] * ldc + j] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_panel_elim(int c, int c1, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ prow,
                                                   const int *__restrict__ fcol, const DenseState *__restrict__ st)
 {
