@@ -296,6 +296,61 @@ def test_schur_round_vs_oracle(S, O, n, k, p, seed):
     assert Sc.rows() == So.rows()
 
 
+def test_config3_full_size_counters_and_sampled_rows(S, O):
+    """BASELINE config 3 at FULL size (1M x 1M, 20 nnz/row, p = 65521), the workload bench.py times.
+    (a) The counters of the whole round equal the oracle's, committed as tests/golden/config3_oracle_counts.json by
+        tests/golden/make_config3_counts.py (the oracle needs ~15 s and 10 GB for the full round, too much for this suite).
+    (b) Three row ranges spread over the matrix are reduced as shards on the GPU and by the oracle here, with the pivots
+        of the whole matrix: their Schur rows must agree entry for entry.
+    (c) Size-independent properties of the full result: rows keep their order, no entry sits on a pivot column, the
+        leftmost column recorded for a row is its smallest column."""
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_oracle_counts.json")))
+    n = 1_000_000
+    A = S.synth_csr(1, n, n, row_nnz=20, prime=65521, seed=0x5A5A0003)
+    # (b) sampled shards first (small results)
+    got_rows = 0
+    for lo, hi in ((0, 20000), (500000, 501500), (998500, 1000000)):
+        Sc, st, p_out = run_plan(S, A, lo, hi)
+        So, info = O.schur_round(A, row_lo=lo, row_hi=hi)
+        assert st["npiv"] == info["npiv"] == gold["npiv"]
+        assert st["nnz_reduced"] == info["nnz_reduced"] and st["applications"] == info["applications"]
+        assert st["nnz_out"] == info["nnz_out"]
+        assert Sc.n == So.n and Sc.rows() == So.rows()
+        assert np.all((p_out >= lo) & (p_out < hi)) and np.all(np.diff(p_out) > 0)
+        got_rows += Sc.n
+    assert got_rows > 3000, got_rows
+    # (a) + (c) the whole round
+    lib = S._abi.lib()
+    plan = lib.spasm_amd_schur_plan_create(A.data, 0, n)
+    assert plan, S._abi.last_error()
+    try:
+        assert lib.spasm_amd_schur_plan_run(plan, None) == 0, S._abi.last_error()
+        st = S._abi.RoundStats()
+        assert lib.spasm_amd_schur_plan_stats(plan, C.byref(st)) == 0, S._abi.last_error()
+        d = st.as_dict()
+        for key in ("npiv", "applications", "nnz_reduced", "nnz_out", "rows_out"):
+            assert d[key] == gold[key], (key, d[key], gold[key])
+        p_out = np.empty(n, dtype=np.int32)
+        ptr = lib.spasm_amd_schur_plan_fetch(plan, p_out.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert ptr, S._abi.last_error()
+        Sc = S.CSR(ptr)
+    finally:
+        lib.spasm_amd_schur_plan_free(plan)
+    assert Sc.n == n - gold["npiv"] and S.nnz(Sc) == gold["nnz_out"]
+    assert np.all(np.diff(p_out[: Sc.n]) > 0)
+    # pivot columns of the round = leftmost columns elected: recompute them on the host from A (min (len, row) per leftmost column)
+    Ap, Aj = A.p, A.j[: S.nnz(A)]
+    assert np.all(np.diff(Ap) > 0)                     # no empty row in this generator
+    lead = np.minimum.reduceat(Aj, Ap[:-1])
+    is_pivot_col = np.zeros(n, dtype=bool)
+    is_pivot_col[lead] = True
+    assert int(is_pivot_col.sum()) == gold["npiv"]
+    assert not is_pivot_col[Sc.j[: S.nnz(Sc)]].any()    # no Schur entry on a pivot column
+    sp = Sc.p
+    nonempty = np.flatnonzero(np.diff(sp) > 0)
+    assert len(nonempty) == gold["rows_out"]
+
+
 @pytest.mark.parametrize("N,nprobe", [(6000, 40), (40000, 6)], ids=["lds_dense_class", "global_memory_class"])
 def test_schur_round_deep_chains(S, O, N, nprobe):
     """Pivot rows that chain through thousands of other pivots: the reach of a row exceeds the sorted-list class of
