@@ -939,16 +939,32 @@ struct HostU {
     std::vector<int> orig;   // originating row of the input
 };
 
+// entries of pivot rows (device, {col,val} pairs) appended to the host arrays of U: split on the device, downloaded straight
+// into the tails of U.j / U.x (was: a host copy of the pairs and 2 x nnz push_backs -- a third of config 2's echelonize)
+void append_entries(HostU &U, const int2 *dent, i64 count, hipStream_t s)
+{
+    if (count <= 0) return;
+    DevBuf<int> dj, dx;
+    dj.alloc((size_t)count);
+    dx.alloc((size_t)count);
+    hipLaunchKernelGGL(k_split_ent, dim3((unsigned)std::min<i64>((count + 255) / 256, 65536)), dim3(256), 0, s, (i64d)count, dent, dj.p, dx.p);
+    HIPCHK(hipGetLastError());
+    const size_t old = U.j.size();
+    U.j.resize(old + (size_t)count);
+    U.x.resize(old + (size_t)count);
+    HIPCHK(hipMemcpyAsync(U.j.data() + old, dj.p, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(U.x.data() + old, dx.p, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+}
+
 // append the pivot rows of a round (device) to the host copy of U
 void append_round_U(HostU &U, const Round &R, const DevMat &A, hipStream_t s)
 {
     const int np = R.npiv;
     if (np == 0) return;
-    std::vector<int2> ent((size_t)R.utotal);
     std::vector<i64d> off((size_t)np + 1);
     std::vector<int> pc((size_t)np), pr((size_t)np);
     std::vector<int> orig((size_t)A.n);
-    HIPCHK(hipMemcpyAsync(ent.data(), R.Ufull.p, (size_t)R.utotal * sizeof(int2), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(off.data(), R.uoff.p, ((size_t)np + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(pc.data(), R.pivcol.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(pr.data(), R.pivrow.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -960,9 +976,7 @@ void append_round_U(HostU &U, const Round &R, const DevMat &A, hipStream_t s)
         U.pivcol.push_back(pc[(size_t)k]);
         U.orig.push_back(orig[(size_t)pr[(size_t)k]]);
     }
-    U.j.reserve(U.j.size() + ent.size());
-    U.x.reserve(U.x.size() + ent.size());
-    for (const int2 &e : ent) { U.j.push_back(e.x); U.x.push_back(e.y); }
+    append_entries(U, R.Ufull.p, R.utotal, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1072,10 +1086,8 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
     hipLaunchKernelGGL(k_dense_emit, dim3(C), dim3(64), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, uoff.p, clist.p, rows.p, M.orig.p,
                        Ufull.p, pivcol.p, porig.p);
     HIPCHK(hipGetLastError());
-    std::vector<int2> ent((size_t)tot);
     std::vector<i64d> off((size_t)npd + 1);
     std::vector<int> pc((size_t)npd), po((size_t)npd);
-    if (tot > 0) HIPCHK(hipMemcpyAsync(ent.data(), Ufull.p, (size_t)tot * sizeof(int2), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(off.data(), uoff.p, ((size_t)npd + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(pc.data(), pivcol.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(po.data(), porig.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1086,9 +1098,7 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
         U.pivcol.push_back(pc[(size_t)k]);
         U.orig.push_back(po[(size_t)k]);
     }
-    U.j.reserve(U.j.size() + ent.size());
-    U.x.reserve(U.x.size() + ent.size());
-    for (const int2 &x : ent) { U.j.push_back(x.x); U.x.push_back(x.y); }
+    append_entries(U, Ufull.p, (i64)tot, s);
     spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots\n", R, C, npd);
     return npd;
 }

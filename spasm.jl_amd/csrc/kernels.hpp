@@ -1351,6 +1351,18 @@ __global__ void k_append_rows(int n, const i64d *__restrict__ start, const int *
     }
 }
 
+// {col, val} pairs -> separate column / value arrays (what the host CSR holds), so that the download lands in place
+__global__ void k_split_ent(i64d n, const int2 *__restrict__ ent, int *__restrict__ oj, int *__restrict__ ox)
+{
+    i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64d stride = (i64d)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int2 e = ent[i];
+        oj[i] = e.x;
+        ox[i] = e.y;
+    }
+}
+
 template <int TEAM>
 __global__ void k_compact_rows(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent,
                                const i64d *__restrict__ ostart, int *__restrict__ oj, int *__restrict__ ox)
