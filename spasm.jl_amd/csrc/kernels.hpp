@@ -2107,33 +2107,8 @@ __global__ void k_hdr_len64(int n, const int2 *__restrict__ hdr, i64d *__restric
 #define DPB 64
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ void k_panel_begin(DenseState *st) { st->npp = 0; }
 
-__global__ void k_panel_scale(int c, int c1, int R, ZpField F, const int *__restrict__ D, i64d ldc, const int *__restrict__ is_piv,
-                              int *__restrict__ prow, int *__restrict__ fcol, double *__restrict__ Lm, int *__restrict__ pan_row,
-                              int *__restrict__ pan_inv, const DenseState *__restrict__ st)
-{
-    const int p = st->cur;
-    if (p < 0) return;
-    const int t = st->npp - 1;
-    const int inv = zp_inverse(F, D[(i64d)p * ldc + c]);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c && i < c1) prow[i] = zp_mul(F, inv, D[(i64d)p * ldc + i]);
-    if (i < R) {
-        const int f = is_piv[i] ? 0 : D[(i64d)i * ldc + c];
-        fcol[i] = f;
-        Lm[(size_t)i * DPB + t] = (double)f;
-    }
-    if (i == 0) { pan_row[t] = p; pan_inv[t] = inv; }
-}
 
-__global__ void k_panel_store_prow(int c, int c1, int *__restrict__ D, i64d ldc, const int *__restrict__ prow, const DenseState *__restrict__ st)
-{
-    const int p = st->cur;
-    if (p < 0) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c && i < c1) D[(i64d)p * ldc + i] = prow[i];
-}
 
 // Two launches per column of a panel (were five: a launch costs ~4.5 us and a 6091-column tail has 6091 of each).
 // (1) one workgroup: first live row with a non-zero in column c (leftmost-pivot rule, row order; the scan stops at the
@@ -2234,38 +2209,8 @@ __global__ __launch_bounds__(64) void k_panel_trsm2(int c1, int C, ZpField F, in
     }
 }
 
-__global__ __launch_bounds__(64) void k_panel_elim(int c, int c1, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ prow,
-                                                  const int *__restrict__ fcol, const DenseState *__restrict__ st)
-{
-    if (st->cur < 0) return;
-    const int i = blockIdx.x;
-    const int f = fcol[i];
-    if (f == 0) return;
-    const int nf = zp_neg(F, f);
-    const int j = c + threadIdx.x;
-    if (j < c1) {
-        int *d = D + (i64d)i * ldc + j;
-        *d = zp_axpy(F, nf, prow[j], *d);
-    }
-}
 
 // one thread per column to the right of the panel; Upan[t][j] (f64) and D[p_t][j] receive the normalised pivot rows
-__global__ void k_panel_trsm(int c1, int C, ZpField F, int *__restrict__ D, i64d ldc, const double *__restrict__ Lm, const int *__restrict__ pan_row,
-                             const int *__restrict__ pan_inv, double *__restrict__ Upan, i64d ldu, const DenseState *__restrict__ st)
-{
-    const int npp = st->npp;
-    const int j = c1 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= C) return;
-    for (int t = 0; t < npp; t++) {
-        const int p = pan_row[t];
-        long long acc = D[(i64d)p * ldc + j];
-        const double *lrow = Lm + (size_t)p * DPB;
-        for (int s = 0; s < t; s++) acc -= (long long)lrow[s] * (long long)Upan[(i64d)s * ldu + j]; // |.| <= 64 p^2/4 < 2^53
-        const int u = zp_mul(F, pan_inv[t], zp_reduce(F, acc));
-        Upan[(i64d)t * ldu + j] = (double)u;
-        D[(i64d)p * ldc + j] = u;
-    }
-}
 
 // D[i][j] -= sum_t Lm[i][t] * Upan[t][j] for the non-pivotal rows; workgroup tile 64 x 64, each wave 16 rows x 64 columns,
 // v_mfma_f64_16x16x4_f64: A[l&15][k = l>>4], B[k = l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg
