@@ -982,7 +982,14 @@ void append_round_U(HostU &U, const Round &R, const DevMat &A, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 // dense tail: leftmost-pivot elimination of the live part of `M`; its pivot rows are appended to U
 // ------------------------------------------------------------------------------------------------
-const i64 kDenseMaxEntries = (i64)1 << 31; // 8 GiB of i32 (288 GB of HBM per device)
+// cells (i32) the dense tail may hold: a third of the free device memory (beside it: 8-byte factors of 64 columns per row,
+// the U rows it emits), at least 2^31 cells
+i64 dense_max_entries()
+{
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (i64)1 << 31;
+    return std::max<i64>((i64)1 << 31, (i64)(fr / 3) / 4);
+}
 
 int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
 {
@@ -1045,7 +1052,7 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
             if (c1 < C) {
                 hipLaunchKernelGGL(k_panel_trsm2, dim3(cdiv(C - c1, 64)), dim3(64), 0, s, c1, C, F, D.p, (i64d)ldc, Lm.p, pan_row.p, pan_inv.p, Upan.p,
                                    (i64d)ldu, st.p);
-                hipLaunchKernelGGL(k_dense_gemm, dim3(cdiv(C - c1, 64), (unsigned)(R64 / 64)), dim3(256), 0, s, c1, R, C, F, D.p, (i64d)ldc, Lm.p,
+                hipLaunchKernelGGL(k_dense_gemm, dim3((unsigned)(R64 / 64), cdiv(C - c1, 64)), dim3(256), 0, s, c1, R, C, F, D.p, (i64d)ldc, Lm.p,
                                    Upan.p, (i64d)ldu, is_piv.p, st.p);
                 HIPCHK(hipGetLastError());
             }
@@ -1133,7 +1140,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         {
             const i64 cfree = (i64)m - (i64)U.pivcol.size();
             const double cells = (double)cur_live * (double)cfree;
-            if (opts->enable_dense && cur_nnz > 0 && cells > 0 && cells <= (double)kDenseMaxEntries &&
+            if (opts->enable_dense && cur_nnz > 0 && cells > 0 && cells <= (double)dense_max_entries() &&
                 (double)cur_nnz > opts->sparsity_threshold * cells) {
                 spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                            cfree > 0 ? (double)cur_live / (double)cfree : 0.0);

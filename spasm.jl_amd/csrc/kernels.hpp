@@ -2220,8 +2220,8 @@ __global__ __launch_bounds__(256) void k_dense_gemm(int c1, int R, int C, ZpFiel
 {
     if (st->npp == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * 64 + wave * 16;
-    const int cb = c1 + blockIdx.x * 64;
+    const int r0 = blockIdx.x * 64 + wave * 16; // rows on x: gridDim.y stops at 65535, a tail can have millions of rows
+    const int cb = c1 + blockIdx.y * 64;
     v4f64 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = (v4f64){0.0, 0.0, 0.0, 0.0};
