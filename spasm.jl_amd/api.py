@@ -264,6 +264,38 @@ class LU:
             raise SpasmError("spasm_echelonize failed: " + _abi.last_error())
         self.data = ptr
 
+    @classmethod
+    def from_parts(cls, U, qinv, p):
+        """An LU from its parts (layout reference src/SpaSM.jl:262-270), e.g. assembled from the rounds of the row-sharded
+        echelonize.  U: CSR whose ownership passes to the LU; qinv: m entries (row of U or -1); p: max(n, m) entries.
+        Everything is malloc'ed so that spasm_lu_free releases it like an LU of spasm_echelonize."""
+        libc = C.CDLL(None)
+        libc.malloc.restype = C.c_void_p
+        libc.malloc.argtypes = [C.c_size_t]
+        qinv = np.ascontiguousarray(qinv, dtype=np.int32)
+        p = np.ascontiguousarray(p, dtype=np.int32)
+
+        def dup(a):
+            mem = libc.malloc(max(a.nbytes, 4))
+            if not mem:
+                raise MemoryError("malloc")
+            C.memmove(mem, a.ctypes.data, a.nbytes)
+            return C.cast(mem, C.POINTER(C.c_int32))
+
+        mem = libc.malloc(C.sizeof(_abi.LuStruct))
+        if not mem:
+            raise MemoryError("malloc")
+        st = C.cast(mem, C.POINTER(_abi.LuStruct))
+        st.contents.r = int(U.n)
+        st.contents.complete = False
+        st.contents.L = None
+        st.contents.U = U.data
+        st.contents.qinv = dup(qinv)
+        st.contents.p = dup(p)
+        st.contents.Ltmp = None
+        U._own = False  # now owned by the LU
+        return cls(st)
+
     def __del__(self):  # finalizer(lu_free, x), reference src/SpaSM.jl:273-277
         if getattr(self, "data", None):
             try:

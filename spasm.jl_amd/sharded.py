@@ -140,3 +140,176 @@ def exchange_pivot_rows(engine, group=None):
     engine.import_(hdr_all, ent_all)
     return npiv, {"owned_rows": n_own, "owned_nnz": nnz_own, "gathered_rows": int(hdr_all.shape[0]),
                   "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4)}
+
+
+# ------------------------------------------------------------------------------------------------
+# The whole echelonization, row-sharded: rounds of (election, pivot-row exchange, local Schur complement) until what is
+# left is small, then every rank finishes the same remainder.
+# ------------------------------------------------------------------------------------------------
+class GpuRoundEngine(GpuShardEngine):
+    """One round of one rank: the exchange protocol of GpuShardEngine plus schur(), which runs the round on the shard and
+    returns its Schur rows as host arrays (ids = rows of the ORIGINAL matrix, ascending)."""
+
+    def schur(self):
+        import numpy as np
+
+        from .api import CSR
+
+        lib = self.lib
+        if lib.spasm_amd_schur_plan_run(self.plan, None) != 0:
+            raise RuntimeError("spasm_amd_schur_plan_run failed: " + _abi.last_error())
+        ids = np.empty(max(self.A.n, 1), dtype=np.int32)
+        ptr = lib.spasm_amd_schur_plan_fetch(self.plan, ids.ctypes.data_as(C.POINTER(C.c_int32)))
+        if not ptr:
+            raise RuntimeError("spasm_amd_schur_plan_fetch failed: " + _abi.last_error())
+        Sc = CSR(ptr)
+        nnz = int(Sc.p[Sc.n])
+        return ids[: Sc.n].copy(), np.array(Sc.p[: Sc.n + 1], dtype=np.int64), np.array(Sc.j[:nnz]), np.array(Sc.x[:nnz])
+
+
+def _virtual_csr(n, m, prime, ids, p, j, x):
+    """An n-row matrix whose rows `ids` (ascending) hold the given rows and whose other rows are empty: a shard's view of
+    the current matrix under the ORIGINAL row numbering, which is what keeps election keys comparable across ranks."""
+    import numpy as np
+
+    from .api import CSR
+
+    lens = np.zeros(n + 1, dtype=np.int64)
+    lens[np.asarray(ids, dtype=np.int64) + 1] = np.diff(p)
+    return CSR.from_arrays(n, m, np.cumsum(lens), j, x, prime)
+
+
+def _ranges(starts, lens):
+    """concatenation of arange(starts[k], starts[k] + lens[k]) without a python loop"""
+    import numpy as np
+
+    starts = np.asarray(starts, dtype=np.int64)
+    lens = np.asarray(lens, dtype=np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)])[:-1]
+    return np.repeat(starts - offs, lens) + np.arange(total, dtype=np.int64)
+
+
+def _balanced(v, prime):
+    """the canonical representative in [p/2 - p + 1, p/2] (reference src/SpaSM.jl:83-88)"""
+    v = v % prime
+    return v - prime if v > prime // 2 else v
+
+
+def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, engine_cls=None, finish=None):
+    """Row-sharded echelonize of A (every rank passes the same matrix; rank r keeps rows r, r + G, ...).
+    Per round: all-reduce(MIN) of the election keys, all-gather of the elected pivot rows, local Schur complement of the
+    rank's rows.  When at most `finish_nnz` entries are left in total, or the remainder is dense enough for the dense tail
+    (the single-device rule), or after `max_rounds` rounds, the remaining rows are all-gathered and every rank finishes
+    them with the single-device engine, so all ranks return the same LU.
+    Returns (LU, info)."""
+    import numpy as np
+
+    from . import api
+
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    engine_cls = engine_cls or GpuRoundEngine
+    finish = finish or (lambda M: api.echelonize(M))
+    sparsity_threshold = float(api.EchelonizeOpts().struct.sparsity_threshold)
+    n, m, prime = A.n, A.m, int(A.prime)
+    Ap, Aj, Ax = np.asarray(A.p), np.asarray(A.j), np.asarray(A.x)
+    ids = np.arange(rank, n, world, dtype=np.int64)
+    lens = (Ap[ids + 1] - Ap[ids]).astype(np.int64)
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    take = _ranges(Ap[ids].astype(np.int64), lens)
+    j, x = Aj[take].astype(np.int32), Ax[take].astype(np.int32)
+
+    u_cols, u_vals, u_len, u_pivcol, u_orig = [], [], [], [], []
+    rounds = []
+    while True:
+        tot = all_gather_counts([len(ids), int(p[-1])], group).sum(dim=0)
+        rows_left, nnz_left = int(tot[0]), int(tot[1])
+        if nnz_left == 0:
+            break
+        free_cols = m - len(u_len)
+        dense_enough = nnz_left > sparsity_threshold * rows_left * max(free_cols, 1)  # the single-device rule for its dense tail
+        if nnz_left <= finish_nnz or len(rounds) >= max_rounds or dense_enough:
+            # hand-off: every rank gets all remaining rows and finishes them (deterministic, so the results agree)
+            counts = all_gather_counts([len(ids), int(p[-1])], group)
+            dev = "cuda" if dist.is_initialized() and dist.get_backend(group) != "gloo" else "cpu"
+            g_ids = all_gather_var(torch.as_tensor(ids, dtype=torch.int64, device=dev), counts[:, 0].tolist(), group).cpu().numpy()
+            g_len = all_gather_var(torch.as_tensor(np.diff(p), dtype=torch.int64, device=dev), counts[:, 0].tolist(), group).cpu().numpy()
+            g_ent = all_gather_var(torch.as_tensor(np.stack([j, x], axis=1).reshape(-1, 2), dtype=torch.int32, device=dev),
+                                   counts[:, 1].tolist(), group).cpu().numpy()
+            order = np.argsort(g_ids, kind="stable")
+            starts = np.concatenate([[0], np.cumsum(g_len)])
+            sel = _ranges(starts[:-1][order], g_len[order])
+            rest = _virtual_csr(n, m, prime, g_ids[order], np.concatenate([[0], np.cumsum(g_len[order])]), g_ent[sel, 0], g_ent[sel, 1])
+            fact = finish(rest)
+            Uc, fp, fq = fact.U, np.asarray(fact.p), np.asarray(fact.qinv)
+            up, uj, ux = np.asarray(Uc.p), np.asarray(Uc.j), np.asarray(Uc.x)
+            col_of_row = np.full(fact.r, -1, dtype=np.int64)
+            col_of_row[fq[fq >= 0]] = np.flatnonzero(fq >= 0)
+            for k in range(fact.r):
+                u_cols.append(np.array(uj[up[k]:up[k + 1]]))
+                u_vals.append(np.array(ux[up[k]:up[k + 1]]))
+                u_len.append(int(up[k + 1] - up[k]))
+                u_pivcol.append(int(col_of_row[k]))
+                u_orig.append(int(fp[k]))
+            rounds.append({"round": len(rounds), "finish": True, "rows": rows_left, "nnz": nnz_left, "npiv": int(fact.r)})
+            break
+        Av = _virtual_csr(n, m, prime, ids, p, j, x)
+        eng = engine_cls(Av, rank, n, stride=world)
+        try:
+            keys = all_reduce_min(eng.elect(), group)
+            npiv, n_own, nnz_own = eng.set_keys(keys)
+            if npiv == 0:
+                break
+            counts = all_gather_counts([n_own, nnz_own], group)
+            hdr, ent = eng.export()
+            hdr_all = all_gather_var(hdr, counts[:, 0].tolist(), group)
+            ent_all = all_gather_var(ent, counts[:, 1].tolist(), group)
+            eng.import_(hdr_all, ent_all)
+            # the round's rows of U, as every rank's engine builds them: the elected rows scaled to a unit pivot
+            keys_h = keys.cpu().numpy()
+            h = hdr_all.cpu().numpy().astype(np.int64)
+            e = ent_all.cpu().numpy()
+            order = np.argsort(h[:, 0], kind="stable")           # ascending pivot index = ascending pivot column
+            starts = np.concatenate([[0], np.cumsum(h[:, 1])])
+            sel = _ranges(starts[:-1][order], h[order, 1])
+            cols_all, vals_all = e[sel, 0].astype(np.int64), e[sel, 1].astype(np.int64)
+            rs = np.concatenate([[0], np.cumsum(h[order, 1])]).astype(np.int64)
+            if len(order):
+                lead_pos = np.array([rs[t] + int(np.argmin(cols_all[rs[t]:rs[t + 1]])) for t in range(len(order))], dtype=np.int64)
+                invs = np.array([pow(int(v) % prime, -1, prime) for v in vals_all[lead_pos]], dtype=object)
+                prod = (vals_all.astype(object) % prime) * np.repeat(invs, h[order, 1]) % prime  # exact (python integers)
+                sv_all = np.where(prod > prime // 2, prod - prime, prod).astype(np.int64)
+                for t in range(len(order)):
+                    u_cols.append(cols_all[rs[t]:rs[t + 1]])
+                    u_vals.append(sv_all[rs[t]:rs[t + 1]])
+                    u_len.append(int(rs[t + 1] - rs[t]))
+                    pc = int(cols_all[lead_pos[t]])
+                    u_pivcol.append(pc)
+                    u_orig.append(int(keys_h[pc] & 0xffffffff))
+            ids, p, j, x = eng.schur()
+            ids = ids.astype(np.int64)
+            rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv),
+                           "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4)})
+        finally:
+            eng.close()
+
+    r = len(u_len)
+    up = np.concatenate([[0], np.cumsum(np.asarray(u_len, dtype=np.int64))]).astype(np.int64)
+    uj = np.concatenate(u_cols).astype(np.int32) if r and up[-1] else np.zeros(0, dtype=np.int32)
+    ux = np.concatenate(u_vals).astype(np.int32) if r and up[-1] else np.zeros(0, dtype=np.int32)
+    U = api.CSR.from_arrays(r, m, up, uj, ux, prime)
+    qinv = np.full(max(m, 1), -1, dtype=np.int32)
+    if r:
+        qinv[np.asarray(u_pivcol, dtype=np.int64)] = np.arange(r, dtype=np.int32)
+    plen = max(n, m, 1)
+    perm = np.full(plen, -1, dtype=np.int32)
+    used = np.zeros(max(n, 1), dtype=bool)
+    if r:
+        perm[:r] = np.asarray(u_orig, dtype=np.int32)
+        used[np.asarray(u_orig, dtype=np.int64)] = True
+    others = np.flatnonzero(~used[:n])
+    perm[r:r + len(others)] = others
+    return api.LU.from_parts(U, qinv[:m] if m else qinv, perm), {"rounds": rounds, "world": world}

@@ -103,6 +103,11 @@ class OLU:
         m = int(self.data.contents.U.contents.m)
         return np.ctypeslib.as_array(self.data.contents.qinv, (max(m, 1),))[:m]
 
+    @property
+    def p(self):  # pivotal rows first; `n` (rows of the input) is set by echelonize()
+        m = int(self.data.contents.U.contents.m)
+        return np.ctypeslib.as_array(self.data.contents.p, (max(getattr(self, "n", 0), m, 1),))
+
 
 def echelonize(A, **kwargs):
     """Oracle echelonize of a product-side CSR (borrowed)."""
@@ -113,6 +118,7 @@ def echelonize(A, **kwargs):
     stats = (C.c_int64 * 2)()
     lu = OLU(lib().orc_echelonize(A.data, C.byref(opts), stats))
     lu.stats = (int(stats[0]), int(stats[1]))
+    lu.n = int(A.n)
     return lu
 
 

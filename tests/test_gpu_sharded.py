@@ -80,3 +80,71 @@ def test_sharded_round_with_exchange(S, O, world, n, k, p, strided):
     if not strided:
         origs = [g for r in results for g in r[5]]
         assert origs == sorted(origs)  # contiguous shards keep the row order
+
+
+def _echelonize_worker(rank, world, port, kind, n, m, kw, p, seed, finish_nnz, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import torch
+    import torch.distributed as dist
+
+    import spasm_jl_amd as S
+    from spasm_jl_amd import sharded
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        A = S.synth_csr(kind, n, m, prime=p, seed=seed, **kw)
+        fact, info = sharded.echelonize_sharded(A, finish_nnz=finish_nnz)
+        K = S.kernel(fact)
+        q.put((rank, fact.r, np.asarray(fact.qinv).tolist(), np.asarray(fact.p).tolist(), fact.U.rows(), K.rows(),
+               [(r["finish"], r["npiv"]) for r in info["rounds"]]))
+    except Exception as exc:
+        import traceback
+
+        q.put((rank, -1, repr(exc) + traceback.format_exc(), [], [], [], []))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind,n,m,kw,p,finish_nnz", [(2, 1, 3000, 3000, dict(row_nnz=6), 65521, 6000),
+                                                           (3, 1, 2000, 2500, dict(row_nnz=5), 2147483647, 8000),
+                                                           (2, 2, 3000, 1200, dict(row_nnz=30), 127, 40000)])
+def test_echelonize_sharded_matches_single_device(S, O, world, kind, n, m, kw, p, finish_nnz):
+    """The whole echelonization with its rows sharded over ranks (rounds of election all-reduce + pivot-row all-gather +
+    local Schur complement, then the replicated finish; the ranks share the test box's one GPU, collectives over gloo)
+    gives the LU of the single-device run: same rank, same pivot columns and rows, same U, same kernel."""
+    seed = 77
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_echelonize_worker, args=(r, world, port, kind, n, m, kw, p, seed, finish_nnz, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] >= 0 for r in results), [r[2] for r in results]
+    assert all(pr.exitcode == 0 for pr in procs)
+    A = S.synth_csr(kind, n, m, prime=p, seed=seed, **kw)
+    ref = S.echelonize(A)
+    refK = S.kernel(ref)
+    assert ref.r == O.echelonize(A).r
+    results.sort()
+    for rank, r, qinv, perm, Urows, Krows, rounds in results:
+        assert r == ref.r
+        assert [c >= 0 for c in qinv] == [c >= 0 for c in np.asarray(ref.qinv).tolist()]
+        assert Krows == refK.rows()                              # the kernel basis is unique
+        assert len(set(perm[:r])) == r and all(0 <= g < n for g in perm[:r])  # U rows come from distinct rows of A
+        assert rounds == results[0][6]
+        assert sum(1 for fin, _ in rounds if not fin) >= 1 and sum(np_ for _, np_ in rounds) == ref.r
+    # the sharded rounds elect what the single device elects: as long as the hand-off happens where the single device is
+    # still in its sparse rounds, the U rows of those rounds are the same rows
+    ref_rounds = S.last_rounds()
+    shard_rounds = [np_ for fin, np_ in results[0][6] if not fin]
+    assert shard_rounds == [rr["npiv"] for rr in ref_rounds[: len(shard_rounds)]]
+    k = sum(shard_rounds)
+    assert results[0][4][:k] == ref.U.rows()[:k]

@@ -122,6 +122,97 @@ def test_exchange_protocol_two_ranks_gloo(S, O):
     assert [row for _, row in got] == So.rows()
 
 
+class NumpyRoundEngine(NumpyShardEngine):
+    """The engine contract of sharded.echelonize_sharded on the CPU: built from the n-row "virtual" matrix of a round
+    (rows rank, rank + stride, ... belong to this rank, the others are empty), python elimination for the Schur rows."""
+
+    def __init__(self, Av, lo, hi, stride=1):
+        rows = Av.rows()
+        self.ids = list(range(lo, hi, stride))
+        NumpyShardEngine.__init__(self, [rows[g] for g in self.ids], Av.m, lo, int(Av.prime))
+        self.stride = stride
+
+    def elect(self):
+        keys = np.full(self.m, INT64_MAX, dtype=np.int64)
+        for i, r in enumerate(self.rows):
+            if r:
+                lead = min(c for c, _ in r)
+                keys[lead] = min(keys[lead], (len(r) << 32) | self.ids[i])
+        return torch.from_numpy(keys)
+
+    def set_keys(self, keys):
+        keys = keys.numpy()
+        self.pivcols = [j for j in range(self.m) if keys[j] != INT64_MAX]
+        self.pivrow = [int(keys[j] & 0xFFFFFFFF) for j in self.pivcols]
+        local = {g: i for i, g in enumerate(self.ids)}
+        self.owned = [(idx, local[g]) for idx, g in enumerate(self.pivrow) if g in local]
+        return len(self.pivcols), len(self.owned), sum(len(self.rows[i]) for _, i in self.owned)
+
+    def schur(self):
+        self.lo, ids = 0, self.ids  # schur_rows() reports lo + local index: translate to global ids below
+        out = self.schur_rows()
+        gid = np.array([ids[i] for i, _ in out], dtype=np.int64)
+        lens = np.array([len(r) for _, r in out], dtype=np.int64)
+        ent = np.array([e for _, r in out for e in r], dtype=np.int64).reshape(-1, 2)
+        return gid, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), ent[:, 0].astype(np.int32), ent[:, 1].astype(np.int32)
+
+    def close(self):
+        pass
+
+
+def _echelonize_worker(rank, world, port, n, m, k, p, seed, finish_nnz, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import oracle_ffi as O
+    import spasm_jl_amd as S
+    from spasm_jl_amd import sharded
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        A = S.synth_csr(1, n, m, row_nnz=k, prime=p, seed=seed)
+        fact, info = sharded.echelonize_sharded(A, engine_cls=NumpyRoundEngine, finish=O.echelonize, finish_nnz=finish_nnz)
+        K = O.kernel(fact)
+        q.put((rank, fact.r, np.asarray(fact.qinv).tolist(), K.rows(), [(r["finish"], r["npiv"]) for r in info["rounds"]]))
+    except Exception as exc:
+        import traceback
+
+        q.put((rank, -1, repr(exc) + traceback.format_exc(), [], []))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,finish_nnz", [(2, 600), (3, 0)])
+def test_echelonize_sharded_rounds_gloo(S, O, world, finish_nnz):
+    """The whole row-sharded echelonization (election all-reduce, pivot-row all-gather, local Schur rows, round after round,
+    then the replicated finish) on CPU ranks over gloo: same rank, pivot columns and kernel as the unsharded oracle."""
+    n, m, k, p, seed = 260, 300, 4, 65521, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_echelonize_worker, args=(r, world, port, n, m, k, p, seed, finish_nnz, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    assert all(r[1] >= 0 for r in results), results
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    A = S.synth_csr(1, n, m, row_nnz=k, prime=p, seed=seed)
+    olu = O.echelonize(A)
+    oK = O.kernel(olu)
+    results.sort()
+    for rank, r, qinv, Krows, rounds in results:
+        assert r == olu.r
+        assert [c >= 0 for c in qinv] == (olu.qinv >= 0).tolist()
+        assert Krows == oK.rows()
+        assert rounds == results[0][4]                       # every rank went through the same rounds
+        assert sum(1 for fin, _ in rounds if not fin) >= 1   # at least one sharded round before the finish
+    assert sum(np_ for _, np_ in results[0][4]) == olu.r
+
+
 def test_collectives_degenerate_to_identity_without_a_group():
     from spasm_jl_amd import sharded
 
