@@ -117,6 +117,14 @@ struct spasm_triplet *spasm_triplet_load(void *file, i64 prime, uint8_t *hash); 
 void spasm_triplet_save(const struct spasm_triplet *T, void *file);  /* FILE*, src/SpaSM.jl:514 */
 void spasm_csr_save(const struct spasm_csr *A, void *file);          /* FILE*, src/SpaSM.jl:523 */
 
+/* ---- spasm_certificate.c: the probabilistic self-check of a factorization (src/SpaSM.jl:934).  Host-side, O(nnz).
+ * Checks (a) the shape of the echelon form: row k of U starts at its pivot column qinv^-1(k) with a 1, so the rows of U are
+ * independent; (b) for random vectors x drawn from `seed`, that x*A reduces to zero modulo the rows of U, i.e. that the row
+ * space of A lies in that of U (a wrong U escapes with probability <= 1/p per trial; 2 trials, 8 for p < 2^16).
+ * Together: rank(A) <= r and U spans at least the rows of A.  libspasm's version also uses L (x*L*U == x*P*A); this
+ * engine's LU has L = NULL, so "the rows of U lie in the row space of A" is NOT checked. ---- */
+bool spasm_factorization_verify(const struct spasm_csr *A, const struct spasm_lu *fact, uint64_t seed);
+
 /* ---- spasm_ZZp.c surface (commented-out binding at src/SpaSM.jl:65; arithmetic restated :73-88,:383-390) ---- */
 void spasm_field_init(i64 p, spasm_field F);
 

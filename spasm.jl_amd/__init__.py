@@ -15,6 +15,7 @@ from .api import (
     ZZp,
     balanced,
     echelonize,
+    factorization_verify,
     kernel,
     last_rounds,
     load,
@@ -28,6 +29,6 @@ from .api import (
 )
 
 __all__ = [
-    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "kernel",
+    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "factorization_verify", "kernel",
     "last_rounds", "nnz", "prime0", "rank", "sparse", "synth_csr", "transpose",
 ]

@@ -364,6 +364,13 @@ def kernel(A, verbose=False, **kwargs):
     return CSR(ptr)
 
 
+def factorization_verify(A, fact, seed=0):
+    """factorization_verify(A, fact, seed) (reference src/SpaSM.jl:934): probabilistic self-check, on the host, that the row
+    space of A lies in the span of fact.U and that U has echelon shape (so rank(A) <= fact.r).  With L = NULL the converse
+    inclusion is not checked (include/spasm_amd.h)."""
+    return bool(_abi.lib().spasm_factorization_verify(A.data, fact.data, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+
 def rank(A, **kwargs):
     """rank(N::LU) = N.r; rank(A::CSR) = rank(echelonize(A)) (reference src/SpaSM.jl:305, :1149)."""
     return A.r if isinstance(A, LU) else echelonize(A, **kwargs).r

@@ -407,6 +407,69 @@ struct Rng {
     double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
 };
 
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// spasm_factorization_verify (reference src/SpaSM.jl:934): see include/spasm_amd.h for what is and is not checked
+// ------------------------------------------------------------------------------------------------
+extern "C" SPASM_API bool spasm_factorization_verify(const struct spasm_csr *A, const struct spasm_lu *fact, uint64_t seed)
+{
+    if (!A || !fact || !fact->U || !fact->qinv) { spasm_set_error("spasm_factorization_verify: null argument"); return false; }
+    const struct spasm_csr *U = fact->U;
+    const int n = A->n, m = A->m, r = U->n;
+    const uint64_t p = (uint64_t)A->field->p;
+    if (U->m != m || fact->r != r || (uint64_t)U->field->p != p) return false;
+    auto res = [p](int v) -> uint64_t { return v < 0 ? (uint64_t)((int64_t)v + (int64_t)p) : (uint64_t)v; };
+    // (a) echelon shape: qinv is a bijection pivot column -> row, every row starts at its pivot column with a 1
+    std::vector<int> pivcol((size_t)std::max(r, 1), -1);
+    for (int j = 0; j < m; j++) {
+        const int k = fact->qinv[j];
+        if (k < -1 || k >= r) return false;
+        if (k >= 0) {
+            if (pivcol[(size_t)k] != -1) return false;
+            pivcol[(size_t)k] = j;
+        }
+    }
+    for (int k = 0; k < r; k++) {
+        if (pivcol[(size_t)k] < 0) return false;
+        bool has_pivot = false;
+        for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
+            if (U->j[q] < pivcol[(size_t)k] || U->j[q] >= m) return false;
+            if (U->j[q] == pivcol[(size_t)k]) { if (res(U->x[q]) != 1 || has_pivot) return false; has_pivot = true; }
+        }
+        if (!has_pivot) return false;
+    }
+    // (b) random combinations of the rows of A must reduce to zero
+    const int trials = p < 65536 ? 8 : 2;
+    std::vector<uint64_t> y((size_t)std::max(m, 1));
+    Rng rng(seed ^ 0x5350415346564552ull);
+    for (int t = 0; t < trials; t++) {
+        std::fill(y.begin(), y.end(), 0);
+        for (int i = 0; i < n; i++) {
+            const uint64_t xi = rng.below(p);
+            if (xi == 0) continue;
+            for (i64 q = A->p[i]; q < A->p[i + 1]; q++) {
+                const int c = A->j[q];
+                if (c < 0 || c >= m) return false;
+                y[(size_t)c] = (y[(size_t)c] + xi * res(A->x ? A->x[q] : 1) % p) % p; // xi, residue < 2^32: the product fits 64 bits
+            }
+        }
+        // ascending pivot columns: row k touches only columns >= pivcol[k], so an eliminated column stays zero
+        for (int j = 0; j < m; j++) {
+            const int k = fact->qinv[j];
+            if (k < 0 || y[(size_t)j] == 0) continue;
+            const uint64_t c = y[(size_t)j];
+            for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
+                const size_t col = (size_t)U->j[q];
+                y[col] = (y[col] + (p - c * res(U->x[q]) % p)) % p;
+            }
+        }
+        for (int j = 0; j < m; j++) if (y[(size_t)j] != 0) return false;
+    }
+    return true;
+}
+
+namespace {
 inline uint64_t row_seed(uint64_t seed, uint64_t row)
 {
     uint64_t x = seed ^ (row * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull);

@@ -196,6 +196,7 @@ def test_config2_random_10k(S, O):
     olu = O.echelonize(A)
     assert fact.r == olu.r
     assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()
+    assert S.factorization_verify(A, fact, 2)  # the reference's self-check (src/SpaSM.jl:934) accepts the engine's LU
     K = S.kernel(fact)
     oK = O.kernel(olu)
     assert K.shape == (oK.n, oK.m)
@@ -228,6 +229,7 @@ def test_config5_macaulay_style_scaled_down(S, O):
     olu = O.echelonize(A)
     assert fact.r == olu.r
     assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()
+    assert S.factorization_verify(A, fact, 5)
     K = S.kernel(fact)
     oK = O.kernel(olu)
     assert K.shape == (oK.n, oK.m) and (K.p == oK.p).all()

@@ -98,6 +98,7 @@ def _echelonize_worker(rank, world, port, kind, n, m, kw, p, seed, finish_nnz, q
         torch.cuda.set_device(0)
         A = S.synth_csr(kind, n, m, prime=p, seed=seed, **kw)
         fact, info = sharded.echelonize_sharded(A, finish_nnz=finish_nnz)
+        assert S.factorization_verify(A, fact, 9)
         K = S.kernel(fact)
         q.put((rank, fact.r, np.asarray(fact.qinv).tolist(), np.asarray(fact.p).tolist(), fact.U.rows(), K.rows(),
                [(r["finish"], r["npiv"]) for r in info["rounds"]]))
