@@ -135,6 +135,10 @@ struct spasm_csr *spasm_transpose(const struct spasm_csr *A);        /* src/SpaS
 void spasm_echelonize_init_opts(struct echelonize_opts *opts);       /* src/SpaSM.jl:817 */
 struct spasm_lu *spasm_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts); /* :863 */
 struct spasm_csr *spasm_kernel(const struct spasm_lu *fact);         /* src/SpaSM.jl:879 */
+/* spasm_rref.c (src/SpaSM.jl:871): the reduced row echelon form of fact->U (r x m; row k = row k of U with its entries on the
+ * other pivot columns eliminated, pivot 1 first); Rqinv (m entries, may be NULL) receives the pivot column -> row map.
+ * Pivots must be the leftmost entries of their rows (this engine's LUs). */
+struct spasm_csr *spasm_rref(const struct spasm_lu *fact, int *Rqinv);
 
 /* ====================================================================================
  * Engine extensions (no reference counterpart): device-resident handles.

@@ -22,6 +22,7 @@ from .api import (
     nnz,
     prime0,
     rank,
+    rref,
     save,
     sparse,
     synth_csr,
@@ -30,5 +31,5 @@ from .api import (
 
 __all__ = [
     "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "factorization_verify", "kernel",
-    "last_rounds", "nnz", "prime0", "rank", "sparse", "synth_csr", "transpose",
+    "last_rounds", "nnz", "prime0", "rank", "rref", "sparse", "synth_csr", "transpose",
 ]

@@ -364,6 +364,18 @@ def kernel(A, verbose=False, **kwargs):
     return CSR(ptr)
 
 
+def rref(fact, verbose=False):
+    """rref(fact) -> (R, Rqinv) (reference src/SpaSM.jl:871): reduced row echelon form of fact.U; Rqinv[j] = row of R whose
+    pivot is column j, or -1."""
+    m = fact.U.m
+    rq = np.full(max(m, 1), -1, dtype=np.int32)
+    with _quiet(not verbose):
+        ptr = _abi.lib().spasm_rref(fact.data, rq.ctypes.data_as(C.POINTER(C.c_int32)))
+    if not ptr:
+        raise SpasmError("spasm_rref failed: " + _abi.last_error())
+    return CSR(ptr), rq[:m]
+
+
 def factorization_verify(A, fact, seed=0):
     """factorization_verify(A, fact, seed) (reference src/SpaSM.jl:934): probabilistic self-check, on the host, that the row
     space of A lies in the span of fact.U and that U has echelon shape (so rank(A) <= fact.r).  With L = NULL the converse

@@ -1412,6 +1412,119 @@ struct spasm_csr *do_transpose(const struct spasm_csr *A)
 // round (each row of U is reduced by all the others); the kernel vector of free column j is then
 // -e_j + sum_a R[a][j] e_{pivcol(a)}: a transpose of R's free part (known answers test/runtests.jl:20-23).
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// spasm_rref (reference src/SpaSM.jl:871): the reduced row echelon form of U.  Row k of R is row k of U minus the
+// combination of the OTHER rows that clears its entries on their pivot columns -- one Schur "round" in which every row
+// of U is a pivot row and, at the same time, a row to reduce with its own pivot excluded (self_idx).  Requires pivots
+// that are the leftmost entries of their rows (true for this engine's and the oracle's LUs): numbering the pivots by
+// ascending column then makes U_PP strictly upper triangular, which is what the solve kernels assume.
+// ------------------------------------------------------------------------------------------------
+struct spasm_csr *do_rref(const struct spasm_lu *fact, int *Rqinv)
+{
+    require_device();
+    if (!fact || !fact->U || !fact->qinv) throw EngineError("spasm_rref: incomplete factorization (U / qinv missing)");
+    const struct spasm_csr *U = fact->U;
+    check_input(U, "spasm_rref");
+    const int r = U->n, m = U->m;
+    const int *qinv = fact->qinv;
+    const i64 prime = U->field->p;
+    // pivots numbered by ascending column: idx -> (column, row of U)
+    std::vector<int> h_qinv_r((size_t)std::max(m, 1), -1), h_pivcol, h_pivrow, h_self((size_t)std::max(r, 1), -1);
+    for (int j = 0; j < m; j++) {
+        const int k = qinv[j];
+        if (k >= r) throw EngineError("spasm_rref: qinv points outside U");
+        if (k < 0) continue;
+        h_qinv_r[(size_t)j] = (int)h_pivcol.size();
+        h_self[(size_t)k] = (int)h_pivcol.size();
+        h_pivcol.push_back(j);
+        h_pivrow.push_back(k);
+    }
+    if ((int)h_pivcol.size() != r) throw EngineError("spasm_rref: qinv does not name one pivot column per row of U");
+    for (int k = 0; k < r; k++) {
+        const int pc = h_pivcol[(size_t)h_self[(size_t)k]];
+        bool unit = false;
+        for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
+            if (U->j[q] < pc) throw EngineError("spasm_rref: the pivot of a row of U must be its leftmost entry");
+            if (U->j[q] == pc && U->x[q] == 1) unit = true;
+        }
+        if (!unit) throw EngineError("spasm_rref: pivots of U must be 1");
+    }
+    struct spasm_csr *Rm = nullptr;
+    std::vector<i64> sp((size_t)r + 1, 0);
+    std::vector<int> sj, sx;
+    if (r > 0) {
+        hipStream_t s = nullptr;
+        DevMat PM;
+        upload_csr(U, 0, r, PM, s);
+        std::unique_ptr<Round> R(new Round());
+        R->F = zp_field_make(prime);
+        R->stream = s;
+        R->m = m;
+        R->npiv = r;
+        R->nnp = r;
+        R->qinv_r.alloc((size_t)m + 1);
+        R->pivcol.alloc((size_t)r + 1);
+        R->pivrow.alloc((size_t)r + 1);
+        R->np_rows.alloc((size_t)r + 1);
+        DevBuf<int> self;
+        self.alloc((size_t)r + 1);
+        HIPCHK(hipMemcpyAsync(R->qinv_r.p, h_qinv_r.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(R->pivcol.p, h_pivcol.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(R->pivrow.p, h_pivrow.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(self.p, h_self.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(r, 256)), dim3(256), 0, s, r, R->np_rows.p);
+        HIPCHK(hipGetLastError());
+        R->build_U(PM, R->pivrow.p);
+        R->prepare_uinv(r);
+        const i64 tot = R->solve_phase(PM, R->np_rows.p, self.p, r, 4 * spasm_nnz(U));
+        R->S.ent.ensure((size_t)tot + 1);
+        R->run_scatter(PM, R->np_rows.p, r);
+        R->fetch_counters();
+        // the non-pivot parts of the reduced rows, compacted on the device
+        DevBuf<i64d> len64, ostart;
+        len64.alloc((size_t)r + 1);
+        ostart.alloc((size_t)r + 1);
+        hipLaunchKernelGGL(k_copy_len64, dim3(cdiv((i64)r + 1, 256)), dim3(256), 0, s, r, R->S.len.p, len64.p);
+        HIPCHK(hipGetLastError());
+        R->scan.exclusive(len64.p, ostart.p, (size_t)r + 1, s);
+        HIPCHK(hipMemcpyAsync(sp.data(), ostart.p, ((size_t)r + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const i64 nz = sp[(size_t)r];
+        DevBuf<int> oj, ox;
+        oj.alloc((size_t)nz + 1);
+        ox.alloc((size_t)nz + 1);
+        constexpr int TEAM = 16;
+        hipLaunchKernelGGL((k_compact_rows<TEAM>), dim3(cdiv((i64)r * TEAM, 256)), dim3(256), 0, s, r, R->S.start.p, R->S.len.p, R->S.ent.p, ostart.p, oj.p, ox.p);
+        HIPCHK(hipGetLastError());
+        sj.resize((size_t)nz);
+        sx.resize((size_t)nz);
+        if (nz > 0) {
+            HIPCHK(hipMemcpyAsync(sj.data(), oj.p, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(sx.data(), ox.p, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    const i64 total = (r > 0 ? sp[(size_t)r] : 0) + r;
+    Rm = spasm_csr_alloc(r, m, total, prime, true);
+    if (!Rm) throw EngineError("out of host memory for R");
+    i64 w = 0;
+    for (int k = 0; k < r; k++) {
+        Rm->p[k] = w;
+        Rm->j[w] = h_pivcol[(size_t)h_self[(size_t)k]];
+        Rm->x[w] = 1;
+        w++;
+        const i64 a = sp[(size_t)k], b = sp[(size_t)k + 1];
+        if (b > a) {
+            memcpy(Rm->j + w, sj.data() + a, (size_t)(b - a) * sizeof(int));
+            memcpy(Rm->x + w, sx.data() + a, (size_t)(b - a) * sizeof(int));
+            w += b - a;
+        }
+    }
+    Rm->p[r] = w;
+    if (Rqinv) for (int j = 0; j < m; j++) Rqinv[j] = qinv[j];
+    return Rm;
+}
+
 struct spasm_csr *do_kernel(const struct spasm_lu *fact)
 {
     require_device();
@@ -1842,6 +1955,17 @@ SPASM_API struct spasm_csr *spasm_kernel(const struct spasm_lu *fact)
         return do_kernel(fact);
     } catch (const std::exception &e) {
         spasm_set_error("spasm_kernel: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API struct spasm_csr *spasm_rref(const struct spasm_lu *fact, int *Rqinv)
+{
+    spasm_clear_error();
+    try {
+        return do_rref(fact, Rqinv);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_rref: %s", e.what());
         return nullptr;
     }
 }

@@ -264,6 +264,59 @@ def test_rounds_in_row_batches_when_memory_is_short(S, O, monkeypatch, kind, n, 
     assert S.kernel(got).rows() == S.kernel(ref).rows()
 
 
+@pytest.mark.parametrize("n,m,p,density,seed", [(60, 80, 65521, 0.08, 1), (120, 90, 127, 0.05, 2), (90, 140, 2147483647, 0.06, 3),
+                                                (200, 260, 42013, 0.02, 4), (40, 70, 0xfffffffb, 0.1, 5)])
+def test_rref_is_the_unique_reduced_echelon_form(S, O, n, m, p, density, seed):
+    """rref(fact) (reference src/SpaSM.jl:871) against an independent dense Gauss-Jordan elimination: the reduced row echelon
+    form of a matrix is unique, so the rows must agree entry for entry (row k of R is the row whose pivot is Rqinv^-1(k))."""
+    rng = np.random.default_rng(seed)
+    D = ((rng.random((n, m)) < density) * rng.integers(1, min(p, 1 << 31), size=(n, m))).astype(np.int64)
+    D[n - 1] = (3 * D[0] + 5 * D[1]) % p  # rank deficiency
+    A = S.CSR(D.T.copy(), prime=p)         # CSR(dense) stores the transpose, like the reference: rows of A = rows of D
+    fact = S.echelonize(A)
+    R, rq = S.rref(fact)
+    want, piv = O.dense_rref(D, p)
+    assert R.n == fact.r == len(piv)
+    assert sorted(np.flatnonzero(rq >= 0).tolist()) == piv
+    got = np.zeros((R.n, m), dtype=object)
+    for k, row in enumerate(R.rows()):
+        assert row[0][1] == 1                                  # the pivot comes first and is 1
+        for c, v in row:
+            got[k, c] = v % p
+    for a, c in enumerate(piv):                                # dense_rref orders its rows by pivot column
+        assert (got[int(rq[c])] == np.asarray(want[a], dtype=object)).all()
+    assert S.factorization_verify(A, S.LU.from_parts(S.CSR.from_rows(R.rows(), m, p), rq, np.full(max(n, m), -1, dtype=np.int32)), 1)
+
+
+def test_rref_of_a_multi_round_factorization(S, O):
+    """U of several sparse rounds plus a dense tail (config-2 style, scaled down): R must have no entry on a foreign pivot
+    column, span the same space (verify), and reproduce the kernel through the textbook formula k[piv(a)] = R[a][j]."""
+    A = S.synth_csr(0, 1500, 1600, density=3e-3, prime=42013, seed=0xABCD)
+    fact = S.echelonize(A)
+    assert len(S.last_rounds()) >= 2
+    R, rq = S.rref(fact)
+    assert R.n == fact.r
+    pivcols = set(np.flatnonzero(rq >= 0).tolist())
+    for k, row in enumerate(R.rows()):
+        assert row[0][1] == 1 and int(rq[row[0][0]]) == k
+        assert not any(c in pivcols for c, _ in row[1:])
+    assert S.factorization_verify(A, S.LU.from_parts(S.CSR.from_rows(R.rows(), A.m, 42013), rq, np.full(max(A.n, A.m), -1, dtype=np.int32)), 3)
+    K = S.kernel(fact)
+    p = 42013
+    Rrows = R.rows()
+    kr = K.rows()
+    free = [j for j in range(A.m) if rq[j] < 0]
+    assert len(kr) == len(free)
+    for f in range(0, len(free), max(1, len(free) // 25)):
+        j = free[f]
+        want = {j: -1}
+        for k, row in enumerate(Rrows):
+            for c, v in row[1:]:
+                if c == j:
+                    want[row[0][0]] = v
+        assert dict(kr[f]) == want
+
+
 # ---- one Schur round (the benchmark's unit of work) vs the oracle -------------------------------
 
 def run_plan(S, A, lo=0, hi=None, stride=1):
