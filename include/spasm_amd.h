@@ -224,6 +224,13 @@ int spasm_amd_shard_elect(spasm_amd_shard *sh, int64_t *keys_dev);
 int spasm_amd_shard_set_keys(spasm_amd_shard *sh, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned);
 int spasm_amd_shard_export(spasm_amd_shard *sh, int *hdr_dev, int *ent_dev);
 spasm_amd_schur_plan *spasm_amd_shard_import(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev);
+/* Multi-round sharded echelonization (spasm.jl_amd/sharded.py: echelonize_sharded): the Schur rows of a sharded plan become the
+ * shard's matrix of the next round, on the device, under the same numbering (local row i = original row lo + i * stride; this
+ * round's pivot rows and empty rows are empty rows).  Runs the plan if it has not run; CONSUMES the plan (also on failure the
+ * caller must not use it again); rows_out / nnz_out: non-empty rows and entries of the new matrix. */
+spasm_amd_shard *spasm_amd_schur_plan_advance(spasm_amd_schur_plan *plan, int *rows_out, i64 *nnz_out);
+/* the shard's current rows as a host CSR with one row per local row (empty ones included); free with spasm_csr_free */
+struct spasm_csr *spasm_amd_shard_fetch(spasm_amd_shard *sh);
 void spasm_amd_shard_free(spasm_amd_shard *sh);
 
 /* Per-round records of the most recent spasm_echelonize call on this thread. */

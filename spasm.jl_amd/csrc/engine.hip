@@ -1835,6 +1835,88 @@ spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries
     return P;
 }
 
+void plan_run(spasm_amd_schur_plan *P, hipStream_t s);
+
+// The round of a sharded plan becomes history: its Schur rows become the shard's matrix of the next round, on the device and
+// under the same local numbering (local row i = original row lo + i * stride).  Consumes the plan.
+spasm_amd_shard *plan_advance(spasm_amd_schur_plan *P, int *rows_out, i64 *nnz_out)
+{
+    if (!P) throw EngineError("spasm_amd_schur_plan_advance: null plan");
+    if (!P->ran) plan_run(P, P->R.stream);
+    Round &R = P->R;
+    hipStream_t s = R.stream;
+    R.fetch_counters(); // synchronises; throws on an exhausted pool / table
+    const int n = P->A.n, nnp = R.nnp;
+    std::unique_ptr<spasm_amd_shard> S2(new spasm_amd_shard());
+    std::unique_ptr<spasm_amd_schur_plan> P2(new spasm_amd_schur_plan());
+    P2->lo = P->lo;
+    P2->hi = P->hi;
+    P2->stride = P->stride;
+    P2->prime = P->prime;
+    P2->nnz_in = (i64)R.hctr.nnz_out;
+    DevMat &A2 = P2->A;
+    A2.n = n;
+    A2.m = P->A.m;
+    A2.start.alloc((size_t)n + 1);
+    A2.len.alloc((size_t)n + 1);
+    A2.lead.alloc((size_t)n + 1);
+    A2.orig.alloc((size_t)n + 1);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_advance_init, dim3(cdiv(n, 256)), dim3(256), 0, s, n, P->lo, P->stride, A2.start.p, A2.len.p, A2.lead.p, A2.orig.p);
+        HIPCHK(hipGetLastError());
+    }
+    if (nnp > 0) {
+        hipLaunchKernelGGL(k_advance_rows, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, n, P->lo, P->stride, R.S.start.p, R.S.len.p, R.S.lead.p,
+                           R.S.orig.p, A2.start.p, A2.len.p, A2.lead.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    A2.ent = std::move(R.S.ent);
+    P2->R.F = zp_field_make(P2->prime);
+    P2->R.stream = s;
+    S2->n_total = P->hi;
+    if (rows_out) *rows_out = R.hctr.nonempty_out;
+    if (nnz_out) *nnz_out = (i64)R.hctr.nnz_out;
+    S2->plan = P2.release();
+    delete P;
+    return S2.release();
+}
+
+// the shard's rows as a host CSR with one row per LOCAL row (empty rows included; local row i = original row lo + i * stride)
+struct spasm_csr *shard_fetch(spasm_amd_shard *S)
+{
+    if (!S || !S->plan) throw EngineError("spasm_amd_shard_fetch: the shard has no matrix (already imported?)");
+    spasm_amd_schur_plan *P = S->plan;
+    Round &R = P->R;
+    hipStream_t s = R.stream;
+    const int n = P->A.n;
+    DevBuf<i64d> len64, ostart;
+    len64.alloc((size_t)n + 1);
+    ostart.alloc((size_t)n + 1);
+    hipLaunchKernelGGL(k_copy_len64, dim3(cdiv((i64)n + 1, 256)), dim3(256), 0, s, n, P->A.len.p, len64.p);
+    HIPCHK(hipGetLastError());
+    R.scan.exclusive(len64.p, ostart.p, (size_t)n + 1, s);
+    std::vector<i64d> hp((size_t)n + 1);
+    HIPCHK(hipMemcpyAsync(hp.data(), ostart.p, ((size_t)n + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const i64 tot = hp[(size_t)n];
+    struct spasm_csr *out = spasm_csr_alloc(n, P->A.m, tot, P->prime, true);
+    if (!out) throw EngineError("out of host memory for the shard's rows");
+    for (int i = 0; i <= n; i++) out->p[i] = hp[(size_t)i];
+    if (tot > 0) {
+        DevBuf<int> oj, ox;
+        oj.alloc((size_t)tot);
+        ox.alloc((size_t)tot);
+        constexpr int TEAM = 16;
+        hipLaunchKernelGGL((k_compact_rows<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, P->A.start.p, P->A.len.p, P->A.ent.p, ostart.p, oj.p, ox.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out->j, oj.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out->x, ox.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return out;
+}
+
 spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi, int stride = 1)
 {
     require_device();
@@ -2107,6 +2189,28 @@ SPASM_API spasm_amd_schur_plan *spasm_amd_shard_import(spasm_amd_shard *sh, int 
         return shard_import(sh, n_rows, n_entries, hdr_dev, ent_dev);
     } catch (const std::exception &e) {
         spasm_set_error("spasm_amd_shard_import: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API spasm_amd_shard *spasm_amd_schur_plan_advance(spasm_amd_schur_plan *plan, int *rows_out, i64 *nnz_out)
+{
+    spasm_clear_error();
+    try {
+        return plan_advance(plan, rows_out, nnz_out);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_schur_plan_advance: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API struct spasm_csr *spasm_amd_shard_fetch(spasm_amd_shard *sh)
+{
+    spasm_clear_error();
+    try {
+        return shard_fetch(sh);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_fetch: %s", e.what());
         return nullptr;
     }
 }

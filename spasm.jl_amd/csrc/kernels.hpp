@@ -1331,6 +1331,33 @@ __global__ void k_copy_len64(int n, const int *__restrict__ len, i64d *__restric
 
 // rows of a batch of the round appended compactly to the matrix of the next round: entries to dst + ostart[i],
 // row i of the batch becomes row row_off + i with start dst_off + ostart[i]
+// A shard's next-round matrix from its Schur rows, in place: local row (orig - lo) / stride of the new matrix is the slice of
+// the Schur row with that original number; every other row (this round's pivots, rows that were or became empty) is empty.
+// No entry moves: the new matrix takes over the Schur entry buffer.
+__global__ void k_advance_init(int n, int row_lo, int row_stride, i64d *__restrict__ start, int *__restrict__ len, int *__restrict__ lead,
+                               int *__restrict__ orig)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    start[i] = 0;
+    len[i] = 0;
+    lead[i] = INT_MAX;
+    orig[i] = row_lo + i * row_stride;
+}
+
+__global__ void k_advance_rows(int nrows, int n, int row_lo, int row_stride, const i64d *__restrict__ sstart, const int *__restrict__ slen,
+                               const int *__restrict__ slead, const int *__restrict__ sorig, i64d *__restrict__ start, int *__restrict__ len,
+                               int *__restrict__ lead)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows) return;
+    const int li = shard_local(sorig[t], row_lo, row_stride, n);
+    if (li < 0) return;
+    start[li] = sstart[t];
+    len[li] = slen[t];
+    lead[li] = slead[t];
+}
+
 template <int TEAM>
 __global__ void k_append_rows(int n, const i64d *__restrict__ start, const int *__restrict__ len, const int *__restrict__ lead,
                               const int *__restrict__ orig, const int2 *__restrict__ ent, const i64d *__restrict__ ostart, i64d dst_off,

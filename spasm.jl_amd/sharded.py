@@ -147,24 +147,50 @@ def exchange_pivot_rows(engine, group=None):
 # left is small, then every rank finishes the same remainder.
 # ------------------------------------------------------------------------------------------------
 class GpuRoundEngine(GpuShardEngine):
-    """One round of one rank: the exchange protocol of GpuShardEngine plus schur(), which runs the round on the shard and
-    returns its Schur rows as host arrays (ids = rows of the ORIGINAL matrix, ascending)."""
+    """The shard of one rank over all rounds: the exchange protocol of GpuShardEngine plus
+        counts()      (non-empty rows, entries) of the shard's current matrix,
+        advance()     run the round; its Schur rows become the shard's matrix ON THE DEVICE (spasm_amd_schur_plan_advance),
+        fetch_rows()  the current rows as host arrays (ids = rows of the ORIGINAL matrix, ascending) for the final gather."""
 
-    def schur(self):
+    def __init__(self, A, row_lo, row_hi, device=None, stride=1):
+        import numpy as np
+
+        GpuShardEngine.__init__(self, A, row_lo, row_hi, device=device, stride=stride)
+        self.lo, self.stride = int(row_lo), int(stride)
+        lens = np.diff(np.asarray(A.p))[self.lo:int(row_hi):self.stride]
+        self._counts = (int((lens > 0).sum()), int(lens.sum()))
+
+    def counts(self):
+        return self._counts
+
+    def advance(self):
+        rows, nnz = C.c_int32(0), C.c_int64(0)
+        plan, self.plan = self.plan, None  # consumed by the call, whatever happens
+        sh = self.lib.spasm_amd_schur_plan_advance(plan, C.byref(rows), C.byref(nnz))
+        if not sh:
+            raise RuntimeError("spasm_amd_schur_plan_advance failed: " + _abi.last_error())
+        if self.shard:
+            self.lib.spasm_amd_shard_free(self.shard)
+        self.shard = sh
+        self._counts = (int(rows.value), int(nnz.value))
+        return self._counts
+
+    def fetch_rows(self):
         import numpy as np
 
         from .api import CSR
 
-        lib = self.lib
-        if lib.spasm_amd_schur_plan_run(self.plan, None) != 0:
-            raise RuntimeError("spasm_amd_schur_plan_run failed: " + _abi.last_error())
-        ids = np.empty(max(self.A.n, 1), dtype=np.int32)
-        ptr = lib.spasm_amd_schur_plan_fetch(self.plan, ids.ctypes.data_as(C.POINTER(C.c_int32)))
+        ptr = self.lib.spasm_amd_shard_fetch(self.shard)
         if not ptr:
-            raise RuntimeError("spasm_amd_schur_plan_fetch failed: " + _abi.last_error())
-        Sc = CSR(ptr)
-        nnz = int(Sc.p[Sc.n])
-        return ids[: Sc.n].copy(), np.array(Sc.p[: Sc.n + 1], dtype=np.int64), np.array(Sc.j[:nnz]), np.array(Sc.x[:nnz])
+            raise RuntimeError("spasm_amd_shard_fetch failed: " + _abi.last_error())
+        M = CSR(ptr)
+        mp = np.asarray(M.p)
+        lens = np.diff(mp)
+        keep = np.flatnonzero(lens > 0)
+        nnz = int(mp[M.n])
+        ids = self.lo + keep.astype(np.int64) * self.stride
+        # empty rows contribute nothing, so the entries of the kept rows are all entries, in order
+        return ids, np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.int64), np.array(M.j[:nnz]), np.array(M.x[:nnz])
 
 
 def _virtual_csr(n, m, prime, ids, p, j, x):
@@ -215,50 +241,43 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
     finish = finish or (lambda M: api.echelonize(M))
     sparsity_threshold = float(api.EchelonizeOpts().struct.sparsity_threshold)
     n, m, prime = A.n, A.m, int(A.prime)
-    Ap, Aj, Ax = np.asarray(A.p), np.asarray(A.j), np.asarray(A.x)
-    ids = np.arange(rank, n, world, dtype=np.int64)
-    lens = (Ap[ids + 1] - Ap[ids]).astype(np.int64)
-    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    take = _ranges(Ap[ids].astype(np.int64), lens)
-    j, x = Aj[take].astype(np.int32), Ax[take].astype(np.int32)
-
+    eng = engine_cls(A, rank, n, stride=world)  # the rank's rows stay on its device from here on
     u_cols, u_vals, u_len, u_pivcol, u_orig = [], [], [], [], []
     rounds = []
-    while True:
-        tot = all_gather_counts([len(ids), int(p[-1])], group).sum(dim=0)
-        rows_left, nnz_left = int(tot[0]), int(tot[1])
-        if nnz_left == 0:
-            break
-        free_cols = m - len(u_len)
-        dense_enough = nnz_left > sparsity_threshold * rows_left * max(free_cols, 1)  # the single-device rule for its dense tail
-        if nnz_left <= finish_nnz or len(rounds) >= max_rounds or dense_enough:
-            # hand-off: every rank gets all remaining rows and finishes them (deterministic, so the results agree)
-            counts = all_gather_counts([len(ids), int(p[-1])], group)
-            dev = "cuda" if dist.is_initialized() and dist.get_backend(group) != "gloo" else "cpu"
-            g_ids = all_gather_var(torch.as_tensor(ids, dtype=torch.int64, device=dev), counts[:, 0].tolist(), group).cpu().numpy()
-            g_len = all_gather_var(torch.as_tensor(np.diff(p), dtype=torch.int64, device=dev), counts[:, 0].tolist(), group).cpu().numpy()
-            g_ent = all_gather_var(torch.as_tensor(np.stack([j, x], axis=1).reshape(-1, 2), dtype=torch.int32, device=dev),
-                                   counts[:, 1].tolist(), group).cpu().numpy()
-            order = np.argsort(g_ids, kind="stable")
-            starts = np.concatenate([[0], np.cumsum(g_len)])
-            sel = _ranges(starts[:-1][order], g_len[order])
-            rest = _virtual_csr(n, m, prime, g_ids[order], np.concatenate([[0], np.cumsum(g_len[order])]), g_ent[sel, 0], g_ent[sel, 1])
-            fact = finish(rest)
-            Uc, fp, fq = fact.U, np.asarray(fact.p), np.asarray(fact.qinv)
-            up, uj, ux = np.asarray(Uc.p), np.asarray(Uc.j), np.asarray(Uc.x)
-            col_of_row = np.full(fact.r, -1, dtype=np.int64)
-            col_of_row[fq[fq >= 0]] = np.flatnonzero(fq >= 0)
-            for k in range(fact.r):
-                u_cols.append(np.array(uj[up[k]:up[k + 1]]))
-                u_vals.append(np.array(ux[up[k]:up[k + 1]]))
-                u_len.append(int(up[k + 1] - up[k]))
-                u_pivcol.append(int(col_of_row[k]))
-                u_orig.append(int(fp[k]))
-            rounds.append({"round": len(rounds), "finish": True, "rows": rows_left, "nnz": nnz_left, "npiv": int(fact.r)})
-            break
-        Av = _virtual_csr(n, m, prime, ids, p, j, x)
-        eng = engine_cls(Av, rank, n, stride=world)
-        try:
+    try:
+        while True:
+            tot = all_gather_counts(list(eng.counts()), group).sum(dim=0)
+            rows_left, nnz_left = int(tot[0]), int(tot[1])
+            if nnz_left == 0:
+                break
+            free_cols = m - len(u_len)
+            dense_enough = nnz_left > sparsity_threshold * rows_left * max(free_cols, 1)  # the single-device rule for its dense tail
+            if nnz_left <= finish_nnz or len(rounds) >= max_rounds or dense_enough:
+                # hand-off: every rank gets all remaining rows and finishes them (deterministic, so the results agree)
+                ids, p, j, x = eng.fetch_rows()
+                counts = all_gather_counts([len(ids), int(p[-1])], group)
+                dev = "cuda" if dist.is_initialized() and dist.get_backend(group) != "gloo" else "cpu"
+                g_ids = all_gather_var(torch.as_tensor(ids, dtype=torch.int64, device=dev), counts[:, 0].tolist(), group).cpu().numpy()
+                g_len = all_gather_var(torch.as_tensor(np.diff(p), dtype=torch.int64, device=dev), counts[:, 0].tolist(), group).cpu().numpy()
+                g_ent = all_gather_var(torch.as_tensor(np.stack([j, x], axis=1).reshape(-1, 2), dtype=torch.int32, device=dev),
+                                       counts[:, 1].tolist(), group).cpu().numpy()
+                order = np.argsort(g_ids, kind="stable")
+                starts = np.concatenate([[0], np.cumsum(g_len)])
+                sel = _ranges(starts[:-1][order], g_len[order])
+                rest = _virtual_csr(n, m, prime, g_ids[order], np.concatenate([[0], np.cumsum(g_len[order])]), g_ent[sel, 0], g_ent[sel, 1])
+                fact = finish(rest)
+                Uc, fp, fq = fact.U, np.asarray(fact.p), np.asarray(fact.qinv)
+                up, uj, ux = np.asarray(Uc.p), np.asarray(Uc.j), np.asarray(Uc.x)
+                col_of_row = np.full(fact.r, -1, dtype=np.int64)
+                col_of_row[fq[fq >= 0]] = np.flatnonzero(fq >= 0)
+                for k in range(fact.r):
+                    u_cols.append(np.array(uj[up[k]:up[k + 1]]))
+                    u_vals.append(np.array(ux[up[k]:up[k + 1]]))
+                    u_len.append(int(up[k + 1] - up[k]))
+                    u_pivcol.append(int(col_of_row[k]))
+                    u_orig.append(int(fp[k]))
+                rounds.append({"round": len(rounds), "finish": True, "rows": rows_left, "nnz": nnz_left, "npiv": int(fact.r)})
+                break
             keys = all_reduce_min(eng.elect(), group)
             npiv, n_own, nnz_own = eng.set_keys(keys)
             if npiv == 0:
@@ -289,12 +308,11 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
                     pc = int(cols_all[lead_pos[t]])
                     u_pivcol.append(pc)
                     u_orig.append(int(keys_h[pc] & 0xffffffff))
-            ids, p, j, x = eng.schur()
-            ids = ids.astype(np.int64)
+            eng.advance()  # the round runs; its Schur rows are the shard's matrix of the next round, still on the device
             rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv),
                            "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4)})
-        finally:
-            eng.close()
+    finally:
+        eng.close()
 
     r = len(u_len)
     up = np.concatenate([[0], np.cumsum(np.asarray(u_len, dtype=np.int64))]).astype(np.int64)

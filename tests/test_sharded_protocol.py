@@ -123,8 +123,8 @@ def test_exchange_protocol_two_ranks_gloo(S, O):
 
 
 class NumpyRoundEngine(NumpyShardEngine):
-    """The engine contract of sharded.echelonize_sharded on the CPU: built from the n-row "virtual" matrix of a round
-    (rows rank, rank + stride, ... belong to this rank, the others are empty), python elimination for the Schur rows."""
+    """The engine contract of sharded.echelonize_sharded on the CPU: rows lo, lo + stride, ... of the matrix stay with this
+    rank over all rounds (python elimination for the Schur rows)."""
 
     def __init__(self, Av, lo, hi, stride=1):
         rows = Av.rows()
@@ -148,12 +148,21 @@ class NumpyRoundEngine(NumpyShardEngine):
         self.owned = [(idx, local[g]) for idx, g in enumerate(self.pivrow) if g in local]
         return len(self.pivcols), len(self.owned), sum(len(self.rows[i]) for _, i in self.owned)
 
-    def schur(self):
-        self.lo, ids = 0, self.ids  # schur_rows() reports lo + local index: translate to global ids below
-        out = self.schur_rows()
-        gid = np.array([ids[i] for i, _ in out], dtype=np.int64)
-        lens = np.array([len(r) for _, r in out], dtype=np.int64)
-        ent = np.array([e for _, r in out for e in r], dtype=np.int64).reshape(-1, 2)
+    def counts(self):
+        return sum(1 for r in self.rows if r), sum(len(r) for r in self.rows)
+
+    def advance(self):
+        """the round's Schur rows replace the shard's rows (pivot rows and eliminated rows become empty)"""
+        self.lo = 0
+        out = dict(self.schur_rows())  # local index -> Schur row
+        self.rows = [out.get(i, []) for i in range(len(self.rows))]
+        return self.counts()
+
+    def fetch_rows(self):
+        keep = [i for i, r in enumerate(self.rows) if r]
+        gid = np.array([self.ids[i] for i in keep], dtype=np.int64)
+        lens = np.array([len(self.rows[i]) for i in keep], dtype=np.int64)
+        ent = np.array([e for i in keep for e in self.rows[i]], dtype=np.int64).reshape(-1, 2)
         return gid, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), ent[:, 0].astype(np.int32), ent[:, 1].astype(np.int32)
 
     def close(self):
