@@ -242,7 +242,8 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
     sparsity_threshold = float(api.EchelonizeOpts().struct.sparsity_threshold)
     n, m, prime = A.n, A.m, int(A.prime)
     eng = engine_cls(A, rank, n, stride=world)  # the rank's rows stay on its device from here on
-    u_cols, u_vals, u_len, u_pivcol, u_orig = [], [], [], [], []
+    blocks = []  # per round: (row lengths, columns, values, pivot columns, original rows) of its rows of U
+    n_u = 0
     rounds = []
     try:
         while True:
@@ -250,7 +251,7 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
             rows_left, nnz_left = int(tot[0]), int(tot[1])
             if nnz_left == 0:
                 break
-            free_cols = m - len(u_len)
+            free_cols = m - n_u
             dense_enough = nnz_left > sparsity_threshold * rows_left * max(free_cols, 1)  # the single-device rule for its dense tail
             if nnz_left <= finish_nnz or len(rounds) >= max_rounds or dense_enough:
                 # hand-off: every rank gets all remaining rows and finishes them (deterministic, so the results agree)
@@ -270,12 +271,9 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
                 up, uj, ux = np.asarray(Uc.p), np.asarray(Uc.j), np.asarray(Uc.x)
                 col_of_row = np.full(fact.r, -1, dtype=np.int64)
                 col_of_row[fq[fq >= 0]] = np.flatnonzero(fq >= 0)
-                for k in range(fact.r):
-                    u_cols.append(np.array(uj[up[k]:up[k + 1]]))
-                    u_vals.append(np.array(ux[up[k]:up[k + 1]]))
-                    u_len.append(int(up[k + 1] - up[k]))
-                    u_pivcol.append(int(col_of_row[k]))
-                    u_orig.append(int(fp[k]))
+                nzu = int(up[fact.r])
+                blocks.append((np.diff(up).astype(np.int64), np.array(uj[:nzu]), np.array(ux[:nzu]), col_of_row, fp[: fact.r].astype(np.int64)))
+                n_u += fact.r
                 rounds.append({"round": len(rounds), "finish": True, "rows": rows_left, "nnz": nnz_left, "npiv": int(fact.r)})
                 break
             keys = all_reduce_min(eng.elect(), group)
@@ -297,27 +295,32 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
             cols_all, vals_all = e[sel, 0].astype(np.int64), e[sel, 1].astype(np.int64)
             rs = np.concatenate([[0], np.cumsum(h[order, 1])]).astype(np.int64)
             if len(order):
-                lead_pos = np.array([rs[t] + int(np.argmin(cols_all[rs[t]:rs[t + 1]])) for t in range(len(order))], dtype=np.int64)
-                invs = np.array([pow(int(v) % prime, -1, prime) for v in vals_all[lead_pos]], dtype=object)
-                prod = (vals_all.astype(object) % prime) * np.repeat(invs, h[order, 1]) % prime  # exact (python integers)
+                # position of the leftmost entry of every row: the smallest of (column, position) keys per segment
+                key = cols_all * (len(cols_all) + 1) + np.arange(len(cols_all), dtype=np.int64)
+                lead_pos = np.minimum.reduceat(key, rs[:-1]) % (len(cols_all) + 1)
+                invs = [pow(int(v) % prime, -1, prime) for v in vals_all[lead_pos]]
+                if prime < (1 << 31):  # residues and inverses below 2^31: the products fit int64
+                    prod = (vals_all % prime) * np.repeat(np.array(invs, dtype=np.int64), h[order, 1]) % prime
+                else:                  # exact python integers
+                    prod = (vals_all.astype(object) % prime) * np.repeat(np.array(invs, dtype=object), h[order, 1]) % prime
                 sv_all = np.where(prod > prime // 2, prod - prime, prod).astype(np.int64)
-                for t in range(len(order)):
-                    u_cols.append(cols_all[rs[t]:rs[t + 1]])
-                    u_vals.append(sv_all[rs[t]:rs[t + 1]])
-                    u_len.append(int(rs[t + 1] - rs[t]))
-                    pc = int(cols_all[lead_pos[t]])
-                    u_pivcol.append(pc)
-                    u_orig.append(int(keys_h[pc] & 0xffffffff))
+                pcs = cols_all[lead_pos]
+                blocks.append((h[order, 1].astype(np.int64), cols_all, sv_all, pcs, (keys_h[pcs] & 0xffffffff).astype(np.int64)))
+                n_u += len(order)
             eng.advance()  # the round runs; its Schur rows are the shard's matrix of the next round, still on the device
             rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv),
                            "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4)})
     finally:
         eng.close()
 
-    r = len(u_len)
-    up = np.concatenate([[0], np.cumsum(np.asarray(u_len, dtype=np.int64))]).astype(np.int64)
-    uj = np.concatenate(u_cols).astype(np.int32) if r and up[-1] else np.zeros(0, dtype=np.int32)
-    ux = np.concatenate(u_vals).astype(np.int32) if r and up[-1] else np.zeros(0, dtype=np.int32)
+    r = n_u
+
+    def cat(i, dt):
+        return np.concatenate([b[i] for b in blocks]).astype(dt) if blocks else np.zeros(0, dtype=dt)
+
+    up = np.concatenate([[0], np.cumsum(cat(0, np.int64))]).astype(np.int64)
+    uj, ux = cat(1, np.int32), cat(2, np.int32)
+    u_pivcol, u_orig = cat(3, np.int64), cat(4, np.int64)
     U = api.CSR.from_arrays(r, m, up, uj, ux, prime)
     qinv = np.full(max(m, 1), -1, dtype=np.int32)
     if r:
