@@ -224,6 +224,9 @@ int spasm_amd_shard_elect(spasm_amd_shard *sh, int64_t *keys_dev);
 int spasm_amd_shard_set_keys(spasm_amd_shard *sh, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned);
 int spasm_amd_shard_export(spasm_amd_shard *sh, int *hdr_dev, int *ent_dev);
 spasm_amd_schur_plan *spasm_amd_shard_import(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev);
+/* The kernel step of a multi-GPU run: the kernel vectors of the free columns number first, first + step, ... only (free
+ * columns counted in ascending order; vector f of spasm_kernel(fact) is row (f - first) / step here). */
+struct spasm_csr *spasm_amd_kernel_strided(const struct spasm_lu *fact, int first, int step);
 /* Multi-round sharded echelonization (spasm.jl_amd/sharded.py: echelonize_sharded): the Schur rows of a sharded plan become the
  * shard's matrix of the next round, on the device, under the same numbering (local row i = original row lo + i * stride; this
  * round's pivot rows and empty rows are empty rows).  Runs the plan if it has not run; CONSUMES the plan (also on failure the

@@ -1525,7 +1525,9 @@ struct spasm_csr *do_rref(const struct spasm_lu *fact, int *Rqinv)
     return Rm;
 }
 
-struct spasm_csr *do_kernel(const struct spasm_lu *fact)
+// first / step: only the free columns number first, first + step, ... (in ascending column order) get their kernel vector:
+// the unit of the multi-GPU kernel step (free columns are independent)
+struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step = 1)
 {
     require_device();
     if (!fact || !fact->U || !fact->qinv) throw EngineError("spasm_kernel: incomplete factorization (U / qinv missing)");
@@ -1600,7 +1602,15 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact)
     std::vector<int> h_lab((size_t)std::max(r, 1)), h_rowsrc((size_t)std::max(r, 1)), h_free;
     for (int a = 0; a < r; a++) h_lab[(size_t)a] = r - 1 - idx_of[(size_t)a];
     for (int t = 0; t < r; t++) h_rowsrc[(size_t)(r - 1 - t)] = pc[(size_t)perm[(size_t)t]]; // column of pivot ridx
-    for (int j = 0; j < m; j++) if (qinv[j] < 0) h_free.push_back(j);
+    if (first < 0 || step < 1) throw EngineError("spasm_amd_kernel_strided: bad (first, step)");
+    {
+        int f = 0;
+        for (int j = 0; j < m; j++)
+            if (qinv[j] < 0) {
+                if (f >= first && (f - first) % step == 0) h_free.push_back(j);
+                f++;
+            }
+    }
     const int nfree = (int)h_free.size();
 
     hipStream_t s = nullptr;
@@ -2037,6 +2047,17 @@ SPASM_API struct spasm_csr *spasm_kernel(const struct spasm_lu *fact)
         return do_kernel(fact);
     } catch (const std::exception &e) {
         spasm_set_error("spasm_kernel: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API struct spasm_csr *spasm_amd_kernel_strided(const struct spasm_lu *fact, int first, int step)
+{
+    spasm_clear_error();
+    try {
+        return do_kernel(fact, first, step);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_kernel_strided: %s", e.what());
         return nullptr;
     }
 }

@@ -334,3 +334,38 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
     others = np.flatnonzero(~used[:n])
     perm[r:r + len(others)] = others
     return api.LU.from_parts(U, qinv[:m] if m else qinv, perm), {"rounds": rounds, "world": world}
+
+
+def kernel_sharded(fact, group=None):
+    """Right kernel of an echelonized matrix with the free columns sharded over the ranks: rank r computes the
+    vectors of the free columns number r, r + G, ... (spasm_amd_kernel_strided), one variable-length all-gather puts the
+    basis together in the order of spasm_kernel(fact).  Every rank returns the whole basis."""
+    import numpy as np
+
+    from . import api
+
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    ptr = _abi.lib().spasm_amd_kernel_strided(fact.data, rank, world)
+    if not ptr:
+        raise RuntimeError("spasm_amd_kernel_strided failed: " + _abi.last_error())
+    Kl = api.CSR(ptr)
+    if world == 1:
+        return Kl
+    kp = np.asarray(Kl.p)
+    nnz = int(kp[Kl.n])
+    counts = all_gather_counts([Kl.n, nnz], group)
+    dev = "cuda" if dist.get_backend(group) != "gloo" else "cpu"
+    g_len = all_gather_var(torch.as_tensor(np.diff(kp), dtype=torch.int64, device=dev), counts[:, 0].tolist(), group).cpu().numpy()
+    ent = np.stack([np.asarray(Kl.j[:nnz]), np.asarray(Kl.x[:nnz])], axis=1).reshape(-1, 2)
+    g_ent = all_gather_var(torch.as_tensor(ent, dtype=torch.int32, device=dev), counts[:, 1].tolist(), group).cpu().numpy()
+    # vector f of the whole basis is vector f // G of rank f % G
+    per = counts[:, 0].numpy().astype(np.int64)
+    first_row = np.concatenate([[0], np.cumsum(per)])[:-1]            # where rank r's rows start in the gathered order
+    total = int(per.sum())
+    f = np.arange(total, dtype=np.int64)
+    src = first_row[f % world] + f // world                           # gathered index of vector f
+    starts = np.concatenate([[0], np.cumsum(g_len)])
+    sel = _ranges(starts[:-1][src], g_len[src])
+    p_out = np.concatenate([[0], np.cumsum(g_len[src])]).astype(np.int64)
+    return api.CSR.from_arrays(total, Kl.m, p_out, g_ent[sel, 0], g_ent[sel, 1], int(Kl.prime))

@@ -288,6 +288,19 @@ def test_rref_is_the_unique_reduced_echelon_form(S, O, n, m, p, density, seed):
     assert S.factorization_verify(A, S.LU.from_parts(S.CSR.from_rows(R.rows(), m, p), rq, np.full(max(n, m), -1, dtype=np.int32)), 1)
 
 
+def test_kernel_of_a_strided_subset_of_the_free_columns(S):
+    """spasm_amd_kernel_strided (the multi-GPU kernel step): vectors first, first + step, ... of the whole basis."""
+    A = S.synth_csr(0, 900, 1100, density=4e-3, prime=42013, seed=0xFEED)
+    fact = S.echelonize(A)
+    K = S.kernel(fact).rows()
+    assert len(K) == A.m - fact.r > 50
+    lib = S._abi.lib()
+    for first, step in ((0, 1), (0, 3), (2, 3), (5, 7), (len(K) - 1, 2), (len(K) + 3, 2)):
+        ptr = lib.spasm_amd_kernel_strided(fact.data, first, step)
+        assert ptr, S._abi.last_error()
+        assert S.CSR(ptr).rows() == K[first::step]
+
+
 def test_rref_of_a_multi_round_factorization(S, O):
     """U of several sparse rounds plus a dense tail (config-2 style, scaled down): R must have no entry on a foreign pivot
     column, span the same space (verify), and reproduce the kernel through the textbook formula k[piv(a)] = R[a][j]."""

@@ -100,6 +100,7 @@ def _echelonize_worker(rank, world, port, kind, n, m, kw, p, seed, finish_nnz, q
         fact, info = sharded.echelonize_sharded(A, finish_nnz=finish_nnz)
         assert S.factorization_verify(A, fact, 9)
         K = S.kernel(fact)
+        assert sharded.kernel_sharded(fact).rows() == K.rows()  # free columns sharded over the ranks, gathered in order
         q.put((rank, fact.r, np.asarray(fact.qinv).tolist(), np.asarray(fact.p).tolist(), fact.U.rows(), K.rows(),
                [(r["finish"], r["npiv"]) for r in info["rounds"]]))
     except Exception as exc:
