@@ -224,6 +224,11 @@ int spasm_amd_shard_elect(spasm_amd_shard *sh, int64_t *keys_dev);
 int spasm_amd_shard_set_keys(spasm_amd_shard *sh, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned);
 int spasm_amd_shard_export(spasm_amd_shard *sh, int *hdr_dev, int *ent_dev);
 spasm_amd_schur_plan *spasm_amd_shard_import(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev);
+/* X * U = B for every row of B in one device pass: what SpaSM.jl's sparse_triangular_solve(U, B, qinv) / `B / LU`
+ * (src/SpaSM.jl:733-755) obtains by looping spasm_sparse_triangular_solve over the rows of B.  Semantics of :694-713: with x_b on
+ * the pivot columns and x_a on the others, x_b * U + x_a == B[k]; X (rows of B x rows of U) holds x_b indexed by the row of U;
+ * ok[k] = 1 when x_a is empty, i.e. X[k] * U == B[k].  U needs unit pivots that are the leftmost entries of their rows. */
+struct spasm_csr *spasm_amd_triangular_solve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok);
 /* The kernel step of a multi-GPU run: the kernel vectors of the free columns number first, first + step, ... only (free
  * columns counted in ascending order; vector f of spasm_kernel(fact) is row (f - first) / step here). */
 struct spasm_csr *spasm_amd_kernel_strided(const struct spasm_lu *fact, int first, int step);

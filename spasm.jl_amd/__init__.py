@@ -25,11 +25,12 @@ from .api import (
     rref,
     save,
     sparse,
+    sparse_triangular_solve,
     synth_csr,
     transpose,
 )
 
 __all__ = [
     "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "factorization_verify", "kernel",
-    "last_rounds", "nnz", "prime0", "rank", "rref", "sparse", "synth_csr", "transpose",
+    "last_rounds", "nnz", "prime0", "rank", "rref", "sparse", "sparse_triangular_solve", "synth_csr", "transpose",
 ]

@@ -364,6 +364,27 @@ def kernel(A, verbose=False, **kwargs):
     return CSR(ptr)
 
 
+def sparse_triangular_solve(U, B, qinv=None, verbose=False):
+    """sparse_triangular_solve(LU, B) / sparse_triangular_solve(U, B, qinv) (reference src/SpaSM.jl:725-755): solve X * U == B in
+    sparse matrices; returns X (rows of B x rows of U), or None if some row of B has no solution.  One device pass over all
+    rows of B (spasm_amd_triangular_solve)."""
+    if isinstance(U, LU):
+        U, qinv = U.U, U.qinv
+    X, ok = _triangular_solve(U, B, qinv, verbose)
+    return X if bool(ok.all()) else None
+
+
+def _triangular_solve(U, B, qinv, verbose=False):
+    """(X, ok): x_b of every row of B and whether its x_a is empty (reference src/SpaSM.jl:694-713)"""
+    q = np.ascontiguousarray(qinv, dtype=np.int32)
+    ok = np.zeros(max(B.n, 1), dtype=np.uint8)
+    with _quiet(not verbose):
+        ptr = _abi.lib().spasm_amd_triangular_solve(U.data, q.ctypes.data_as(C.POINTER(C.c_int32)), B.data, ok.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    if not ptr:
+        raise SpasmError("spasm_amd_triangular_solve failed: " + _abi.last_error())
+    return CSR(ptr), ok[: B.n].astype(bool)
+
+
 def rref(fact, verbose=False):
     """rref(fact) -> (R, Rqinv) (reference src/SpaSM.jl:871): reduced row echelon form of fact.U; Rqinv[j] = row of R whose
     pivot is column j, or -1."""

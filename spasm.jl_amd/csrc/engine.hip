@@ -1525,6 +1525,104 @@ struct spasm_csr *do_rref(const struct spasm_lu *fact, int *Rqinv)
     return Rm;
 }
 
+// ------------------------------------------------------------------------------------------------
+// X * U = B for every row of B at once (the reference loops spasm_sparse_triangular_solve over the rows of B,
+// src/SpaSM.jl:733-755): with x_b on the pivot columns and x_a on the others, x_b * U + x_a == B[k] (:694-713).  One Schur
+// "round" with U as the pivot rows and B as the rows to reduce: the multipliers ARE x_b, the Schur row IS x_a.
+// Returns X (rows of B x rows of U); ok[k] = 1 when x_a is empty, i.e. row k has a solution.  Same requirement on U as rref.
+// ------------------------------------------------------------------------------------------------
+struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok)
+{
+    require_device();
+    if (!U || !qinv || !B) throw EngineError("spasm_amd_triangular_solve: null argument");
+    check_input(U, "spasm_amd_triangular_solve");
+    check_input(B, "spasm_amd_triangular_solve");
+    const int r = U->n, m = U->m, nb = B->n;
+    const i64 prime = U->field->p;
+    if (B->m != m || B->field->p != prime) throw EngineError("spasm_amd_triangular_solve: B and U differ in columns or field");
+    std::vector<int> h_qinv_r((size_t)std::max(m, 1), -1), h_pivcol, h_pivrow, h_idx_of_row((size_t)std::max(r, 1), -1);
+    for (int j = 0; j < m; j++) {
+        const int k = qinv[j];
+        if (k >= r) throw EngineError("spasm_amd_triangular_solve: qinv points outside U");
+        if (k < 0) continue;
+        h_qinv_r[(size_t)j] = (int)h_pivcol.size();
+        h_idx_of_row[(size_t)k] = (int)h_pivcol.size();
+        h_pivcol.push_back(j);
+        h_pivrow.push_back(k);
+    }
+    if ((int)h_pivcol.size() != r) throw EngineError("spasm_amd_triangular_solve: qinv does not name one pivot column per row of U");
+    for (int k = 0; k < r; k++) {
+        const int pc = h_pivcol[(size_t)h_idx_of_row[(size_t)k]];
+        bool unit = false;
+        for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
+            if (U->j[q] < pc) throw EngineError("spasm_amd_triangular_solve: the pivot of a row of U must be its leftmost entry");
+            if (U->j[q] == pc && U->x[q] == 1) unit = true;
+        }
+        if (!unit) throw EngineError("spasm_amd_triangular_solve: pivots of U must be 1");
+    }
+    std::vector<i64> xp((size_t)nb + 1, 0);
+    std::vector<int> slen((size_t)std::max(nb, 1), 0);
+    struct spasm_csr *X = nullptr;
+    if (nb > 0 && r > 0) {
+        hipStream_t s = nullptr;
+        DevMat PM, BM;
+        upload_csr(U, 0, r, PM, s);
+        upload_csr(B, 0, nb, BM, s);
+        std::unique_ptr<Round> R(new Round());
+        R->F = zp_field_make(prime);
+        R->stream = s;
+        R->m = m;
+        R->npiv = r;
+        R->nnp = nb;
+        R->qinv_r.alloc((size_t)m + 1);
+        R->pivcol.alloc((size_t)r + 1);
+        R->pivrow.alloc((size_t)r + 1);
+        R->np_rows.alloc((size_t)nb + 1);
+        HIPCHK(hipMemcpyAsync(R->qinv_r.p, h_qinv_r.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(R->pivcol.p, h_pivcol.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(R->pivrow.p, h_pivrow.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(nb, 256)), dim3(256), 0, s, nb, R->np_rows.p);
+        HIPCHK(hipGetLastError());
+        R->build_U(PM, R->pivrow.p);
+        R->prepare_uinv(nb);
+        const i64 tot = R->solve_phase(BM, R->np_rows.p, nullptr, nb, 4 * (spasm_nnz(B) + spasm_nnz(U)));
+        R->S.ent.ensure((size_t)tot + 1);
+        R->run_scatter(BM, R->np_rows.p, nb);
+        R->fetch_counters();
+        DevBuf<i64d> xlen, xstart;
+        xlen.alloc((size_t)nb + 1);
+        xstart.alloc((size_t)nb + 1);
+        hipLaunchKernelGGL(k_xcount, dim3(cdiv(((i64)nb + 1) * 64, 256)), dim3(256), 0, s, nb, R->Lstart.p, R->Llen.p, R->Lpool.p, xlen.p);
+        HIPCHK(hipGetLastError());
+        R->scan.exclusive(xlen.p, xstart.p, (size_t)nb + 1, s);
+        HIPCHK(hipMemcpyAsync(xp.data(), xstart.p, ((size_t)nb + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(slen.data(), R->S.len.p, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const i64 nz = xp[(size_t)nb];
+        X = spasm_csr_alloc(nb, r, nz, prime, true);
+        if (!X) throw EngineError("out of host memory for X");
+        if (nz > 0) {
+            DevBuf<int> oj, ox;
+            oj.alloc((size_t)nz);
+            ox.alloc((size_t)nz);
+            hipLaunchKernelGGL(k_xfill, dim3(cdiv((i64)nb * 64, 256)), dim3(256), 0, s, nb, R->pivrow.p, R->Lstart.p, R->Llen.p, R->Lpool.p, xstart.p,
+                               oj.p, ox.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(X->j, oj.p, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(X->x, ox.p, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        for (int k = 0; k <= nb; k++) X->p[k] = xp[(size_t)k];
+    } else {
+        X = spasm_csr_alloc(nb, r, 0, prime, true);
+        if (!X) throw EngineError("out of host memory for X");
+        for (int k = 0; k <= nb; k++) X->p[k] = 0;
+        for (int k = 0; k < nb; k++) slen[(size_t)k] = (int)(B->p[k + 1] - B->p[k]); // without pivots a row is solvable iff it is zero
+    }
+    if (ok) for (int k = 0; k < nb; k++) ok[k] = slen[(size_t)k] == 0;
+    return X;
+}
+
 // first / step: only the free columns number first, first + step, ... (in ascending column order) get their kernel vector:
 // the unit of the multi-GPU kernel step (free columns are independent)
 struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step = 1)
@@ -2058,6 +2156,17 @@ SPASM_API struct spasm_csr *spasm_amd_kernel_strided(const struct spasm_lu *fact
         return do_kernel(fact, first, step);
     } catch (const std::exception &e) {
         spasm_set_error("spasm_amd_kernel_strided: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API struct spasm_csr *spasm_amd_triangular_solve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok)
+{
+    spasm_clear_error();
+    try {
+        return do_trisolve(U, qinv, B, ok);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_triangular_solve: %s", e.what());
         return nullptr;
     }
 }

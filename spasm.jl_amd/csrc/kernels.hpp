@@ -2068,6 +2068,44 @@ __global__ void k_kfill(int nfree, const int *__restrict__ freecol, const int *_
     }
 }
 
+// X of the batched triangular solve X * U = B: row f = {(row of U of pivot idx, multiplier)}, zero multipliers dropped
+__global__ void k_xcount(int n, const i64d *__restrict__ Lstart, const int *__restrict__ Llen, const int4 *__restrict__ Lpool, i64d *__restrict__ xlen)
+{
+    const int lane = threadIdx.x & 63;
+    const int f = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (f > n) return;
+    if (f == n) { if (lane == 0) xlen[f] = 0; return; }
+    const i64d ls = Lstart[f];
+    const int ll = Llen[f];
+    int cnt = 0;
+    for (int i = lane; i < ll; i += 64) cnt += Lpool[ls + i].y != 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) xlen[f] = (i64d)cnt;
+}
+
+__global__ void k_xfill(int n, const int *__restrict__ rowof, const i64d *__restrict__ Lstart, const int *__restrict__ Llen,
+                        const int4 *__restrict__ Lpool, const i64d *__restrict__ xstart, int *__restrict__ oj, int *__restrict__ ox)
+{
+    const int lane = threadIdx.x & 63;
+    const int f = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (f >= n) return;
+    const i64d ls = Lstart[f];
+    const int ll = Llen[f];
+    i64d pos = xstart[f];
+    for (int i0 = 0; i0 < ll; i0 += 64) {
+        const int i = i0 + lane;
+        int4 r = make_int4(0, 0, 0, 0);
+        if (i < ll) r = Lpool[ls + i];
+        const u64d m = __ballot(r.y != 0);
+        if (r.y != 0) {
+            const i64d at = pos + __popcll(m & lanemask_lt());
+            oj[at] = rowof[r.x];
+            ox[at] = r.y;
+        }
+        pos += __popcll(m);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // multi-GPU exchange of the elected pivot rows: a rank exports the pivot rows it owns,
 // every rank imports the concatenation (rank-major, each part in ascending pivot index)

@@ -288,6 +288,53 @@ def test_rref_is_the_unique_reduced_echelon_form(S, O, n, m, p, density, seed):
     assert S.factorization_verify(A, S.LU.from_parts(S.CSR.from_rows(R.rows(), m, p), rq, np.full(max(n, m), -1, dtype=np.int32)), 1)
 
 
+@pytest.mark.parametrize("n,m,p,seed", [(400, 500, 65521, 1), (300, 360, 127, 2), (350, 420, 2147483647, 3), (200, 260, 0xfffffffb, 4)])
+def test_sparse_triangular_solve_all_rows_at_once(S, O, n, m, p, seed):
+    """sparse_triangular_solve(LU, B) (reference src/SpaSM.jl:725-755, semantics :694-713): X * U == B checked exactly with
+    integers; rows outside the row space are reported unsolvable; the oracle's row-by-row solve gives the same x_b."""
+    A = S.synth_csr(1, n, m, row_nnz=5, prime=p, seed=seed)
+    fact = S.echelonize(A)
+    U, qinv = fact.U, np.asarray(fact.qinv)
+    r = fact.r
+    rng = np.random.default_rng(seed)
+    Urows = U.rows()
+    # B: 40 random combinations of rows of U (solvable) + the rows of A themselves (solvable) + 5 rows pushed outside
+    coeff = [{int(k): int(v) for k, v in zip(rng.choice(r, size=6, replace=False), rng.integers(1, min(p, 1 << 31), size=6))} for _ in range(40)]
+    def combo(cf):
+        acc = {}
+        for k, v in cf.items():
+            for c, x in Urows[k]:
+                acc[c] = (acc.get(c, 0) + v * x) % p
+        return sorted((c, v) for c, v in acc.items() if v)
+    free = [j for j in range(m) if qinv[j] < 0]
+    rowsB = [combo(cf) for cf in coeff] + A.rows()
+    bad = []
+    for t in range(5):
+        row = dict(rowsB[t])
+        row[free[t]] = (row.get(free[t], 0) + 1) % p   # + e_f, f a free column: every vector of the row space leads on a pivot column
+        bad.append(sorted((c, v) for c, v in row.items() if v))
+    B = S.CSR.from_rows(rowsB + bad, m, p)
+    X, ok = S.api._triangular_solve(U, B, qinv)
+    assert X.shape == (B.n, r)
+    Xrows = X.rows()
+    for kk in range(B.n):
+        acc = {}
+        for k, v in Xrows[kk]:
+            for c, x in Urows[k]:
+                acc[c] = (acc.get(c, 0) + v * x) % p
+        got = {c: v for c, v in acc.items() if v}
+        target = {c: v % p for c, v in (rowsB + bad)[kk]}
+        if ok[kk]:
+            assert got == target                              # X[k] * U == B[k] exactly
+        else:
+            assert got != target
+    assert ok[: len(rowsB)].all() and not ok[len(rowsB):].any()
+    for t, cf in enumerate(coeff):                             # the combination is recovered (U's rows are independent)
+        assert {k: v % p for k, v in Xrows[t]} == {k: v % p for k, v in cf.items()}
+    assert S.sparse_triangular_solve(fact, S.CSR.from_rows(rowsB, m, p)) is not None
+    assert S.sparse_triangular_solve(fact, B) is None
+
+
 def test_kernel_of_a_strided_subset_of_the_free_columns(S):
     """spasm_amd_kernel_strided (the multi-GPU kernel step): vectors first, first + step, ... of the whole basis."""
     A = S.synth_csr(0, 900, 1100, density=4e-3, prime=42013, seed=0xFEED)
