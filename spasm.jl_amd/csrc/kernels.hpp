@@ -908,9 +908,9 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
     STAMP(0); // prologue
     for (int w = first; w < count; w += stride) {
         // (A) prefetch the descriptor two rows ahead (vector load; unpacked to SGPRs at the end of the iteration)
-        DescRegs dnn_regs;
-        const bool has_nn = w + 2 * stride < count;
-        if (has_nn) dnn_regs = desc_load(&a.desc[w + 2 * stride]);
+        // unconditional, clamped to the last descriptor: a load under `if` made the compiler wait for it on the spot and copy
+        // its 12 registers into the merged variable -- a full global-load latency at the top of every row
+        const DescRegs dnn_regs = desc_load(&a.desc[min(w + 2 * stride, count - 1)]);
         // (B) every load of the current row: qinv of the own entry, entries of the pivot rows
         const int ln = d.len, ll = d.llen;
         int q_own = 0;
@@ -1000,13 +1000,12 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         // (A') stage-1 data of the NEXT row (its own entries and multiplier records) straight into the pipeline
         // registers, which are dead from here on: these loads fly during the sweep
         const int ln_cur = ln;
-        own = make_int2(0, 0);
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) rec[r] = make_int4(0, 0, 0, 0);
-        if (w + stride < count) {
-            if (rtid < dn.len) own = a.ent[dn.ent_start + rtid];
-            // clamped like the pivot-row loads: groups past the end of the list re-read its last record (or Lpool[0] for an
-            // empty list) and are masked out by the test against llen when the record is used
+        {
+            // UNCONDITIONAL and clamped (lanes past the end of the row / groups past the end of the list re-read the last
+            // entry / record and are masked out where the data is used; after the last row `dn` is the last descriptor
+            // again).  Under an `if` the compiler loaded into temporaries, waited for them on the spot and copied them into
+            // the pipeline registers: the latency these prefetches are meant to hide was paid in full before the sweep.
+            own = a.ent[dn.ent_start + min(rtid, max(dn.len - 1, 0))];
             const int lastrec = max(dn.llen - 1, 0);
 #pragma unroll
             for (int r = 0; r < MAXR; r++) rec[r] = a.Lpool[dn.l_start + min(gg + r * NG, lastrec)];
@@ -1131,7 +1130,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         STAMP(6); // prefetch issue + sweep + stores
         // rotate the pipeline
         d = dn;
-        if (has_nn) dn = desc_unpack(dnn_regs);
+        dn = desc_unpack(dnn_regs); // (beyond the last row this is the last descriptor again: never used)
     }
 #ifdef SPASM_STAMPS
     if (lane == 0 && a.stamps) {
