@@ -1618,9 +1618,10 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
             // the two prefetched batches: both column-record gathers in flight together
             const bool va = tl < ln, vb = tl + TEAM < ln;
             int4 ci_a = make_int4(-1, 0, 0, 0), ci_b = ci_a;
-            bool pa = false, pb = false;
-            if (va) pa = (a.pbits[(unsigned)own_a.x >> 5] >> (own_a.x & 31)) & 1u;
-            if (vb) pb = (a.pbits[(unsigned)own_b.x >> 5] >> (own_b.x & 31)) & 1u;
+            // both bitmap words requested before either is used (lanes without an entry hold column 0: word 0 is always there);
+            // under separate `if`s the second load was issued only after the first had returned
+            const unsigned wa = a.pbits[(unsigned)own_a.x >> 5], wb = a.pbits[(unsigned)own_b.x >> 5];
+            const bool pa = va && ((wa >> (own_a.x & 31)) & 1u), pb = vb && ((wb >> (own_b.x & 31)) & 1u);
             if (pa) ci_a = a.colinfo[own_a.x];
             if (pb) ci_b = a.colinfo[own_b.x];
             {
