@@ -164,13 +164,13 @@ def main():
 
     if rank == 0:
         # dominant kernel: the scatter launch of the busiest class (HIP events on the launch stream, last step)
-        cls = max(range(8), key=lambda c: d["ms_class"][c])
+        cls = max(range(16), key=lambda c: d["ms_class"][c])
         k_bytes = 8 * d["ent_class"][cls] + 16 * d["seg_class"][cls]
         k_ms = d["ms_class"][cls]
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # HBM traffic of that kernel from the PMC counters (collected in separate rocprofv3 passes and calibrated for
         # this access shape, profiles/r01_final_traffic.json); only quoted for the workload it was measured on
-        prefix = SCATTER_KERNEL_PREFIX[cls] if args.prime < 65536 else None
+        prefix = SCATTER_KERNEL_PREFIX[cls] if (args.prime < 65536 and cls < 8) else None
         traffic = None
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")))["kernels"]
@@ -182,7 +182,7 @@ def main():
             pass
         roofline = {
             "bound": "hbm",
-            "kernel": f"k_scatter class {cls} ({d['rows_class'][cls]} rows)",
+            "kernel": (f"k_stream class {cls - 8}" if cls >= 8 else f"k_scatter class {cls}") + f" ({d['rows_class'][cls]} rows)",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -193,7 +193,9 @@ def main():
             "round_algorithmic_read_GBs": round(d["read_bytes"] / ((d["ms_solve"] + d["ms_scatter"]) * 1e-3) / 1e9, 1)
             if (d["ms_solve"] + d["ms_scatter"]) > 0 else None,
             "round_ms": {"solve": round(d["ms_solve"], 4), "scatter": round(d["ms_scatter"], 4)},
-            "per_class_ms": [round(x, 4) for x in d["ms_class"][:6]],
+            "per_class_ms": {"hash": [round(x, 4) for x in d["ms_class"][:8]], "stream": [round(x, 4) for x in d["ms_class"][8:15]]},
+            "per_class_rows": {"hash": d["rows_class"][:8], "stream": d["rows_class"][8:15]},
+            "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"],
         }
         out = {
             "metric": "Schur nnz reduced/sec (GF(p) echelonize), 1Mx1M CSR",

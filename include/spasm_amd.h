@@ -159,12 +159,16 @@ struct spasm_amd_round_stats {
     double ms_solve;      /* device time, triangular-solve kernel (multipliers) */
     double ms_scatter;    /* device time, scatter/accumulate kernel (Schur rows) */
     double ms_total;
-    /* scatter kernel, per hash-table class (one launch each): device time, rows, entries streamed
-     * (the row's own entries + the non-pivot part of every applied pivot row) and row segments visited */
-    double ms_class[8];
-    int rows_class[8];
-    i64 ent_class[8];
-    i64 seg_class[8];
+    /* scatter kernels, per size class (one launch each): device time, rows, entries streamed (the row's own
+     * entries + the non-pivot part of every applied pivot row) and row segments visited.  Classes 0..6: LDS hash
+     * tables of 256..16384 slots, 7: the global-memory last resort, 8..14: the streaming twins of 0..6 (rows whose
+     * entries are written out directly; a row with too many duplicate columns is redone by its hash class) */
+    double ms_class[16];
+    int rows_class[16];
+    i64 ent_class[16];
+    i64 seg_class[16];
+    i64 stream_fix;       /* duplicate columns the streaming kernels merged after the fact */
+    i64 stream_redo;      /* rows the streaming kernels handed back to the hash-table kernels */
 };
 
 typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;

@@ -85,10 +85,12 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
         ("ms_solve", C.c_double),
         ("ms_scatter", C.c_double),
         ("ms_total", C.c_double),
-        ("ms_class", C.c_double * 8),
-        ("rows_class", C.c_int32 * 8),
-        ("ent_class", C.c_int64 * 8),
-        ("seg_class", C.c_int64 * 8),
+        ("ms_class", C.c_double * 16),
+        ("rows_class", C.c_int32 * 16),
+        ("ent_class", C.c_int64 * 16),
+        ("seg_class", C.c_int64 * 16),
+        ("stream_fix", C.c_int64),
+        ("stream_redo", C.c_int64),
     ]
 
     def as_dict(self):

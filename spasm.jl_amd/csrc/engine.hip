@@ -6,6 +6,7 @@
 // the rank come back.  There is NO CPU fallback: without a HIP device these entry points fail.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "stream.hpp"
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 #include <vector>
@@ -130,6 +131,32 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
     }
 }
 
+template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW = 1> void launch_stream(const StreamArgs &a, int grid, size_t lds, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_stream<LOGT, TPR, WPB, MAXR, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_stream<LOGT, TPR, WPB, MAXR, SMALL, MINW>), dim3(grid), dim3(WPB * 64), lds, s, a);
+    HIPCHK(hipGetLastError());
+}
+
+// the streaming twins of the hash-table classes: same table sizes (the 8-byte slot is {column, position}), same geometry
+template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int grid, size_t lds, hipStream_t s)
+{
+    switch (cls) {
+    case 0: launch_stream<8, 64, 4, 1, SMALL>(a, grid, lds, s); break;
+    case 1: launch_stream<9, 64, 4, 2, SMALL>(a, grid, lds, s); break;
+    case 2: launch_stream<10, 64, 4, 4, SMALL, 4>(a, grid, lds, s); break;
+    case 3: launch_stream<11, 128, 2, 4, SMALL, 4>(a, grid, lds, s); break;
+    case 4: launch_stream<12, 256, 4, 4, SMALL, 4>(a, grid, lds, s); break;
+    case 5: launch_stream<13, 256, 4, 5, SMALL>(a, grid, lds, s); break;
+    case 6: launch_stream<14, 256, 4, 5, SMALL>(a, grid, lds, s); break;
+    default: break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // One echelonization round on one device.
 // ------------------------------------------------------------------------------------------------
@@ -162,6 +189,10 @@ struct Round {
     i64 uinv_nnz = 0;
     // solve
     DevBuf<int4> Lpool;
+    DevBuf<int> Lidx;               // pivot index of every record (only when want_idx: kernel basis, triangular solve)
+    bool want_idx = false;
+    DevBuf<int> sflag;              // per row slot: the streaming scatter may take the row
+    bool use_stream = true;         // SPASM_AMD_STREAM=0 turns the streaming scatter off
     DevBuf<u64d> pool_ctr;          // NPOOL sharded bump counters
     int npool_active = NPOOL;       // regions in use by the current solve
     u64d region_cap = 0;
@@ -192,7 +223,9 @@ struct Round {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t side = nullptr;     // the few rows of the largest table classes run beside the others
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_cls[NCLASS + 1];
+    hipEvent_t ev_cls[NCLASS + 1];  // one in front of every scatter launch (class_timing) and one behind the last
+    int launch_cls[NCLASS];         // class id of launch i
+    int nlaunch = 0;
     int hclass_count[NCLASS];
     int nhash_used = 0;
     bool class_timing = true;       // record an event pair around every scatter class (costs a few microseconds of gap each)
@@ -203,6 +236,8 @@ struct Round {
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
         for (auto &e : ev_cls) { e = nullptr; HIPCHK(hipEventCreate(&e)); }
         memset(hclass_count, 0, sizeof hclass_count);
+        memset(launch_cls, 0, sizeof launch_cls);
+        if (const char *e = getenv("SPASM_AMD_STREAM")) use_stream = atoi(e) != 0;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
@@ -309,9 +344,11 @@ struct Round {
         fail_list.ensure((size_t)nrows + 1);
         overflow2_list.ensure((size_t)nrows + 1);
         pmask.ensure((size_t)nrows + 1);
+        sflag.ensure((size_t)nrows + 1);
         npool_active = std::min(NPOOL, std::max(1, nrows / 4));
         region_cap = ((u64d)lpool_entries + npool_active - 1) / npool_active;
         Lpool.ensure((size_t)(region_cap * npool_active) + 1);
+        if (want_idx) Lidx.ensure((size_t)(region_cap * npool_active) + 1);
         pool_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
         alloc_big();
         ctr.ensure(NCTR);
@@ -436,6 +473,7 @@ struct Round {
             a.uhdr = uhdr.p;
             a.UPP = UPP.p;
             a.Lpool = nullptr;
+            a.Lidx = nullptr;
             a.Lpool2 = UinvPool.p;
             a.lpool_cap = ucap;
             a.pool_ctr = pool_ctr.p;
@@ -501,7 +539,7 @@ struct Round {
             const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), npool_words = NPOOL * POOL_STRIDE;
             const int span = std::max(std::max(nctr_words, npool_words), nrows + 1);
             hipLaunchKernelGGL(k_solve_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, nrows, (unsigned *)ctr.p, nctr_words, pool_ctr.p,
-                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p);
+                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p, sflag.p);
             HIPCHK(hipGetLastError());
         }
         if (nrows == 0) return;
@@ -518,6 +556,7 @@ struct Round {
         a.uhdr = uhdr.p;
         a.UPP = UPP.p;
         a.Lpool = Lpool.p;
+        a.Lidx = want_idx ? Lidx.p : nullptr;
         a.Lpool2 = nullptr;
         a.lpool_cap = region_cap;
         a.pool_ctr = pool_ctr.p;
@@ -546,6 +585,8 @@ struct Round {
             c.uhdr = uhdr.p;
             c.UinvPool = UinvPool.p;
             c.Lpool = Lpool.p;
+            c.Lidx = want_idx ? Lidx.p : nullptr;
+            c.sflag = sflag.p;
             c.lpool_cap = region_cap;
             c.pool_ctr = pool_ctr.p;
             c.npool = npool_active;
@@ -603,7 +644,9 @@ struct Round {
             c.scatter_overflow += h[i].scatter_overflow;
             c.nonempty_out += h[i].nonempty_out;
             c.nnz_out += h[i].nnz_out;
-            for (int k = 0; k < 8; k++) { c.class_ent[k] += h[i].class_ent[k]; c.class_seg[k] += h[i].class_seg[k]; }
+            c.stream_redo += h[i].stream_redo;
+            c.stream_fix += h[i].stream_fix;
+            for (int k = 0; k < 16; k++) { c.class_ent[k] += h[i].class_ent[k]; c.class_seg[k] += h[i].class_seg[k]; }
         }
         return c;
     }
@@ -659,16 +702,18 @@ struct Round {
     {
         S.n = nrows;
         S.m = m;
+        nlaunch = 0;
         if (nrows == 0) return;
         HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
+        int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1; // 12-byte slots: the 2^14 table exceeds LDS
+        const bool streaming = use_stream && use_uinv; // the stream positions come from the combine kernel
         BinArgs b;
         b.nrows = nrows;
         b.bound = bound.p;
         b.Llen = Llen.p;
         for (int c = 0; c < NCLASS; c++) b.cap[c] = -1;
-        int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1; // 12-byte slots: the 2^14 table exceeds LDS
         for (int c = 0; c < nhash; c++) b.cap[c] = kClasses[c].cap;
-        // classes nhash..NCLASS-2 are unused (cap -1 never matches); the last class collects what fits nowhere
+        // classes nhash..NHASHMAX-2 are unused (cap -1 never matches); class NHASHMAX-1 collects what fits nowhere
         b.class_count = class_count.p;
         b.class_list = class_list.p;
         b.rows = rows;
@@ -678,6 +723,9 @@ struct Round {
         b.Lstart = Lstart.p;
         b.sstart = sstart.p;
         b.pmask = pmask.p;
+        b.sflag = sflag.p;
+        b.stream_classes = streaming ? nhash : 0;
+        b.Sorig = S.orig.p;
         b.desc = class_desc.p;
         hipLaunchKernelGGL(k_bin, dim3(cdiv(nrows, 1024)), dim3(256), 0, stream, b);
         HIPCHK(hipGetLastError());
@@ -691,7 +739,6 @@ struct Round {
         a.Sent = S.ent.p;
         a.Slen = S.len.p;
         a.Slead = S.lead.p;
-        a.Sorig = S.orig.p;
         a.ctr = ctr.p;
         a.F = F;
         {
@@ -704,6 +751,17 @@ struct Round {
         HIPCHK(hipMemsetAsync(stamps.p, 0, NCLASS * 2 * NSTAMP * sizeof(u64d), stream));
         a.stamps = stamps.p;
 #endif
+        StreamArgs sa;
+        sa.ent = M.ent.p;
+        sa.qinv_r = qinv_r.p;
+        sa.UPN = UPN.p;
+        sa.Lpool = Lpool.p;
+        sa.Sent = S.ent.p;
+        sa.Slen = S.len.p;
+        sa.Slead = S.lead.p;
+        sa.ctr = ctr.p;
+        sa.F = F;
+        sa.dbg = a.dbg;
         nhash_used = nhash;
         // The classes with the largest tables hold few rows (config 3: 7829 and 51 of 830527), each a long serial job of one
         // workgroup: launched after the others they are a tail on a nearly empty chip (0.27 of 4.1 ms; 74 of 760 us for a
@@ -719,7 +777,13 @@ struct Round {
             HIPCHK(hipEventRecord(ev_fork, stream));
             HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
         }
+        auto mark = [&](int cls_id, hipStream_t s) { // event in front of a launch, for the per-class times
+            if (!class_timing || nlaunch >= NCLASS) return;
+            HIPCHK(hipEventRecord(ev_cls[nlaunch], s));
+            launch_cls[nlaunch++] = cls_id;
+        };
         auto launch_class = [&](int c, hipStream_t s) {
+            mark(c, s);
             a.cls = c;
             a.class_count = class_count.p + c;
             a.desc = class_desc.p + (size_t)c * nrows;
@@ -730,6 +794,23 @@ struct Round {
             const int grid = std::max(1, std::min(cdiv(nrows, rows_per_block), num_cu * per_cu));
             if (F.small) launch_scatter_class<true>(c, a, grid, lds, s);
             else launch_scatter_class<false>(c, a, grid, lds, s);
+        };
+        // the streaming twin of hash class c; rows it gives up on land in class c's list, which therefore runs after it
+        auto launch_stream_cls = [&](int c, hipStream_t s) {
+            if (!streaming) return;
+            mark(NSTREAM0 + c, s);
+            sa.cls = NSTREAM0 + c;
+            sa.class_count = class_count.p + NSTREAM0 + c;
+            sa.desc = class_desc.p + (size_t)(NSTREAM0 + c) * nrows;
+            sa.redo_count = class_count.p + c;
+            sa.redo_desc = class_desc.p + (size_t)c * nrows;
+            const size_t lds = stream_lds_bytes(kClasses[c].logt, kClasses[c].tpr, kClasses[c].wpb);
+            int per_cu = (int)std::min<size_t>(32 / kClasses[c].wpb, (160 * 1024) / lds);
+            if (per_cu < 1) per_cu = 1;
+            const int rows_per_block = kClasses[c].tpr == 64 ? kClasses[c].wpb : 1;
+            const int grid = std::max(1, std::min(cdiv(nrows, rows_per_block), num_cu * per_cu));
+            if (F.small) launch_stream_class<true>(c, sa, grid, lds, s);
+            else launch_stream_class<false>(c, sa, grid, lds, s);
         };
         auto launch_big = [&](hipStream_t s) {
             // rows that fit no LDS table: the last class, through the global-memory kernel
@@ -744,11 +825,12 @@ struct Round {
                 sc_xdense.zero(s);
                 sc_bitmap.zero(s);
             }
+            mark(NHASHMAX - 1, s);
             BigScatterArgs bb;
             bb.s = a;
-            bb.s.cls = NCLASS - 1;
-            bb.s.class_count = class_count.p + (NCLASS - 1);
-            bb.s.desc = class_desc.p + (size_t)(NCLASS - 1) * nrows;
+            bb.s.cls = NHASHMAX - 1;
+            bb.s.class_count = class_count.p + (NHASHMAX - 1);
+            bb.s.desc = class_desc.p + (size_t)(NHASHMAX - 1) * nrows;
             bb.m = std::max(m, 1);
             bb.nwords = (std::max(m, 1) + 31) / 32;
             bb.xdense = sc_xdense.p;
@@ -758,18 +840,17 @@ struct Round {
             HIPCHK(hipGetLastError());
         };
         if (use_side) {
-            for (int c = nhash - 1; c >= first_side; c--) launch_class(c, side); // longest rows first
+            for (int c = nhash - 1; c >= first_side; c--) { launch_stream_cls(c, side); launch_class(c, side); } // longest rows first
             launch_big(side);
             HIPCHK(hipEventRecord(ev_join, side));
+            for (int c = 0; c < first_side; c++) launch_stream_cls(c, stream);
             for (int c = 0; c < first_side; c++) launch_class(c, stream);
             HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
         } else {
-            for (int c = 0; c < nhash; c++) {
-                if (class_timing) HIPCHK(hipEventRecord(ev_cls[c], stream));
-                launch_class(c, stream);
-            }
-            if (class_timing) HIPCHK(hipEventRecord(ev_cls[nhash], stream));
+            for (int c = 0; c < nhash; c++) launch_stream_cls(c, stream);
+            for (int c = 0; c < nhash; c++) launch_class(c, stream);
             launch_big(stream);
+            if (class_timing) HIPCHK(hipEventRecord(ev_cls[nlaunch], stream));
         }
         hipLaunchKernelGGL(k_scatter_mark_failed, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, Llen.p, S.len.p, S.lead.p);
         HIPCHK(hipGetLastError());
@@ -831,7 +912,8 @@ void upload_csr(const struct spasm_csr *A, int row_lo, int row_hi, DevMat &M, hi
     if (nnz > 0) {
         HIPCHK(hipMemcpyAsync(dj.p, A->j + base, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
         if (A->x) HIPCHK(hipMemcpyAsync(dx.p, A->x + base, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_pack_entries, dim3(std::min<i64>(cdiv(nnz, 256), 65536)), dim3(256), 0, s, (i64d)nnz, dj.p, A->x ? dx.p : nullptr, M.ent.p);
+        hipLaunchKernelGGL(k_pack_entries, dim3(std::min<i64>(cdiv(nnz, 256), 65536)), dim3(256), 0, s, (i64d)nnz, zp_field_make(A->field->p), dj.p,
+                           A->x ? dx.p : nullptr, M.ent.p);
         HIPCHK(hipGetLastError());
     }
     if (n > 0) {
@@ -875,7 +957,8 @@ void upload_csr_strided(const struct spasm_csr *A, int row_lo, int row_hi, int s
     if (nnz > 0) {
         HIPCHK(hipMemcpyAsync(dj.p, hj.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
         if (A->x) HIPCHK(hipMemcpyAsync(dx.p, hx.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_pack_entries, dim3(std::min<i64>(cdiv(nnz, 256), 65536)), dim3(256), 0, s, (i64d)nnz, dj.p, A->x ? dx.p : nullptr, M.ent.p);
+        hipLaunchKernelGGL(k_pack_entries, dim3(std::min<i64>(cdiv(nnz, 256), 65536)), dim3(256), 0, s, (i64d)nnz, zp_field_make(A->field->p), dj.p,
+                           A->x ? dx.p : nullptr, M.ent.p);
         HIPCHK(hipGetLastError());
     }
     if (n > 0) {
@@ -924,12 +1007,15 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     if (hipEventElapsedTime(&ms, R.ev[1], R.ev[2]) == hipSuccess) st.ms_solve = ms;
     if (hipEventElapsedTime(&ms, R.ev[2], R.ev[3]) == hipSuccess) st.ms_scatter = ms;
     if (hipEventElapsedTime(&ms, R.ev[0], R.ev[3]) == hipSuccess) st.ms_total = ms;
-    for (int c = 0; c < R.nhash_used && c < 8; c++) {
-        if (R.class_timing && hipEventElapsedTime(&ms, R.ev_cls[c], R.ev_cls[c + 1]) == hipSuccess) st.ms_class[c] = ms;
+    for (int i = 0; i < R.nlaunch; i++)
+        if (R.class_timing && hipEventElapsedTime(&ms, R.ev_cls[i], R.ev_cls[i + 1]) == hipSuccess) st.ms_class[R.launch_cls[i]] = ms;
+    for (int c = 0; c < NCLASS; c++) {
         st.rows_class[c] = R.hclass_count[c];
         st.ent_class[c] = (i64)R.hctr.class_ent[c];
         st.seg_class[c] = (i64)R.hctr.class_seg[c];
     }
+    st.stream_fix = R.hctr.stream_fix;
+    st.stream_redo = R.hctr.stream_redo;
 }
 
 struct HostU {
@@ -1220,7 +1306,9 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
             acc.segments += R->hctr.segments;
             acc.nonempty_out += R->hctr.nonempty_out;
             acc.nnz_out += R->hctr.nnz_out;
-            for (int c = 0; c < 8; c++) { acc.class_ent[c] += R->hctr.class_ent[c]; acc.class_seg[c] += R->hctr.class_seg[c]; }
+            acc.stream_fix += R->hctr.stream_fix;
+            acc.stream_redo += R->hctr.stream_redo;
+            for (int c = 0; c < 16; c++) { acc.class_ent[c] += R->hctr.class_ent[c]; acc.class_seg[c] += R->hctr.class_seg[c]; }
             for (int c = 0; c < NCLASS; c++) acc_class[c] += R->hclass_count[c];
             nbatch++;
             if (off == 0 && cnt == nnp) {
@@ -1270,7 +1358,9 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         R->hctr.segments = acc.segments;
         R->hctr.nonempty_out = acc.nonempty_out;
         R->hctr.nnz_out = acc.nnz_out;
-        for (int c = 0; c < 8; c++) { R->hctr.class_ent[c] = acc.class_ent[c]; R->hctr.class_seg[c] = acc.class_seg[c]; }
+        R->hctr.stream_fix = acc.stream_fix;
+        R->hctr.stream_redo = acc.stream_redo;
+        for (int c = 0; c < 16; c++) { R->hctr.class_ent[c] = acc.class_ent[c]; R->hctr.class_seg[c] = acc.class_seg[c]; }
         for (int c = 0; c < NCLASS; c++) R->hclass_count[c] = acc_class[c];
         append_round_U(U, *R, *cur, stream);
 
@@ -1583,6 +1673,7 @@ struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const 
         HIPCHK(hipMemcpyAsync(R->pivrow.p, h_pivrow.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_iota, dim3(cdiv(nb, 256)), dim3(256), 0, s, nb, R->np_rows.p);
         HIPCHK(hipGetLastError());
+        R->want_idx = true; // X is assembled from (pivot index, multiplier)
         R->build_U(PM, R->pivrow.p);
         R->prepare_uinv(nb);
         const i64 tot = R->solve_phase(BM, R->np_rows.p, nullptr, nb, 4 * (spasm_nnz(B) + spasm_nnz(U)));
@@ -1605,7 +1696,7 @@ struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const 
             DevBuf<int> oj, ox;
             oj.alloc((size_t)nz);
             ox.alloc((size_t)nz);
-            hipLaunchKernelGGL(k_xfill, dim3(cdiv((i64)nb * 64, 256)), dim3(256), 0, s, nb, R->pivrow.p, R->Lstart.p, R->Llen.p, R->Lpool.p, xstart.p,
+            hipLaunchKernelGGL(k_xfill, dim3(cdiv((i64)nb * 64, 256)), dim3(256), 0, s, nb, R->pivrow.p, R->Lstart.p, R->Llen.p, R->Lpool.p, R->Lidx.p, xstart.p,
                                oj.p, ox.p);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(X->j, oj.p, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1751,6 +1842,7 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
         hipLaunchKernelGGL(k_iota, dim3(cdiv(r, 256)), dim3(256), 0, s, r, R->pivcol.p);
         HIPCHK(hipGetLastError());
     }
+    R->want_idx = true; // the kernel vectors are assembled from (pivot index, multiplier)
     R->build_U(T, rowsrc.p);
     R->prepare_uinv(nfree);
     R->solve_phase(T, freecol.p, nullptr, nfree, 4 * spasm_nnz(U));
@@ -1767,7 +1859,7 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
     DevBuf<int2> Kent;
     Kent.alloc((size_t)ktot + 1);
     if (nfree > 0) {
-        hipLaunchKernelGGL(k_kfill, dim3(cdiv((i64)nfree * 64, 256)), dim3(256), 0, s, nfree, freecol.p, rowsrc.p, R->Lstart.p, R->Llen.p, R->Lpool.p,
+        hipLaunchKernelGGL(k_kfill, dim3(cdiv((i64)nfree * 64, 256)), dim3(256), 0, s, nfree, freecol.p, rowsrc.p, R->Lstart.p, R->Llen.p, R->Lpool.p, R->Lidx.p,
                            kstart.p, Kent.p);
         HIPCHK(hipGetLastError());
     }

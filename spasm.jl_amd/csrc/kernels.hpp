@@ -63,8 +63,10 @@ struct RoundCounters {
     int scatter_overflow;// rows whose bound exceeds the largest hash table class
     int nonempty_out;    // non-empty Schur rows
     u64d nnz_out;        // entries of the Schur complement
-    u64d class_ent[8];   // scatter kernel, per class: entries streamed
-    u64d class_seg[8];   // scatter kernel, per class: row segments visited
+    u64d class_ent[16];  // scatter kernels, per class (0..7 hash tables + last resort, 8..15 streaming): entries streamed
+    u64d class_seg[16];  // scatter kernels, per class: row segments visited
+    int stream_redo;     // rows the streaming kernel handed back to the hash-table kernel (too many duplicate columns)
+    int stream_fix;      // duplicate columns the streaming kernel merged after the fact
 };
 
 // bump allocation of n entries from the region of this workgroup; returns the absolute offset in the pool,
@@ -111,14 +113,45 @@ __device__ __forceinline__ int wave_min_i32(int x)
 
 __device__ __forceinline__ u64d lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
+// inclusive prefix sum over the TEAM lanes of a team (TEAM = 16: one DPP row; TEAM = 64: the wave) and the team's total in every
+// lane, without LDS: DPP row shifts (lanes shifted in from outside the row read 0), rotations for the total
+template <int TEAM> __device__ __forceinline__ int team_incl_scan(int x, int &total);
+template <> __device__ __forceinline__ int team_incl_scan<16>(int x, int &total)
+{
+    int t = x;
+    t += __builtin_amdgcn_update_dpp(0, t, 0x128, 0xf, 0xf, false); // row_ror:8
+    t += __builtin_amdgcn_update_dpp(0, t, 0x124, 0xf, 0xf, false); // row_ror:4
+    t += __builtin_amdgcn_update_dpp(0, t, 0x122, 0xf, 0xf, false); // row_ror:2
+    t += __builtin_amdgcn_update_dpp(0, t, 0x121, 0xf, 0xf, false); // row_ror:1
+    total = t;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); // row_shr:8
+    return x;
+}
+template <> __device__ __forceinline__ int team_incl_scan<64>(int x, int &total)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2,3
+    total = __builtin_amdgcn_readlane(x, 63);
+    return x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // ingest: host-style CSR arrays (p,j,x) -> (start,len,ent)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pack_entries(i64d nnz, const int *__restrict__ j, const int *__restrict__ x, int2 *__restrict__ ent)
+// values are brought to the canonical balanced residue here, once: the kernels downstream rely on it (the streaming scatter
+// writes an own entry as it stands; reference src/SpaSM.jl:955-958 builds CSRs that way, but a C caller may not)
+__global__ void k_pack_entries(i64d nnz, ZpField F, const int *__restrict__ j, const int *__restrict__ x, int2 *__restrict__ ent)
 {
     i64d k = (i64d)blockIdx.x * blockDim.x + threadIdx.x;
     const i64d stride = (i64d)gridDim.x * blockDim.x;
-    for (; k < nnz; k += stride) ent[k] = make_int2(j[k], x ? x[k] : 1);
+    for (; k < nnz; k += stride) ent[k] = make_int2(j[k], x ? zp_reduce(F, (int64_t)x[k]) : 1);
 }
 
 // local row i of a shard is global row row_lo + i * row_stride (stride 1: a contiguous block; stride G: every G-th row,
@@ -308,7 +341,9 @@ struct SolveArgs {
     const int *qinv_r;
     const UHdr *uhdr;
     const int2 *UPP;
-    int4 *Lpool;               // multiplier records {pivot index, multiplier, offset of the pivot row in UPN, npn}
+    int4 *Lpool;               // multiplier records {stream position of the pivot row's entries (combine kernel only), multiplier,
+                               // offset of the pivot row in UPN, npn}
+    int *Lidx;                 // when non-NULL: pivot index of every record (kernel basis, triangular solve, L factor)
     int2 *Lpool2;              // when non-NULL the list is published as {pivot index, value} instead (rows of Uinv)
     u64d lpool_cap;            // entries per pool region
     u64d *pool_ctr;            // NPOOL bump counters, POOL_STRIDE words apart
@@ -454,7 +489,8 @@ __global__ __launch_bounds__(TPB) void k_solve(SolveArgs a)
                         const int kk = key[i], vv = val[i];
                         UHdr h; h.off = 0; h.npn = 0;
                         if (vv != 0) h = a.uhdr[kk];
-                        a.Lpool[base + i] = make_int4(kk, vv, (int)h.off, h.npn);
+                        a.Lpool[base + i] = make_int4(0, vv, (int)h.off, h.npn);
+                        if (a.Lidx) a.Lidx[base + i] = kk;
                     }
                 }
                 if (tl == 0) {
@@ -482,7 +518,9 @@ __global__ __launch_bounds__(TPB) void k_solve(SolveArgs a)
 // ------------------------------------------------------------------------------------------------
 // binning of rows by the size of the hash table their Schur row needs
 // ------------------------------------------------------------------------------------------------
-#define NCLASS 8
+#define NCLASS 16
+#define NHASHMAX 8     // classes 0..6: LDS hash tables, 7: the global-memory last resort
+#define NSTREAM0 8     // classes 8..14: the streaming twins of classes 0..6
 // everything the scatter kernel needs to know about one row, gathered once by the binning pass so that the
 // kernel's per-row dependent-load chain is: descriptor (prefetched) -> multiplier records -> pivot row entries
 struct __attribute__((aligned(16))) RowDesc {
@@ -492,7 +530,7 @@ struct __attribute__((aligned(16))) RowDesc {
     int len;
     int llen;
     int t;            // row slot (index of the Schur row)
-    int orig;
+    int bound;        // bound of the Schur row = length of the row's entry stream (streaming kernel: exactly nN + sum npn)
     long long pmask;  // bit k set <=> own entry k sits on a pivot column (from the solve kernel); < 0: not available
 };
 
@@ -519,7 +557,7 @@ __device__ __forceinline__ RowDesc desc_unpack(const DescRegs &r)
     d.len = __builtin_amdgcn_readfirstlane(r.b.z);
     d.llen = __builtin_amdgcn_readfirstlane(r.b.w);
     d.t = __builtin_amdgcn_readfirstlane(r.c.x);
-    d.orig = __builtin_amdgcn_readfirstlane(r.c.y);
+    d.bound = __builtin_amdgcn_readfirstlane(r.c.y);
     d.pmask = (long long)(((u64d)(unsigned)__builtin_amdgcn_readfirstlane(r.c.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(r.c.z));
     return d;
 }
@@ -535,6 +573,9 @@ struct BinArgs {
     const i64d *Lstart;
     const i64d *sstart;
     const long long *pmask;  // per row slot, from the solve kernel (NULL: none)
+    const int *sflag;        // per row slot: 1 = the records carry stream positions and the bound is exact (streaming kernel)
+    int stream_classes;      // hash classes 0..stream_classes-1 have a streaming twin (class + NSTREAM0); 0 = streaming off
+    int *Sorig;              // out: originating row of every row slot
     RowDesc *desc;           // [NCLASS][nrows]
     i64d cap[NCLASS];        // class c takes rows with bound <= cap[c]; the last class takes the rest
     int *class_count;        // [NCLASS]
@@ -557,8 +598,9 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a)
         pos[i] = 0;
         if (t < a.nrows && a.Llen[t] >= 0) {
             const i64d b = a.bound[t];
-            int c = NCLASS - 1;
-            for (int k = NCLASS - 2; k >= 0; k--) if (b <= a.cap[k]) c = k;
+            int c = NHASHMAX - 1;
+            for (int k = NHASHMAX - 2; k >= 0; k--) if (b <= a.cap[k]) c = k;
+            if (c < a.stream_classes && a.sflag && a.sflag[t]) c += NSTREAM0;
             cls[i] = c;
             pos[i] = atomicAdd(&s_cnt[c], 1);
         }
@@ -580,10 +622,15 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a)
             d.len = a.len[row];
             d.llen = a.Llen[t];
             d.t = t;
-            d.orig = a.orig[row];
+            d.bound = (int)(a.bound[t] < (i64d)INT_MAX ? a.bound[t] : (i64d)INT_MAX);
             d.pmask = a.pmask ? a.pmask[t] : -1;
             a.desc[slot] = d;
         }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int t = base + i * 256 + threadIdx.x;
+        if (t < a.nrows) a.Sorig[t] = a.orig[a.rows ? a.rows[t] : t];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -890,7 +937,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
 #endif
     // ---- pipeline registers
     RowDesc d, dn;
-    d.ent_start = d.l_start = d.s_start = 0; d.len = d.llen = d.t = d.orig = 0; d.pmask = -1;
+    d.ent_start = d.l_start = d.s_start = 0; d.len = d.llen = d.t = d.bound = 0; d.pmask = -1;
     dn = d;
     int2 own = make_int2(0, 0);
     int4 rec[MAXR];
@@ -1120,7 +1167,6 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         if (rtid == 0) {
             a.Slen[d.t] = n_out;
             a.Slead[d.t] = lead_out;
-            a.Sorig[d.t] = d.orig;
             c_nnz += (u64d)n_out;
             c_rows += n_out > 0;
             c_ent += (u64d)ln_cur;
@@ -1230,7 +1276,6 @@ __global__ __launch_bounds__(256) void k_scatter_big(BigScatterArgs b)
         if (tid == 0) {
             a.Slen[d.t] = s_nout;
             a.Slead[d.t] = s_lead;
-            a.Sorig[d.t] = d.orig;
             atomicAdd(&ctr_shard(a.ctr)->nnz_out, (u64d)s_nout);
             if (s_nout > 0) atomicAdd(&ctr_shard(a.ctr)->nonempty_out, 1);
             c_ent += (u64d)d.len;
@@ -1442,13 +1487,14 @@ __global__ void k_colinfo(int m, const int *__restrict__ qinv_r, const i64d *__r
 // what a solve starts from, in one launch instead of five memsets (a launch costs ~4.5 us, a third of a 1/8 shard's fixed
 // cost): statistics and pool counters zero, class counts zero, every row's pivot-column mask "none", bound[n] = 0
 __global__ void k_solve_reset(int n, unsigned *__restrict__ ctr_words, int nctr_words, u64d *__restrict__ pool_ctr, int npool_words,
-                              int *__restrict__ class_count, int nclass, i64d *__restrict__ bound, long long *__restrict__ pmask)
+                              int *__restrict__ class_count, int nclass, i64d *__restrict__ bound, long long *__restrict__ pmask,
+                              int *__restrict__ sflag)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < nctr_words) ctr_words[t] = 0;
     if (t < npool_words) pool_ctr[t] = 0;
     if (t < nclass) class_count[t] = 0;
-    if (t <= n) pmask[t] = -1;
+    if (t <= n) { pmask[t] = -1; sflag[t] = 0; }
     if (t == n) bound[n] = 0;
 }
 
@@ -1476,7 +1522,10 @@ struct CombineArgs {
     const int4 *colinfo;       // per column: {pivot index or -1, offset of its Uinv row, its length, -}
     const UHdr *uhdr;
     const int2 *UinvPool;
-    int4 *Lpool;
+    int4 *Lpool;               // records {stream position of the pivot row's first entry, multiplier, offset in UPN, npn}
+    int *Lidx;                 // when non-NULL: the pivot index of every record
+    int *sflag;                // out: per row slot, 1 when the streaming scatter may take the row (exact bound within the free
+                               // columns, no zero-valued own entry)
     u64d lpool_cap;            // entries per pool region
     u64d *pool_ctr;
     int npool;
@@ -1559,6 +1608,7 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         const int self = a.self_idx ? a.self_idx[t] : -1;
         int nN = 0;
         bool ok = true;
+        bool zero_own = false; // an own entry whose value is 0 mod p: the streaming scatter would write it out as it stands
         // distinct pivot indices met so far: the same value in every lane of the team (the team's inserts are sequential, so
         // no LDS counter is needed: a counter hit by 16 lanes at once serialises 16-fold)
         int dcnt = 0;
@@ -1574,6 +1624,7 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         auto process = [&](const int2 own, const int4 ci, const bool valid) {
             const bool isP = valid && ci.x >= 0 && ci.x != self;
             nN += __popcll(team_ballot<TEAM>(valid && ci.x < 0));
+            zero_own |= valid && own.y == 0;
             u64d mP = team_ballot<TEAM>(isP);
             while (mP && ok) {
                 // up to MAXP pivot entries: all their Uinv rows are requested before any accumulation
@@ -1661,7 +1712,7 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         // ---- one pass over the occupied slots (dcount <= MAXD of them): reduce, drop the zero multipliers, fetch the
         // headers of the applied pivot rows (gathers of a batch in flight together), records out
         int nout = 0;
-        i64d bound = 0;
+        i64d bound = nN; // the row's entry stream: its nN own entries on non-pivot columns first, then the pivot rows in record order
         u64d r_red = 0;
         for (int i0 = 0; i0 < dcount; i0 += 4 * TEAM) {
             int kk[4], vv[4], pos[4];
@@ -1685,19 +1736,24 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                // stream position of the record's pivot row: running total + exclusive prefix over the team (records without a
+                // multiplier carry npn = 0)
+                int tot;
+                const int incl = team_incl_scan<TEAM>(hh[j].npn, tot);
                 if (vv[j] != 0) {
-                    if (room && !SCATTER_DBG(a, 128)) a.Lpool[base + pos[j]] = make_int4(kk[j], vv[j], (int)hh[j].off, hh[j].npn);
-                    bound += hh[j].npn;
+                    const int pre = (int)(bound < (i64d)INT_MAX ? bound : (i64d)INT_MAX) + incl - hh[j].npn;
+                    if (room && !SCATTER_DBG(a, 128)) {
+                        a.Lpool[base + pos[j]] = make_int4(pre, vv[j], (int)hh[j].off, hh[j].npn);
+                        if (a.Lidx) a.Lidx[base + pos[j]] = kk[j];
+                    }
                     r_red += (u64d)hh[j].len;
                 }
+                bound += tot;
             }
         }
-        for (int o = TEAM / 2; o > 0; o >>= 1) {
-            bound += __shfl_xor(bound, o, TEAM);
-            r_red += __shfl_xor(r_red, o, TEAM);
-        }
-        bound += nN;
+        for (int o = TEAM / 2; o > 0; o >>= 1) r_red += __shfl_xor(r_red, o, TEAM);
         r_red += (u64d)ln;
+        const bool any_zero_own = team_ballot<TEAM>(zero_own) != 0;
         if (tl == 0) {
             if (!room) {
                 atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1);
@@ -1706,6 +1762,7 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
                 a.Lstart[t] = (i64d)base;
                 a.Llen[t] = SCATTER_DBG(a, 128) ? 0 : nout; // ablation: the scatter must not read records that were never written
                 a.bound[t] = bound < (i64d)a.free_cols ? bound : (i64d)a.free_cols;
+                if (a.sflag) a.sflag[t] = (bound <= (i64d)a.free_cols && !any_zero_own) ? 1 : 0;
                 c_app += (u64d)nout;
                 c_red += r_red;
                 c_seg += 1 + (u64d)nout;
@@ -1833,7 +1890,10 @@ __global__ __launch_bounds__(NT) void k_solve_big(BigSolveArgs b)
             for (int i = tid; i < cnt; i += NT) {
                 const int4 r = out[i];
                 if (a.Lpool2) a.Lpool2[base + i] = make_int2(r.x, r.y);
-                else a.Lpool[base + i] = r;
+                else {
+                    a.Lpool[base + i] = make_int4(0, r.y, r.z, r.w);
+                    if (a.Lidx) a.Lidx[base + i] = r.x;
+                }
             }
             if (tid == 0) {
                 bound += s_nN;
@@ -2048,7 +2108,8 @@ __global__ void k_kcount(int nfree, const i64d *__restrict__ Lstart, const int *
 }
 
 __global__ void k_kfill(int nfree, const int *__restrict__ freecol, const int *__restrict__ colof, const i64d *__restrict__ Lstart,
-                        const int *__restrict__ Llen, const int4 *__restrict__ Lpool, const i64d *__restrict__ kstart, int2 *__restrict__ Kent)
+                        const int *__restrict__ Llen, const int4 *__restrict__ Lpool, const int *__restrict__ Lidx,
+                        const i64d *__restrict__ kstart, int2 *__restrict__ Kent)
 {
     const int lane = threadIdx.x & 63;
     const int f = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -2063,7 +2124,7 @@ __global__ void k_kfill(int nfree, const int *__restrict__ freecol, const int *_
         int4 r = make_int4(0, 0, 0, 0);
         if (i < ll) r = Lpool[ls + i];
         const u64d m = __ballot(r.y != 0);
-        if (r.y != 0) Kent[pos + __popcll(m & lanemask_lt())] = make_int2(colof[r.x], r.y);
+        if (r.y != 0) Kent[pos + __popcll(m & lanemask_lt())] = make_int2(colof[Lidx[ls + i]], r.y);
         pos += __popcll(m);
     }
 }
@@ -2084,7 +2145,8 @@ __global__ void k_xcount(int n, const i64d *__restrict__ Lstart, const int *__re
 }
 
 __global__ void k_xfill(int n, const int *__restrict__ rowof, const i64d *__restrict__ Lstart, const int *__restrict__ Llen,
-                        const int4 *__restrict__ Lpool, const i64d *__restrict__ xstart, int *__restrict__ oj, int *__restrict__ ox)
+                        const int4 *__restrict__ Lpool, const int *__restrict__ Lidx, const i64d *__restrict__ xstart, int *__restrict__ oj,
+                        int *__restrict__ ox)
 {
     const int lane = threadIdx.x & 63;
     const int f = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -2099,7 +2161,7 @@ __global__ void k_xfill(int n, const int *__restrict__ rowof, const i64d *__rest
         const u64d m = __ballot(r.y != 0);
         if (r.y != 0) {
             const i64d at = pos + __popcll(m & lanemask_lt());
-            oj[at] = rowof[r.x];
+            oj[at] = rowof[Lidx[ls + i]];
             ox[at] = r.y;
         }
         pos += __popcll(m);
