@@ -60,11 +60,12 @@ struct StreamRetry {
     int4 *buf;
     int cnt; // wave-uniform
     __device__ __forceinline__ void bind(unsigned char *p) { buf = (int4 *)p; cnt = 0; }
-    __device__ __forceinline__ void put(int i, int c, int v, int pos, unsigned h) { buf[i] = make_int4(c, v, (int)(((unsigned)pos << 14) | h), 0); }
-    __device__ __forceinline__ void get(int i, int &c, int &v, int &pos, unsigned &h) const
+    // prim = 0: a clamped copy of an entry (it must find the entry in the table, or put it there, but never report a duplicate)
+    __device__ __forceinline__ void put(int i, int c, int v, int pos, unsigned h, int prim) { buf[i] = make_int4(c, v, (int)(((unsigned)pos << 14) | h), prim); }
+    __device__ __forceinline__ void get(int i, int &c, int &v, int &pos, unsigned &h, int &prim) const
     {
         const int4 e = buf[i];
-        c = e.x; v = e.y; pos = (int)((unsigned)e.z >> 14); h = (unsigned)e.z & 0x3fffu;
+        c = e.x; v = e.y; pos = (int)((unsigned)e.z >> 14); h = (unsigned)e.z & 0x3fffu; prim = e.w;
     }
 };
 
@@ -75,7 +76,14 @@ __device__ __forceinline__ void stream_fix_push(int *s_nfix, int2 *fix, int fcap
     if (i < fcap) fix[i] = make_int2((int)(((unsigned)owner_pos << 14) | (unsigned)pos), v);
 }
 
-__device__ __forceinline__ u64d stream_pack(int c, int pos) { return ((u64d)(unsigned)pos << 32) | (u64d)(unsigned)c; }
+// a table slot: {column, byte offset of the entry in the Schur row}
+__device__ __forceinline__ u64d stream_pack(int c, int off) { return ((u64d)(unsigned)off << 32) | (u64d)(unsigned)c; }
+
+// slot of a column: multiplicative hash on full-rate 24-bit multiplies (v_mul_lo_u32 is quarter rate); columns that differ
+// only above bit 23 share a slot, which costs probes, never correctness
+template <int LOGT> __device__ __forceinline__ unsigned stream_hash(int c) { return __umul24((unsigned)c, 0x9E3779u); }
+template <int LOGT> __device__ __forceinline__ unsigned stream_slot(unsigned x) { return x >> (32 - LOGT); }
+template <int LOGT> __device__ __forceinline__ unsigned stream_step(unsigned x) { return ((x >> 5) & ((1u << LOGT) - 1)) | 1u; }
 
 // drain the wave's retry list: one entry per lane, probing on from where its first probe left off
 template <int LOGT>
@@ -86,69 +94,26 @@ __device__ __forceinline__ void stream_drain(u64d *tab, StreamRetry &rl, int *s_
     const int lane = threadIdx.x & 63;
     for (int b = 0; b < rl.cnt; b += 64) {
         bool pending = b + lane < rl.cnt;
-        int c = 0, v = 0, pos = 0;
+        int c = 0, v = 0, pos = 0, prim = 0;
         unsigned h = 0, st = 1;
         if (pending) {
-            rl.get(b + lane, c, v, pos, h);
-            unsigned h0;
-            hash2<LOGT>(c, h0, st);
+            rl.get(b + lane, c, v, pos, h, prim);
+            st = stream_step<LOGT>(stream_hash<LOGT>(c));
         }
+        const u64d want = stream_pack(c, pos << 3);
         for (unsigned round = 0; round < T && __ballot(pending) != 0; round++) {
             if (pending) {
-                const u64d old = atomicCAS(&tab[h], EMPTY64, stream_pack(c, pos));
-                if (old == EMPTY64) pending = false;
-                else if ((int)(unsigned)old == c) { stream_fix_push(s_nfix, fix, FCAP, (int)(old >> 32), pos, v); pending = false; }
-                else h = (h + st) & (T - 1);
+                const u64d old = atomicCAS(&tab[h], EMPTY64, want);
+                if (old == EMPTY64 || old == want) pending = false; // (met itself: a lane past the end of a pivot row repeats its last entry)
+                else if ((int)(unsigned)old == c) {
+                    if (prim) stream_fix_push(s_nfix, fix, FCAP, (int)(old >> 35), pos, v);
+                    pending = false;
+                } else h = (h + st) & (T - 1);
             }
         }
         if (pending) atomicAdd(&ctr_shard(ctr)->scatter_overflow, 1);
     }
     rl.cnt = 0;
-}
-
-// one probe for each of the N entries of this lane (every lane of the wave takes part: the retry list is bookkept per wave)
-template <int LOGT, int N>
-__device__ __forceinline__ void stream_try_n(u64d *tab, StreamRetry &rl, int *s_nfix, int2 *fix, const int (&c)[N], const int (&v)[N],
-                                             const int (&pos)[N], unsigned valid, RoundCounters *ctr)
-{
-    static_assert(N * 64 <= SRCAP, "the retry list must hold one batch");
-    constexpr unsigned T = 1u << LOGT;
-    constexpr int FCAP = stream_fcap(LOGT);
-    unsigned h[N], st[N];
-    u64d old[N];
-#pragma unroll
-    for (int j = 0; j < N; j++) hash2<LOGT>(c[j], h[j], st[j]);
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        old[j] = EMPTY64; // lanes without an entry: "won", nothing to do
-        if (valid & (1u << j)) old[j] = atomicCAS(&tab[h[j]], EMPTY64, stream_pack(c[j], pos[j]));
-    }
-    bool fail[N], same[N], anysame = false;
-    u64d fm[N];
-    int nfail = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        const bool won = old[j] == EMPTY64;
-        same[j] = !won && (int)(unsigned)old[j] == c[j];
-        fail[j] = !won && !same[j];
-        anysame |= same[j];
-        fm[j] = __ballot(fail[j]);
-        nfail += __popcll(fm[j]);
-    }
-    if (__ballot(anysame) != 0) { // rare: a second entry on a column of this row
-#pragma unroll
-        for (int j = 0; j < N; j++)
-            if (same[j]) stream_fix_push(s_nfix, fix, FCAP, (int)(old[j] >> 32), pos[j], v[j]);
-    }
-    if (nfail == 0) return;
-    if (rl.cnt + nfail > SRCAP) stream_drain<LOGT>(tab, rl, s_nfix, fix, ctr);
-    int at = rl.cnt;
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        if (fail[j]) rl.put(at + __popcll(fm[j] & lanemask_lt()), c[j], v[j], pos[j], (h[j] + st[j]) & (T - 1));
-        at += __popcll(fm[j]);
-    }
-    rl.cnt = at;
 }
 
 // one entry of one lane, probing until it is in (safe under divergence: no wave-level bookkeeping)
@@ -157,12 +122,14 @@ __device__ __forceinline__ void stream_add_1(u64d *tab, int *s_nfix, int2 *fix, 
 {
     constexpr unsigned T = 1u << LOGT;
     constexpr int FCAP = stream_fcap(LOGT);
-    unsigned h, st;
-    hash2<LOGT>(c, h, st);
+    const unsigned x = stream_hash<LOGT>(c);
+    unsigned h = stream_slot<LOGT>(x);
+    const unsigned st = stream_step<LOGT>(x);
+    const u64d want = stream_pack(c, pos << 3);
     for (unsigned round = 0; round < T; round++) {
-        const u64d old = atomicCAS(&tab[h], EMPTY64, stream_pack(c, pos));
-        if (old == EMPTY64) return;
-        if ((int)(unsigned)old == c) { stream_fix_push(s_nfix, fix, FCAP, (int)(old >> 32), pos, v); return; }
+        const u64d old = atomicCAS(&tab[h], EMPTY64, want);
+        if (old == EMPTY64 || old == want) return;
+        if ((int)(unsigned)old == c) { stream_fix_push(s_nfix, fix, FCAP, (int)(old >> 35), pos, v); return; }
         h = (h + st) & (T - 1);
     }
     atomicAdd(&ctr_shard(ctr)->scatter_overflow, 1);
@@ -261,9 +228,52 @@ __device__ __noinline__ int stream_fixup(const ZpField F, const int2 *fix, int n
     return n_out;
 }
 
+// What a batch of N probes left unresolved: an entry that met ANOTHER column goes to the wave's retry list, an entry that met
+// its own column under another position is a duplicate and goes to the row's fix-up list.  (An entry that met itself --
+// same column, same position: lanes past the end of a pivot row repeat its last entry -- is in.)  Wave-uniform call.
+template <int LOGT, int N>
+__device__ __forceinline__ void stream_resolve(u64d *tab, StreamRetry &rl, int *s_nfix, int2 *fix, const int (&c)[N], const int (&v)[N],
+                                               const unsigned (&off)[N], const u64d (&old)[N], const bool (&bad)[N], const bool (&prim)[N],
+                                               RoundCounters *ctr)
+{
+    // prim[j]: this lane holds the entry itself, not a clamped copy of it -- a duplicate column is reported once
+    constexpr int FCAP = stream_fcap(LOGT);
+    constexpr unsigned T = 1u << LOGT;
+    u64d fm[N];
+    int nfail = 0;
+    bool anysame = false;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const bool same = bad[j] && (int)(unsigned)old[j] == c[j];
+        anysame |= same && prim[j];
+        fm[j] = __ballot(bad[j] && !same);
+        nfail += __popcll(fm[j]);
+    }
+    if (__ballot(anysame) != 0) {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (prim[j] && bad[j] && (int)(unsigned)old[j] == c[j]) stream_fix_push(s_nfix, fix, FCAP, (int)(old[j] >> 35), (int)(off[j] >> 3), v[j]);
+    }
+    if (nfail == 0) return;
+    if (rl.cnt + nfail > SRCAP) stream_drain<LOGT>(tab, rl, s_nfix, fix, ctr);
+    int at = rl.cnt;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (fm[j] & (1ull << (threadIdx.x & 63))) {
+            const unsigned x = stream_hash<LOGT>(c[j]);
+            rl.put(at + __popcll(fm[j] & lanemask_lt()), c[j], v[j], (int)(off[j] >> 3), (stream_slot<LOGT>(x) + stream_step<LOGT>(x)) & (T - 1), prim[j] ? 1 : 0);
+        }
+        at += __popcll(fm[j]);
+    }
+    rl.cnt = at;
+}
+
 // TPR = threads cooperating on one row: 64 (a wave per row, WPB independent rows per workgroup, no barriers) or WPB * 64
 // MAXR = rounds of pivot rows whose loads are all issued before any of them is used; round r hands pivot row gg + r * NG
 //        of the row's record list to the 8-lane group gg
+// The common path carries NO per-entry predicate: a lane past the end of its pivot row holds a copy of the row's last entry
+// (clamped index) and simply repeats that entry's store and its CAS -- same bytes to the same address, and a CAS that finds
+// {same column, same position} counts as "in".  Groups past the end of the record list repeat the last record the same way.
 template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
 {
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
     int c_rows = 0, c_fix = 0, c_redo = 0;
     int par = 0;
 
-    // ---- pipeline registers (as in k_scatter): descriptor two rows ahead, own entries + records one row ahead
+    // ---- pipeline registers: descriptor two rows ahead, first own entries + records one row ahead
     RowDesc d, dn;
     d.ent_start = d.l_start = d.s_start = 0; d.len = d.llen = d.t = d.bound = 0; d.pmask = -1;
     dn = d;
@@ -325,21 +335,23 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
         const DescRegs dnn_regs = desc_load(&a.desc[min(w + 2 * stride, count - 1)]);
         const int ln = d.len, ll = d.llen;
         int *const s_nfix = misc + par * 8;
-        // ---- every load of the row: qinv of the own entry (first 64, wave 0), entries of the pivot rows
+        // ---- every load of the row: qinv of the own entry (first 64, wave 0), entries of the pivot rows (clamped indices)
         int q_own = 0;
         if (d.pmask >= 0) q_own = ((d.pmask >> lane) & 1) ? 0 : -1;
         else if (lane < ln) q_own = a.qinv_r[own.x];
         int2 u[MAXR][3];
-        int npn[MAXR];
+        bool gok[MAXR];         // the group's record has entries (a pivot row may consist of its pivot alone)
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
-            npn[r] = (gg + r * NG < ll && rec[r].y != 0) ? rec[r].w : 0;
+            const int np = rec[r].w;
+            gok[r] = np > 0 && rec[r].y != 0;
             const int2 *up = a.UPN + (unsigned)rec[r].z;
-            const int last = max(npn[r] - 1, 0);
+            const int last = max(np - 1, 0);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                u[r][j] = make_int2(gl + j * G + r * 1024 + gg * 32, 1);
-                if (!SCATTER_DBG(a, 8)) u[r][j] = up[min(gl + j * G, last)];
+                const int idx = min(gl + j * G, last);
+                u[r][j] = make_int2(idx + r * 1024 + gg * 32, 1);
+                if (!SCATTER_DBG(a, 8)) u[r][j] = up[idx];
             }
         }
         // ---- stage-1 data of the NEXT row (its first own entries, its records), behind this row's loads: they have long
@@ -355,21 +367,29 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
         }
         unsigned char *const rowp = (unsigned char *)(a.Sent + d.s_start);
         int mylead = INT_MAX;
-        int r_ent = 0, r_seg = 0;
+        int nN = 0;
         // ---- the row's own entries on non-pivot columns: stream positions 0 .. nN-1, one wave (their rank is a ballot)
         if (WAVE_ROW || wave == 0) {
-            int nbase = 0;
             {
                 const bool nonpiv = lane < ln && q_own < 0;
                 const u64d m = __ballot(nonpiv);
-                const int pos = __popcll(m & lanemask_lt());
+                const unsigned off = (unsigned)__popcll(m & lanemask_lt()) << 3;
+                u64d old = EMPTY64;
+                const u64d want = stream_pack(own.x, (int)off);
                 if (nonpiv) {
-                    __builtin_nontemporal_store(((long long)(unsigned)own.y << 32) | (unsigned)own.x, (long long *)(rowp + ((unsigned)pos << 3)));
+                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)own.y << 32) | (unsigned)own.x, (long long *)(rowp + off));
                     mylead = min(mylead, own.x);
+                    if (!SCATTER_DBG(a, 2)) old = atomicCAS(&tab[stream_slot<LOGT>(stream_hash<LOGT>(own.x))], EMPTY64, want);
                 }
-                const int oc[1] = {own.x}, ov[1] = {own.y}, op[1] = {pos};
-                stream_try_n<LOGT, 1>(tab, rl, s_nfix, fix, oc, ov, op, nonpiv ? 1u : 0u, a.ctr);
-                nbase = __popcll(m);
+                const bool bad[1] = {old != EMPTY64 && old != want};
+                if (__ballot(bad[0]) != 0) {
+                    const int oc[1] = {own.x}, ov[1] = {own.y};
+                    const unsigned oo[1] = {off};
+                    const u64d ol[1] = {old};
+                    const bool pr[1] = {true};
+                    stream_resolve<LOGT, 1>(tab, rl, s_nfix, fix, oc, ov, oo, ol, bad, pr, a.ctr);
+                }
+                nN = __popcll(m);
             }
             for (int k0 = 64; k0 < ln; k0 += 64) { // rows longer than a wave (wave-uniform trip count)
                 const int k = k0 + lane;
@@ -380,66 +400,86 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
                     nonpiv = a.qinv_r[e.x] < 0;
                 }
                 const u64d m = __ballot(nonpiv);
-                const int pos = nbase + __popcll(m & lanemask_lt());
+                const unsigned off = (unsigned)(nN + __popcll(m & lanemask_lt())) << 3;
+                u64d old = EMPTY64;
+                const u64d want = stream_pack(e.x, (int)off);
                 if (nonpiv) {
-                    __builtin_nontemporal_store(((long long)(unsigned)e.y << 32) | (unsigned)e.x, (long long *)(rowp + ((unsigned)pos << 3)));
+                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)e.y << 32) | (unsigned)e.x, (long long *)(rowp + off));
                     mylead = min(mylead, e.x);
+                    if (!SCATTER_DBG(a, 2)) old = atomicCAS(&tab[stream_slot<LOGT>(stream_hash<LOGT>(e.x))], EMPTY64, want);
                 }
-                const int oc[1] = {e.x}, ov[1] = {e.y}, op[1] = {pos};
-                stream_try_n<LOGT, 1>(tab, rl, s_nfix, fix, oc, ov, op, nonpiv ? 1u : 0u, a.ctr);
-                nbase += __popcll(m);
+                const bool bad[1] = {old != EMPTY64 && old != want};
+                if (__ballot(bad[0]) != 0) {
+                    const int oc[1] = {e.x}, ov[1] = {e.y};
+                    const unsigned oo[1] = {off};
+                    const u64d ol[1] = {old};
+                    const bool pr[1] = {true};
+                    stream_resolve<LOGT, 1>(tab, rl, s_nfix, fix, oc, ov, oo, ol, bad, pr, a.ctr);
+                }
+                nN += __popcll(m);
             }
         }
-        // ---- the pivot rows: multiply, store at the record's stream position, one CAS for the duplicate check
+        // ---- the pivot rows: multiply, store at the entry's stream position, one CAS for the duplicate check
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
-            if (__ballot(npn[r] > 0) != 0) { // wave-uniform
-                if (gl == 0) { r_ent += npn[r]; r_seg += npn[r] > 0; }
+            if (r * NG < ll) { // scalar: there are records for this round
                 const int nm = -rec[r].y;
-                int bc[3], bv[3], bp[3];
-                unsigned valid = 0;
+                const bool allok = __ballot(!gok[r]) == 0;
+                int bc[3], bv[3];
+                unsigned uoff[3]; // byte offset of the entry in the Schur row
+                u64d old[3], want[3];
+                bool bad[3];
+                const int last = max(rec[r].w - 1, 0);
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     bc[j] = u[r][j].x;
                     bv[j] = stream_mul<SMALL>(F, nm, u[r][j].y);
-                    bp[j] = rec[r].x + gl + j * G;
-                    if (gl + j * G < npn[r]) {
-                        valid |= 1u << j;
-                        if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)bv[j] << 32) | (unsigned)bc[j], (long long *)(rowp + ((unsigned)bp[j] << 3)));
-                    }
+                    uoff[j] = (unsigned)(rec[r].x + min(gl + j * G, last)) << 3;
+                    want[j] = stream_pack(bc[j], (int)uoff[j]);
+                    old[j] = EMPTY64;
                 }
-                // lanes past the end of the pivot row hold a copy of its last entry: their columns are columns of the row
-                if (npn[r] > 0) mylead = min(mylead, min(bc[0], min(bc[1], bc[2])));
-                if (SCATTER_DBG(a, 2)) asm volatile("" ::"v"(bc[0]), "v"(bv[0]), "v"(bp[0]));
-                else if (SCATTER_DBG(a, 32)) {
+                if (allok) {
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
-                        unsigned hh, ss;
-                        hash2<LOGT>(bc[j], hh, ss);
-                        if (valid & (1u << j)) {
-                            const unsigned o = atomicCAS((unsigned *)&tab[hh], 0xffffffffu, (unsigned)bc[j]);
-                            asm volatile("" ::"v"(o));
-                        }
+                        if (!SCATTER_DBG(a, 2)) old[j] = atomicCAS(&tab[stream_slot<LOGT>(stream_hash<LOGT>(bc[j]))], EMPTY64, want[j]);
+                        if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)bv[j] << 32) | (unsigned)bc[j], (long long *)(rowp + uoff[j]));
                     }
-                } else stream_try_n<LOGT, 3>(tab, rl, s_nfix, fix, bc, bv, bp, valid, a.ctr);
-                const int2 *up = a.UPN + (unsigned)rec[r].z;
-                for (int k = gl + 3 * G; k < npn[r]; k += G) { // pivot rows longer than 24 entries
-                    const int2 uu = up[k];
-                    const int vv = stream_mul<SMALL>(F, nm, uu.y);
-                    const int pp = rec[r].x + k;
-                    __builtin_nontemporal_store(((long long)(unsigned)vv << 32) | (unsigned)uu.x, (long long *)(rowp + ((unsigned)pp << 3)));
-                    mylead = min(mylead, uu.x);
-                    stream_add_1<LOGT>(tab, s_nfix, fix, uu.x, vv, pp, a.ctr);
+                    mylead = min(mylead, min(bc[0], min(bc[1], bc[2])));
+                } else if (gok[r]) { // a group without entries in this round: the others go on under their own predicate
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        old[j] = atomicCAS(&tab[stream_slot<LOGT>(stream_hash<LOGT>(bc[j]))], EMPTY64, want[j]);
+                        __builtin_nontemporal_store(((long long)(unsigned)bv[j] << 32) | (unsigned)bc[j], (long long *)(rowp + uoff[j]));
+                    }
+                    mylead = min(mylead, min(bc[0], min(bc[1], bc[2])));
+                }
+#pragma unroll
+                for (int j = 0; j < 3; j++) bad[j] = old[j] != EMPTY64 && old[j] != want[j];
+                if (__ballot(bad[0] | bad[1] | bad[2]) != 0) {
+                    const bool gprim = gg + r * NG < ll;
+                    const bool pr[3] = {gprim && gl <= last, gprim && gl + G <= last, gprim && gl + 2 * G <= last};
+                    stream_resolve<LOGT, 3>(tab, rl, s_nfix, fix, bc, bv, uoff, old, bad, pr, a.ctr);
+                }
+                if (__ballot(gok[r] && rec[r].w > 3 * G) != 0) { // pivot rows longer than 24 entries
+                    const int2 *up = a.UPN + (unsigned)rec[r].z;
+                    const int np = gok[r] ? rec[r].w : 0;
+                    for (int k = gl + 3 * G; k < np; k += G) {
+                        const int2 uu = up[k];
+                        const int vv = stream_mul<SMALL>(F, nm, uu.y);
+                        const int pp = rec[r].x + k;
+                        __builtin_nontemporal_store(((long long)(unsigned)vv << 32) | (unsigned)uu.x, (long long *)(rowp + ((unsigned)pp << 3)));
+                        mylead = min(mylead, uu.x);
+                        stream_add_1<LOGT>(tab, s_nfix, fix, uu.x, vv, pp, a.ctr);
+                    }
                 }
             }
         }
-        // ---- more pivot rows than NG * MAXR: the same, one round at a time (wave-uniform trip count)
+        // ---- more pivot rows than NG * MAXR: one round at a time, per-lane probing (wave-uniform trip count)
         for (int e0 = MAXR * NG; e0 < ll; e0 += NG) {
             const int e = e0 + gg;
             int4 le = make_int4(0, 0, 0, 0);
             if (e < ll) le = a.Lpool[d.l_start + e];
             const int np = le.y != 0 ? le.w : 0;
-            if (gl == 0) { r_ent += np; r_seg += np > 0; }
             const int nm = -le.y;
             const int2 *up = a.UPN + (unsigned)le.z;
             for (int k = gl; k < np; k += G) {
@@ -485,14 +525,12 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
                 a.Slead[t_cur] = n_out > 0 ? lead_out : INT_MAX;
                 c_nnz += (u64d)n_out;
                 c_rows += n_out > 0;
-                c_ent += (u64d)ln_cur;
-                c_seg += 1;
+                // entries streamed: the own entries + the non-pivot parts of the applied pivot rows (= E - nN, the records of the
+                // combine kernel all carry a multiplier); segments: the row + one per record
+                c_ent += (u64d)ln_cur + (u64d)(E - nN);
+                c_seg += 1 + (u64d)ll;
                 c_fix += nfix;
             }
-        }
-        if (!redo) {
-            c_ent += (u64d)(unsigned)r_ent;
-            c_seg += (u64d)(unsigned)r_seg;
         }
         // ---- reset: the table, and the other parity's words (nobody reads them any more: every wave is past its barrier)
         for (int s = rtid * 2; s < T; s += TPR * 2) *(int4 *)(tab + s) = make_int4(-1, -1, -1, -1);
