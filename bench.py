@@ -195,7 +195,7 @@ def main():
             "round_ms": {"solve": round(d["ms_solve"], 4), "scatter": round(d["ms_scatter"], 4)},
             "per_class_ms": {"hash": [round(x, 4) for x in d["ms_class"][:8]], "stream": [round(x, 4) for x in d["ms_class"][8:15]]},
             "per_class_rows": {"hash": d["rows_class"][:8], "stream": d["rows_class"][8:15]},
-            "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"],
+            "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"], "stream_fix_ms": round(d["ms_class"][15], 4),
         }
         out = {
             "metric": "Schur nnz reduced/sec (GF(p) echelonize), 1Mx1M CSR",

@@ -131,28 +131,35 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
     }
 }
 
-template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW = 1> void launch_stream(const StreamArgs &a, int grid, size_t lds, hipStream_t s)
+// grid = min(rows, resident workgroups): the kernels walk their row list with a grid stride, and a workgroup that is not resident
+// from the start would do its share after everybody else (the LDS bound alone can be above what the registers admit)
+template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW = 1> void launch_stream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int per_cu = 0;
+    if (!per_cu) {
         HIPCHK(hipFuncSetAttribute((const void *)k_stream<LOGT, TPR, WPB, MAXR, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        int nb = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_stream<LOGT, TPR, WPB, MAXR, SMALL, MINW>, WPB * 64, lds));
+        per_cu = std::max(nb, 1);
     }
+    const int rows_per_block = TPR == 64 ? WPB : 1;
+    const int grid = std::max(1, std::min((nrows + rows_per_block - 1) / rows_per_block, num_cu * per_cu));
     hipLaunchKernelGGL((k_stream<LOGT, TPR, WPB, MAXR, SMALL, MINW>), dim3(grid), dim3(WPB * 64), lds, s, a);
     HIPCHK(hipGetLastError());
 }
 
-// the streaming twins of the hash-table classes: same table sizes (the 8-byte slot is {column, position}), same geometry
-template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int grid, size_t lds, hipStream_t s)
+// the streaming twins of the hash-table classes 0..4 (row bounds up to 160 << c): first table of 512 << c words (at most 5/16
+// full), same threads per row as the hash class
+const int kNumStreamClasses = 5;
+inline int stream_logt(int c) { return 9 + c; }
+template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
     switch (cls) {
-    case 0: launch_stream<8, 64, 4, 1, SMALL>(a, grid, lds, s); break;
-    case 1: launch_stream<9, 64, 4, 2, SMALL>(a, grid, lds, s); break;
-    case 2: launch_stream<10, 64, 4, 4, SMALL, 4>(a, grid, lds, s); break;
-    case 3: launch_stream<11, 128, 2, 4, SMALL, 4>(a, grid, lds, s); break;
-    case 4: launch_stream<12, 256, 4, 4, SMALL, 4>(a, grid, lds, s); break;
-    case 5: launch_stream<13, 256, 4, 5, SMALL>(a, grid, lds, s); break;
-    case 6: launch_stream<14, 256, 4, 5, SMALL>(a, grid, lds, s); break;
+    case 0: launch_stream<9, 64, 4, 1, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 1: launch_stream<10, 64, 4, 2, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 2: launch_stream<11, 64, 4, 4, SMALL, 3>(a, nrows, num_cu, lds, s); break;
+    case 3: launch_stream<12, 128, 2, 4, SMALL, 3>(a, nrows, num_cu, lds, s); break;
+    case 4: launch_stream<13, 256, 4, 4, SMALL, 3>(a, nrows, num_cu, lds, s); break;
     default: break;
     }
 }
@@ -192,6 +199,8 @@ struct Round {
     DevBuf<int> Lidx;               // pivot index of every record (only when want_idx: kernel basis, triangular solve)
     bool want_idx = false;
     DevBuf<int> sflag;              // per row slot: the streaming scatter may take the row
+    DevBuf<int2> fixbuf;            // per row slot: SFIX duplicates found by the streaming kernels, merged by k_stream_fix
+    DevBuf<int> fixcnt;
     bool use_stream = true;         // SPASM_AMD_STREAM=0 turns the streaming scatter off
     DevBuf<u64d> pool_ctr;          // NPOOL sharded bump counters
     int npool_active = NPOOL;       // regions in use by the current solve
@@ -345,6 +354,8 @@ struct Round {
         overflow2_list.ensure((size_t)nrows + 1);
         pmask.ensure((size_t)nrows + 1);
         sflag.ensure((size_t)nrows + 1);
+        fixcnt.ensure((size_t)nrows + 1);
+        if (use_stream) fixbuf.ensure(((size_t)nrows + 1) * SFIX);
         npool_active = std::min(NPOOL, std::max(1, nrows / 4));
         region_cap = ((u64d)lpool_entries + npool_active - 1) / npool_active;
         Lpool.ensure((size_t)(region_cap * npool_active) + 1);
@@ -706,7 +717,8 @@ struct Round {
         if (nrows == 0) return;
         HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
         int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1; // 12-byte slots: the 2^14 table exceeds LDS
-        const bool streaming = use_stream && use_uinv; // the stream positions come from the combine kernel
+        // the stream positions come from the combine kernel; the duplicate check identifies a column by 24 bits
+        const bool streaming = use_stream && use_uinv && m < (1 << 24);
         BinArgs b;
         b.nrows = nrows;
         b.bound = bound.p;
@@ -724,8 +736,9 @@ struct Round {
         b.sstart = sstart.p;
         b.pmask = pmask.p;
         b.sflag = sflag.p;
-        b.stream_classes = streaming ? nhash : 0;
+        b.stream_classes = streaming ? std::min(nhash, kNumStreamClasses) : 0;
         b.Sorig = S.orig.p;
+        b.fixcnt = fixcnt.p;
         b.desc = class_desc.p;
         hipLaunchKernelGGL(k_bin, dim3(cdiv(nrows, 1024)), dim3(256), 0, stream, b);
         HIPCHK(hipGetLastError());
@@ -762,6 +775,9 @@ struct Round {
         sa.ctr = ctr.p;
         sa.F = F;
         sa.dbg = a.dbg;
+        sa.stamps = a.stamps;
+        sa.fixbuf = fixbuf.p;
+        sa.fixcnt = fixcnt.p;
         nhash_used = nhash;
         // The classes with the largest tables hold few rows (config 3: 7829 and 51 of 830527), each a long serial job of one
         // workgroup: launched after the others they are a tail on a nearly empty chip (0.27 of 4.1 ms; 74 of 760 us for a
@@ -797,20 +813,33 @@ struct Round {
         };
         // the streaming twin of hash class c; rows it gives up on land in class c's list, which therefore runs after it
         auto launch_stream_cls = [&](int c, hipStream_t s) {
-            if (!streaming) return;
+            if (!streaming || c >= kNumStreamClasses) return;
             mark(NSTREAM0 + c, s);
             sa.cls = NSTREAM0 + c;
             sa.class_count = class_count.p + NSTREAM0 + c;
             sa.desc = class_desc.p + (size_t)(NSTREAM0 + c) * nrows;
             sa.redo_count = class_count.p + c;
             sa.redo_desc = class_desc.p + (size_t)c * nrows;
-            const size_t lds = stream_lds_bytes(kClasses[c].logt, kClasses[c].tpr, kClasses[c].wpb);
-            int per_cu = (int)std::min<size_t>(32 / kClasses[c].wpb, (160 * 1024) / lds);
-            if (per_cu < 1) per_cu = 1;
-            const int rows_per_block = kClasses[c].tpr == 64 ? kClasses[c].wpb : 1;
-            const int grid = std::max(1, std::min(cdiv(nrows, rows_per_block), num_cu * per_cu));
-            if (F.small) launch_stream_class<true>(c, sa, grid, lds, s);
-            else launch_stream_class<false>(c, sa, grid, lds, s);
+            const size_t lds = stream_lds_bytes(stream_logt(c), kClasses[c].tpr, kClasses[c].wpb);
+            if (F.small) launch_stream_class<true>(c, sa, nrows, num_cu, lds, s);
+            else launch_stream_class<false>(c, sa, nrows, num_cu, lds, s);
+        };
+        // the duplicates the streaming kernels found are merged afterwards, a wave per row that has any
+        auto launch_stream_fix = [&](hipStream_t s) {
+            if (!streaming) return;
+            mark(NCLASS - 1, s); // (reported as class 15)
+            StreamFixArgs fa;
+            fa.nrows = nrows;
+            fa.fixcnt = fixcnt.p;
+            fa.fixbuf = fixbuf.p;
+            fa.sstart = sstart.p;
+            fa.Sent = S.ent.p;
+            fa.Slen = S.len.p;
+            fa.Slead = S.lead.p;
+            fa.ctr = ctr.p;
+            fa.F = F;
+            hipLaunchKernelGGL(k_stream_fix, dim3(cdiv(nrows, 256)), dim3(256), 0, s, fa);
+            HIPCHK(hipGetLastError());
         };
         auto launch_big = [&](hipStream_t s) {
             // rows that fit no LDS table: the last class, through the global-memory kernel
@@ -844,10 +873,12 @@ struct Round {
             launch_big(side);
             HIPCHK(hipEventRecord(ev_join, side));
             for (int c = 0; c < first_side; c++) launch_stream_cls(c, stream);
+            launch_stream_fix(stream);
             for (int c = 0; c < first_side; c++) launch_class(c, stream);
             HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
         } else {
             for (int c = 0; c < nhash; c++) launch_stream_cls(c, stream);
+            launch_stream_fix(stream);
             for (int c = 0; c < nhash; c++) launch_class(c, stream);
             launch_big(stream);
             if (class_timing) HIPCHK(hipEventRecord(ev_cls[nlaunch], stream));
@@ -869,7 +900,15 @@ struct Round {
             std::vector<u64d> h(NCLASS * 2 * NSTAMP);
             HIPCHK(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(u64d), hipMemcpyDeviceToHost));
             static const char *names[NSTAMP] = {"prologue", "issue", "wait-loads", "own", "rounds", "remainder", "sweep", "-"};
-            for (int c = 0; c < NCLASS; c++) {
+            static const char *snames[NSTAMP] = {"issue", "own", "rounds", "rowend", "reset", "rotate", "-", "-"};
+            for (int c = NSTREAM0; c < NCLASS; c++) {
+                const double waves = (double)h[(size_t)c * 2 * NSTAMP + NSTAMP];
+                if (waves == 0) continue;
+                fprintf(stderr, "[stamps] stream class %d rows %d waves %.0f: cycles per wave:", c - NSTREAM0, cc[c], waves);
+                for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%.0f", snames[i], (double)h[(size_t)c * 2 * NSTAMP + i] / waves);
+                fprintf(stderr, "\n");
+            }
+            for (int c = 0; c < NHASHMAX; c++) {
                 const double waves = (double)h[(size_t)c * 2 * NSTAMP + NSTAMP];
                 if (waves == 0) continue;
                 fprintf(stderr, "[stamps] class %d rows %d waves %.0f: cycles per wave:", c, cc[c], waves);

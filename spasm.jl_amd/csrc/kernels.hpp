@@ -576,6 +576,7 @@ struct BinArgs {
     const int *sflag;        // per row slot: 1 = the records carry stream positions and the bound is exact (streaming kernel)
     int stream_classes;      // hash classes 0..stream_classes-1 have a streaming twin (class + NSTREAM0); 0 = streaming off
     int *Sorig;              // out: originating row of every row slot
+    int *fixcnt;             // out: 0 for every row slot (duplicates the streaming kernels leave for k_stream_fix)
     RowDesc *desc;           // [NCLASS][nrows]
     i64d cap[NCLASS];        // class c takes rows with bound <= cap[c]; the last class takes the rest
     int *class_count;        // [NCLASS]
@@ -629,7 +630,10 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a)
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const int t = base + i * 256 + threadIdx.x;
-        if (t < a.nrows) a.Sorig[t] = a.orig[a.rows ? a.rows[t] : t];
+        if (t < a.nrows) {
+            a.Sorig[t] = a.orig[a.rows ? a.rows[t] : t];
+            a.fixcnt[t] = 0;
+        }
     }
 }
 
@@ -1522,7 +1526,7 @@ struct CombineArgs {
     const int4 *colinfo;       // per column: {pivot index or -1, offset of its Uinv row, its length, -}
     const UHdr *uhdr;
     const int2 *UinvPool;
-    int4 *Lpool;               // records {stream position of the pivot row's first entry, multiplier, offset in UPN, npn}
+    int4 *Lpool;               // records {stream position of the pivot row's first entry << 16 | npn, multiplier, offset in UPN, npn}
     int *Lidx;                 // when non-NULL: the pivot index of every record
     int *sflag;                // out: per row slot, 1 when the streaming scatter may take the row (exact bound within the free
                                // columns, no zero-valued own entry)
@@ -1743,7 +1747,8 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
                 if (vv[j] != 0) {
                     const int pre = (int)(bound < (i64d)INT_MAX ? bound : (i64d)INT_MAX) + incl - hh[j].npn;
                     if (room && !SCATTER_DBG(a, 128)) {
-                        a.Lpool[base + pos[j]] = make_int4(pre, vv[j], (int)hh[j].off, hh[j].npn);
+                        // .x: what the streaming scatter reads in one word (its rows have bounds, hence positions and npn, below 2^14)
+                        a.Lpool[base + pos[j]] = make_int4((int)(((unsigned)pre << 16) | (unsigned)min(hh[j].npn, 0xffff)), vv[j], (int)hh[j].off, hh[j].npn);
                         if (a.Lidx) a.Lidx[base + pos[j]] = kk[j];
                     }
                     r_red += (u64d)hh[j].len;

@@ -5,24 +5,31 @@
 //
 // On sparse matrices nearly every entry of a Schur row lands on a column of its own: with ~600 entries thrown on ~10^6
 // columns a row sees 0.2 collisions.  The hash-table kernel pays for the general case on every entry (CAS + atomic add in
-// LDS, then a sweep over all slots that reduces, compacts and stores).  Here an entry's value IS its final value unless a
-// second entry shows up on the same column, so:
+// LDS, probing, then a sweep over all slots that reduces, compacts and stores).  Here an entry's value IS its final value
+// unless a second entry shows up on the same column, so:
 //   * every entry of the row's stream (its own entries on non-pivot columns, then the non-pivot parts of the applied pivot
 //     rows, in record order) has a fixed POSITION known before anything is loaded: the combine kernel stores the running
 //     total of npn in each multiplier record;
 //   * the entry is multiplied, reduced to its balanced residue and stored straight to S[row][position] from registers;
-//   * the LDS table only detects duplicates: one 64-bit CAS per entry on {column, position}.  An entry that finds its
-//     column already there goes to the row's fix-up list {owner's position, own position, value};
-//   * after the last entry the (rare) fix-ups are applied in global memory: the value is added to the owner's entry with a
-//     64-bit compare-and-swap, the duplicate's position becomes a hole, and holes are filled with the entries at the end
-//     of the row (the order of a row's entries carries no meaning, reference src/SpaSM.jl:1017-1020).
-// No accumulate, no sweep: LDS traffic per entry is one CAS, VALU work about a third of the hash kernel's.
+//   * LDS only detects duplicates, with DIRECT-MAPPED tables of 32-bit words and no probing: x = column * K mod 2^24 is a
+//     bijection of the column (K odd, columns below 2^24), the slot is its top bits, and the word stored is
+//     (x << 14) | (position + 1) -- the slot index and the 18 low bits of x in the word identify the column exactly.  One
+//     CAS per entry; an entry that finds ANOTHER column in its slot (the table is at most 5/16 full) gets one more CAS in a
+//     second table a quarter of the size under another K; what loses there too (about 1 %) goes to a short list that is
+//     compared pairwise at the end of the row.  No loops, no retry lists;
+//   * an entry that finds its own column under another position is a duplicate: {owner's position, own position, value}
+//     goes to the row's fix-up list.  After the last entry the (rare) fix-ups are applied in global memory: the value is
+//     added to the owner's entry with a 64-bit compare-and-swap, the duplicate's position becomes a hole, and holes are
+//     filled with the entries at the end of the row (the order of a row's entries carries no meaning, reference
+//     src/SpaSM.jl:1017-1020);
+//   * no per-entry predicates: a lane past the end of its pivot row holds a copy of the row's last entry (clamped index) and
+//     repeats that entry's store and CAS -- same bytes to the same address, and a CAS that finds the very word it wanted to
+//     write counts as "in";
+//   * the loads of a row's pivot-row entries are issued one row ahead (its records two rows ahead, its descriptor three).
 // Rows with more duplicates than the fix-up list holds (structured matrices) are handed back to the hash-table kernel
 // of the same size class through its row list.
 #pragma once
 #include "kernels.hpp"
-
-#define EMPTY64 (~0ull)
 
 struct StreamArgs {
     const int *class_count;    // rows in this class
@@ -30,7 +37,7 @@ struct StreamArgs {
     const int2 *ent;
     const int *qinv_r;
     const int2 *UPN;
-    const int4 *Lpool;         // {stream position, multiplier, offset in UPN, npn}
+    const int4 *Lpool;         // {stream position << 16 | npn, multiplier, offset in UPN, npn}
     int2 *Sent;
     int *Slen;
     int *Slead;
@@ -38,102 +45,30 @@ struct StreamArgs {
     int cls;                   // index of this class for the per-class counters (NSTREAM0 + size class)
     int *redo_count;           // the hash-table class of the same size: rows this kernel gives up on are appended there
     RowDesc *redo_desc;
+    int2 *fixbuf;              // [row slot][SFIX] duplicates found in the row, merged afterwards by k_stream_fix
+    int *fixcnt;               // [row slot] how many
+    u64d *stamps;              // diagnostic build only: [class][NSTAMP] cycle sums + [class][NSTAMP] wave counts
     int dbg;                   // TIMING ABLATIONS ONLY (diagnostic builds, env SPASM_DBG; results are wrong when non-zero):
-                               // 1 = no Schur stores, 2 = no duplicate check (no LDS traffic), 4 = fix-ups ignored, 8 = no pivot-row loads,
-                               // 32 = 32-bit CAS on the column only
+                               // 1 = no Schur stores, 2 = no duplicate check (no LDS traffic), 4 = fix-ups ignored, 8 = no pivot-row loads
     ZpField F;
 };
 
-constexpr int SRCAP = 192; // entries of a wave's retry list = the worst case of one batch of 3 entries per lane
+constexpr int SLCAP = 64; // entries of a row's list of second-table losers
+constexpr int SFIX = 16;  // duplicates a row may collect before it is handed to the hash-table kernel (a row of 2560 random columns
+                          // out of 10^6 expects 3)
 
-// fix-up entries a row may collect before it is handed to the hash-table kernel
-__host__ __device__ constexpr int stream_fcap(int logt) { return logt <= 11 ? 64 : (1 << logt) / 32; }
+// LDS of one row: first table (4 B x 2^logt), second table (a quarter), 64 B of counters, fix-up list, loser list
+__host__ __device__ constexpr size_t stream_row_bytes(int logt) { return ((size_t)5 << logt) + 64 + (size_t)SFIX * 8 + (size_t)SLCAP * 16; }
+__host__ __device__ constexpr size_t stream_lds_bytes(int logt, int tpr, int wpb) { return tpr == 64 ? stream_row_bytes(logt) * (size_t)wpb : stream_row_bytes(logt); }
 
-__host__ __device__ constexpr size_t stream_lds_bytes(int logt, int tpr, int wpb)
-{
-    const size_t row = ((size_t)8 << logt) + 64 + (size_t)stream_fcap(logt) * 8; // table, misc, fix-up list
-    const size_t retry = (size_t)SRCAP * 16;                                      // per wave
-    return tpr == 64 ? (row + retry) * (size_t)wpb : row + retry * (size_t)wpb;
-}
-
-struct StreamRetry {
-    int4 *buf;
-    int cnt; // wave-uniform
-    __device__ __forceinline__ void bind(unsigned char *p) { buf = (int4 *)p; cnt = 0; }
-    // prim = 0: a clamped copy of an entry (it must find the entry in the table, or put it there, but never report a duplicate)
-    __device__ __forceinline__ void put(int i, int c, int v, int pos, unsigned h, int prim) { buf[i] = make_int4(c, v, (int)(((unsigned)pos << 14) | h), prim); }
-    __device__ __forceinline__ void get(int i, int &c, int &v, int &pos, unsigned &h, int &prim) const
-    {
-        const int4 e = buf[i];
-        c = e.x; v = e.y; pos = (int)((unsigned)e.z >> 14); h = (unsigned)e.z & 0x3fffu; prim = e.w;
-    }
-};
-
-// the row's fix-up list: {owner position << 14 | own position, value}; positions are below 2^14 (largest class: 10240)
+// the row's fix-up list: {owner position << 14 | own position, value}; positions are below 2^14
 __device__ __forceinline__ void stream_fix_push(int *s_nfix, int2 *fix, int fcap, int owner_pos, int pos, int v)
 {
     const int i = atomicAdd(s_nfix, 1);
     if (i < fcap) fix[i] = make_int2((int)(((unsigned)owner_pos << 14) | (unsigned)pos), v);
 }
 
-// a table slot: {column, byte offset of the entry in the Schur row}
-__device__ __forceinline__ u64d stream_pack(int c, int off) { return ((u64d)(unsigned)off << 32) | (u64d)(unsigned)c; }
-
-// slot of a column: multiplicative hash on full-rate 24-bit multiplies (v_mul_lo_u32 is quarter rate); columns that differ
-// only above bit 23 share a slot, which costs probes, never correctness
-template <int LOGT> __device__ __forceinline__ unsigned stream_hash(int c) { return __umul24((unsigned)c, 0x9E3779u); }
-template <int LOGT> __device__ __forceinline__ unsigned stream_slot(unsigned x) { return x >> (32 - LOGT); }
-template <int LOGT> __device__ __forceinline__ unsigned stream_step(unsigned x) { return ((x >> 5) & ((1u << LOGT) - 1)) | 1u; }
-
-// drain the wave's retry list: one entry per lane, probing on from where its first probe left off
-template <int LOGT>
-__device__ __forceinline__ void stream_drain(u64d *tab, StreamRetry &rl, int *s_nfix, int2 *fix, RoundCounters *ctr)
-{
-    constexpr unsigned T = 1u << LOGT;
-    constexpr int FCAP = stream_fcap(LOGT);
-    const int lane = threadIdx.x & 63;
-    for (int b = 0; b < rl.cnt; b += 64) {
-        bool pending = b + lane < rl.cnt;
-        int c = 0, v = 0, pos = 0, prim = 0;
-        unsigned h = 0, st = 1;
-        if (pending) {
-            rl.get(b + lane, c, v, pos, h, prim);
-            st = stream_step<LOGT>(stream_hash<LOGT>(c));
-        }
-        const u64d want = stream_pack(c, pos << 3);
-        for (unsigned round = 0; round < T && __ballot(pending) != 0; round++) {
-            if (pending) {
-                const u64d old = atomicCAS(&tab[h], EMPTY64, want);
-                if (old == EMPTY64 || old == want) pending = false; // (met itself: a lane past the end of a pivot row repeats its last entry)
-                else if ((int)(unsigned)old == c) {
-                    if (prim) stream_fix_push(s_nfix, fix, FCAP, (int)(old >> 35), pos, v);
-                    pending = false;
-                } else h = (h + st) & (T - 1);
-            }
-        }
-        if (pending) atomicAdd(&ctr_shard(ctr)->scatter_overflow, 1);
-    }
-    rl.cnt = 0;
-}
-
-// one entry of one lane, probing until it is in (safe under divergence: no wave-level bookkeeping)
-template <int LOGT>
-__device__ __forceinline__ void stream_add_1(u64d *tab, int *s_nfix, int2 *fix, int c, int v, int pos, RoundCounters *ctr)
-{
-    constexpr unsigned T = 1u << LOGT;
-    constexpr int FCAP = stream_fcap(LOGT);
-    const unsigned x = stream_hash<LOGT>(c);
-    unsigned h = stream_slot<LOGT>(x);
-    const unsigned st = stream_step<LOGT>(x);
-    const u64d want = stream_pack(c, pos << 3);
-    for (unsigned round = 0; round < T; round++) {
-        const u64d old = atomicCAS(&tab[h], EMPTY64, want);
-        if (old == EMPTY64 || old == want) return;
-        if ((int)(unsigned)old == c) { stream_fix_push(s_nfix, fix, FCAP, (int)(old >> 35), pos, v); return; }
-        h = (h + st) & (T - 1);
-    }
-    atomicAdd(&ctr_shard(ctr)->scatter_overflow, 1);
-}
+constexpr unsigned STREAM_K1 = 0x9E3779u, STREAM_K2 = 0x85EBCBu; // odd: c -> c * K mod 2^24 is a bijection
 
 // multiplier * entry as THE balanced residue (it is stored as it stands)
 template <bool SMALL> __device__ __forceinline__ int stream_mul(const ZpField &F, int nm, int y);
@@ -143,13 +78,13 @@ template <> __device__ __forceinline__ int stream_mul<false>(const ZpField &F, i
 __device__ __forceinline__ u64d stream_load_fresh(const u64d *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ------------------------------------------------------------------------------------------------
-// The rare path, run by ONE wave once every store of the row has left its wave (s_waitcnt vmcnt(0) + barrier): apply the
-// fix-ups in global memory, then fill the holes from the end of the row.  `scratch` is the row's table memory (its
-// contents are dead by now): 4 arrays of 2 * FCAP ints.  Returns the row's length; `lead` is recomputed when an entry
-// cancelled to zero (its column leaves the row).
+// Merging the duplicates of a row, by ONE wave, after the fact (k_stream_fix below: a kernel of its own, so that the streaming
+// kernel never waits for its stores): the duplicate's value is added to the owner's entry, then the holes are filled from
+// the end of the row.  `scratch`: 4 arrays of 2 * FCAP ints in LDS.  Returns the row's length; `lead` is recomputed when an
+// entry cancelled to zero (its column leaves the row).
 // ------------------------------------------------------------------------------------------------
 template <int FCAP>
-__device__ __noinline__ int stream_fixup(const ZpField F, const int2 *fix, int nfix, int *scratch, u64d *row, int E, int *lead)
+__device__ __forceinline__ int stream_fixup(const ZpField F, const int2 *fix, int nfix, int *scratch, u64d *row, int E, int *lead)
 {
     constexpr int HC = 2 * FCAP;
     const int lane = threadIdx.x & 63;
@@ -228,166 +163,220 @@ __device__ __noinline__ int stream_fixup(const ZpField F, const int2 *fix, int n
     return n_out;
 }
 
-// What a batch of N probes left unresolved: an entry that met ANOTHER column goes to the wave's retry list, an entry that met
-// its own column under another position is a duplicate and goes to the row's fix-up list.  (An entry that met itself --
-// same column, same position: lanes past the end of a pivot row repeat its last entry -- is in.)  Wave-uniform call.
-template <int LOGT, int N>
-__device__ __forceinline__ void stream_resolve(u64d *tab, StreamRetry &rl, int *s_nfix, int2 *fix, const int (&c)[N], const int (&v)[N],
-                                               const unsigned (&off)[N], const u64d (&old)[N], const bool (&bad)[N], const bool (&prim)[N],
-                                               RoundCounters *ctr)
+
+// A row descriptor (12 dwords) fetched as ONE dword per lane and unpacked with v_readlane when it is needed: a scalar load
+// would sit on lgkmcnt, which every LDS wait of the kernel drains (its whole miss latency was exposed, measured), and twelve
+// registers per descriptor in flight is what the k_scatter form costs.
+__device__ __forceinline__ int stream_desc_load(const RowDesc *p) { return ((const int *)p)[(threadIdx.x & 63) % 12]; }
+__device__ __forceinline__ RowDesc stream_desc_unpack(int v)
 {
-    // prim[j]: this lane holds the entry itself, not a clamped copy of it -- a duplicate column is reported once
-    constexpr int FCAP = stream_fcap(LOGT);
-    constexpr unsigned T = 1u << LOGT;
-    u64d fm[N];
-    int nfail = 0;
-    bool anysame = false;
+    RowDesc d;
+    const unsigned w0 = __builtin_amdgcn_readlane(v, 0), w1 = __builtin_amdgcn_readlane(v, 1), w2 = __builtin_amdgcn_readlane(v, 2),
+                   w3 = __builtin_amdgcn_readlane(v, 3), w4 = __builtin_amdgcn_readlane(v, 4), w5 = __builtin_amdgcn_readlane(v, 5),
+                   w10 = __builtin_amdgcn_readlane(v, 10), w11 = __builtin_amdgcn_readlane(v, 11);
+    d.ent_start = (i64d)(((u64d)w1 << 32) | w0);
+    d.l_start = (i64d)(((u64d)w3 << 32) | w2);
+    d.s_start = (i64d)(((u64d)w5 << 32) | w4);
+    d.len = __builtin_amdgcn_readlane(v, 6);
+    d.llen = __builtin_amdgcn_readlane(v, 7);
+    d.t = __builtin_amdgcn_readlane(v, 8);
+    d.bound = __builtin_amdgcn_readlane(v, 9);
+    d.pmask = (long long)(((u64d)w11 << 32) | w10);
+    return d;
+}
+
+// the two direct-mapped tables of a row
+template <int LOGT> struct StreamTabs {
+    static constexpr int L2 = LOGT - 2;
+    unsigned *t1, *t2;
+    __device__ __forceinline__ void bind(unsigned char *p) { t1 = (unsigned *)p; t2 = t1 + (1 << LOGT); }
+    // first table: the word wanted for (column, position + 1) and its slot
+    __device__ __forceinline__ unsigned want1(int c, int pos1, unsigned &slot) const
+    {
+        const unsigned x = __umul24((unsigned)c, STREAM_K1);
+        slot = (x >> (24 - LOGT)) & ((1u << LOGT) - 1);
+        return (x << 14) | (unsigned)pos1;
+    }
+    __device__ __forceinline__ unsigned want2(int c, int pos1, unsigned &slot) const
+    {
+        const unsigned x = __umul24((unsigned)c, STREAM_K2);
+        slot = (x >> (24 - L2)) & ((1u << L2) - 1);
+        return (x << 14) | (unsigned)pos1;
+    }
+};
+
+// Outcome of an entry's insertion: 0 = in (new, or met itself), otherwise what is left to do.
+//   1: duplicate of the entry at position (old & 0x3fff) - 1        2: lost in both tables
+// `old` is the word found by the CAS that decided.  N entries of a lane go together: all first-table CAS are in flight at
+// once, then the second-table CAS of those that met another column -- two LDS round trips per batch instead of 2 N.
+template <int LOGT, int N>
+__device__ __forceinline__ void stream_insert_n(const StreamTabs<LOGT> &tb, const int (&c)[N], const int (&pos1)[N], unsigned (&old)[N], unsigned (&res)[N])
+{
+    unsigned w1[N], s1[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) w1[j] = tb.want1(c[j], pos1[j], s1[j]);
+#pragma unroll
+    for (int j = 0; j < N; j++) old[j] = atomicCAS(&tb.t1[s1[j]], 0u, w1[j]);
+    bool go2[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        const bool same = bad[j] && (int)(unsigned)old[j] == c[j];
-        anysame |= same && prim[j];
-        fm[j] = __ballot(bad[j] && !same);
-        nfail += __popcll(fm[j]);
+        const unsigned d1 = old[j] ^ w1[j];
+        const bool other = old[j] != 0 && d1 != 0; // the slot holds something else
+        res[j] = (other && d1 < 0x4000u) ? 1u : 0u; // same column, another position
+        go2[j] = other && d1 >= 0x4000u;            // another column: second table
     }
-    if (__ballot(anysame) != 0) {
-#pragma unroll
-        for (int j = 0; j < N; j++)
-            if (prim[j] && bad[j] && (int)(unsigned)old[j] == c[j]) stream_fix_push(s_nfix, fix, FCAP, (int)(old[j] >> 35), (int)(off[j] >> 3), v[j]);
-    }
-    if (nfail == 0) return;
-    if (rl.cnt + nfail > SRCAP) stream_drain<LOGT>(tab, rl, s_nfix, fix, ctr);
-    int at = rl.cnt;
+    unsigned w2[N], o2[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        if (fm[j] & (1ull << (threadIdx.x & 63))) {
-            const unsigned x = stream_hash<LOGT>(c[j]);
-            rl.put(at + __popcll(fm[j] & lanemask_lt()), c[j], v[j], (int)(off[j] >> 3), (stream_slot<LOGT>(x) + stream_step<LOGT>(x)) & (T - 1), prim[j] ? 1 : 0);
+        o2[j] = 0;
+        if (go2[j]) {
+            unsigned s2;
+            w2[j] = tb.want2(c[j], pos1[j], s2);
+            o2[j] = atomicCAS(&tb.t2[s2], 0u, w2[j]);
         }
-        at += __popcll(fm[j]);
     }
-    rl.cnt = at;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (go2[j]) {
+            const unsigned d2 = o2[j] ^ w2[j];
+            old[j] = o2[j];
+            if (o2[j] != 0 && d2 != 0) res[j] = d2 < 0x4000u ? 1u : 2u;
+        }
+    }
+}
+template <int LOGT>
+__device__ __forceinline__ unsigned stream_insert(const StreamTabs<LOGT> &tb, int c, int pos1, unsigned &old)
+{
+    const int cc[1] = {c}, pp[1] = {pos1};
+    unsigned oo[1], rr[1];
+    stream_insert_n<LOGT, 1>(tb, cc, pp, oo, rr);
+    old = oo[0];
+    return rr[0];
+}
+
+// the slow side of an insertion (rare): duplicates to the fix-up list, double losers to the row's list.  prim = false for a
+// clamped copy of an entry: it reports nothing (the entry itself does).
+__device__ __forceinline__ void stream_report(unsigned res, unsigned old, bool prim, int c, int v, int pos1, int *misc, int2 *fix, int fcap, int4 *lst)
+{
+    if (!prim || res == 0) return;
+    if (res == 1) stream_fix_push(misc, fix, fcap, (int)(old & 0x3fffu) - 1, pos1 - 1, v);
+    else {
+        const int i = atomicAdd(misc + 1, 1);
+        if (i < SLCAP) lst[i] = make_int4(c, v, pos1 - 1, 0);
+    }
 }
 
 // TPR = threads cooperating on one row: 64 (a wave per row, WPB independent rows per workgroup, no barriers) or WPB * 64
-// MAXR = rounds of pivot rows whose loads are all issued before any of them is used; round r hands pivot row gg + r * NG
-//        of the row's record list to the 8-lane group gg
-// The common path carries NO per-entry predicate: a lane past the end of its pivot row holds a copy of the row's last entry
-// (clamped index) and simply repeats that entry's store and its CAS -- same bytes to the same address, and a CAS that finds
-// {same column, same position} counts as "in".  Groups past the end of the record list repeat the last record the same way.
+// MAXR = rounds of pivot rows kept in registers per row; round r hands pivot row gg + r * NG of the row's record list to
+//        the 8-lane group gg.  Rows with more records finish in a loop that loads as it goes.
 template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
 {
     constexpr bool WAVE_ROW = (TPR == 64);
     static_assert(WAVE_ROW || TPR == WPB * 64, "a row is owned by one wave or by the whole workgroup");
-    constexpr int T = 1 << LOGT;
+    constexpr int T1 = 1 << LOGT;
     constexpr int G = 8;
     constexpr int NG = TPR / G;
-    constexpr int FCAP = stream_fcap(LOGT);
-    constexpr size_t TABB = (size_t)T * 8, MISCB = 64, FIXB = (size_t)FCAP * 8, RB = (size_t)SRCAP * 16;
-    constexpr size_t SLOT = TABB + MISCB + FIXB + RB; // wave-per-row: everything of a row
-    static_assert((size_t)8 * FCAP * 4 <= TABB, "the fix-up scratch lives in the table");
+    constexpr int FCAP = SFIX;
+    constexpr size_t TABB = (size_t)5 * T1, MISCB = 64, FIXB = (size_t)FCAP * 8;
+    constexpr size_t SLOT = stream_row_bytes(LOGT);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rtid = WAVE_ROW ? lane : tid;
     unsigned char *base = s_raw + (WAVE_ROW ? (size_t)wave * SLOT : 0);
-    u64d *tab = (u64d *)base;
-    // misc[par * 8 + 0] = fix-ups pushed, [par * 8 + 4 + w] = leftmost column seen by wave w (block-per-row); two parities so
-    // that a row's words can be reset while the waves are still reading the previous row's
+    StreamTabs<LOGT> tb;
+    tb.bind(base);
+    // misc[par * 8 + 0] = fix-ups pushed, [+ 1] = losers listed, [+ 4 + w] = leftmost column seen by wave w (block-per-row);
+    // two parities so that a row's words can be reset while the waves are still reading the previous row's
     int *misc = (int *)(base + TABB);
     int2 *fix = (int2 *)(base + TABB + MISCB);
-    StreamRetry rl;
-    rl.bind(base + TABB + MISCB + FIXB + (WAVE_ROW ? 0 : (size_t)wave * RB));
+    int4 *lst = (int4 *)(base + TABB + MISCB + FIXB);
     const int gg = rtid / G, gl = rtid % G;
     const ZpField F = a.F;
 
     const int count = *a.class_count;
     if ((WAVE_ROW ? (int)blockIdx.x * WPB : (int)blockIdx.x) >= count) return;
-    for (int s = rtid * 2; s < T; s += TPR * 2) *(int4 *)(tab + s) = make_int4(-1, -1, -1, -1);
+    for (int s = rtid * 4; s < T1 + T1 / 4; s += TPR * 4) *(int4 *)(tb.t1 + s) = make_int4(0, 0, 0, 0);
     if (rtid < 16) misc[rtid] = (rtid & 7) >= 4 ? INT_MAX : 0;
     __syncthreads();
 
     const int first = WAVE_ROW ? (int)blockIdx.x * WPB + wave : (int)blockIdx.x;
     const int stride = WAVE_ROW ? (int)gridDim.x * WPB : (int)gridDim.x;
+    // statistics: wave-uniform values only (they live in SGPRs)
     u64d c_nnz = 0, c_ent = 0, c_seg = 0;
-    int c_rows = 0, c_fix = 0, c_redo = 0;
+    int c_rows = 0, c_redo = 0;
     int par = 0;
 
-    // ---- pipeline registers: descriptor two rows ahead, first own entries + records one row ahead
-    RowDesc d, dn;
-    d.ent_start = d.l_start = d.s_start = 0; d.len = d.llen = d.t = d.bound = 0; d.pmask = -1;
-    dn = d;
-    int2 own = make_int2(0, 0);
-    int4 rec[MAXR];
+    // ---- pipeline registers: descriptors of this row and the next two (SGPRs; a fourth in flight), records of this row and
+    // the next, pivot-row entries and first own entries of this row.  Everything is loaded unconditionally with clamped
+    // indices (beyond the last row: the last descriptor again), see k_scatter.
+    RowDesc d, dn, dnn;
+    int3 rec[MAXR], rec_n[MAXR]; // {position << 16 | npn, multiplier, offset in UPN} (the 4th word of a record is the hash kernel's)
+    int2 u[MAXR][3];
+    int2 own;
+    auto load_rec = [&](const RowDesc &dd, int r) { return *(const int3 *)&a.Lpool[dd.l_start + min(gg + r * NG, max(dd.llen - 1, 0))]; };
+    auto load_u = [&](const int3 &rc, int j) {
+        const int last = max((rc.x & 0xffff) - 1, 0);
+        return a.UPN[(size_t)(unsigned)rc.z + (unsigned)min(gl + j * G, last)];
+    };
+    {
+        d = stream_desc_unpack(stream_desc_load(a.desc + min(first, count - 1)));
+        dn = stream_desc_unpack(stream_desc_load(a.desc + min(first + stride, count - 1)));
+        dnn = stream_desc_unpack(stream_desc_load(a.desc + min(first + 2 * stride, count - 1)));
 #pragma unroll
-    for (int r = 0; r < MAXR; r++) rec[r] = make_int4(0, 0, 0, 0);
-    if (first < count) {
-        d = desc_unpack(desc_load(&a.desc[first]));
+        for (int r = 0; r < MAXR; r++) { rec[r] = load_rec(d, r); rec_n[r] = load_rec(dn, r); }
         own = a.ent[d.ent_start + min(lane, max(d.len - 1, 0))];
-        const int lastrec = max(d.llen - 1, 0);
 #pragma unroll
-        for (int r = 0; r < MAXR; r++) rec[r] = a.Lpool[d.l_start + min(gg + r * NG, lastrec)];
+        for (int r = 0; r < MAXR; r++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) u[r][j] = load_u(rec[r], j);
     }
-    if (first + stride < count) dn = desc_unpack(desc_load(&a.desc[first + stride]));
 
+#ifdef SPASM_STAMPS
+    u64d st_sum[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64d st_last = stamp_now();
+#endif
     for (int w = first; w < count; w += stride) {
-        const DescRegs dnn_regs = desc_load(&a.desc[min(w + 2 * stride, count - 1)]);
+        // ---- (1) the loads of the rows ahead
+        const int d3_reg = stream_desc_load(a.desc + min(w + 3 * stride, count - 1));
+        int3 rec_nn[MAXR];
+        int2 u_n[MAXR][3];
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) rec_nn[r] = load_rec(dnn, r);
+#pragma unroll
+        for (int r = 0; r < MAXR; r++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                u_n[r][j] = make_int2(gl + j * G + r * 1024 + gg * 32, 1);
+                if (!SCATTER_DBG(a, 8)) u_n[r][j] = load_u(rec_n[r], j);
+            }
+        const int2 own_n = a.ent[dn.ent_start + min(lane, max(dn.len - 1, 0))];
         const int ln = d.len, ll = d.llen;
-        int *const s_nfix = misc + par * 8;
-        // ---- every load of the row: qinv of the own entry (first 64, wave 0), entries of the pivot rows (clamped indices)
+        int *const mrow = misc + par * 8;
         int q_own = 0;
         if (d.pmask >= 0) q_own = ((d.pmask >> lane) & 1) ? 0 : -1;
         else if (lane < ln) q_own = a.qinv_r[own.x];
-        int2 u[MAXR][3];
-        bool gok[MAXR];         // the group's record has entries (a pivot row may consist of its pivot alone)
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) {
-            const int np = rec[r].w;
-            gok[r] = np > 0 && rec[r].y != 0;
-            const int2 *up = a.UPN + (unsigned)rec[r].z;
-            const int last = max(np - 1, 0);
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const int idx = min(gl + j * G, last);
-                u[r][j] = make_int2(idx + r * 1024 + gg * 32, 1);
-                if (!SCATTER_DBG(a, 8)) u[r][j] = up[idx];
-            }
-        }
-        // ---- stage-1 data of the NEXT row (its first own entries, its records), behind this row's loads: they have long
-        // arrived when this row is done.  Unconditional and clamped (see k_scatter): after the last row `dn` is the last
-        // descriptor again.
-        int2 own_n;
-        int4 rec_n[MAXR];
-        {
-            own_n = a.ent[dn.ent_start + min(lane, max(dn.len - 1, 0))];
-            const int lastrec = max(dn.llen - 1, 0);
-#pragma unroll
-            for (int r = 0; r < MAXR; r++) rec_n[r] = a.Lpool[dn.l_start + min(gg + r * NG, lastrec)];
-        }
         unsigned char *const rowp = (unsigned char *)(a.Sent + d.s_start);
         int mylead = INT_MAX;
         int nN = 0;
-        // ---- the row's own entries on non-pivot columns: stream positions 0 .. nN-1, one wave (their rank is a ballot)
+        unsigned rare = 0; // any lane, any entry: something to report
+        STAMP(0); // issue of the loads of the rows ahead
+        // ---- (2) the row's own entries on non-pivot columns: stream positions 0 .. nN-1, one wave (their rank is a ballot)
         if (WAVE_ROW || wave == 0) {
             {
                 const bool nonpiv = lane < ln && q_own < 0;
                 const u64d m = __ballot(nonpiv);
-                const unsigned off = (unsigned)__popcll(m & lanemask_lt()) << 3;
-                u64d old = EMPTY64;
-                const u64d want = stream_pack(own.x, (int)off);
+                const int pos1 = __popcll(m & lanemask_lt()) + 1;
                 if (nonpiv) {
-                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)own.y << 32) | (unsigned)own.x, (long long *)(rowp + off));
+                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)own.y << 32) | (unsigned)own.x, (long long *)(rowp + ((unsigned)(pos1 - 1) << 3)));
                     mylead = min(mylead, own.x);
-                    if (!SCATTER_DBG(a, 2)) old = atomicCAS(&tab[stream_slot<LOGT>(stream_hash<LOGT>(own.x))], EMPTY64, want);
-                }
-                const bool bad[1] = {old != EMPTY64 && old != want};
-                if (__ballot(bad[0]) != 0) {
-                    const int oc[1] = {own.x}, ov[1] = {own.y};
-                    const unsigned oo[1] = {off};
-                    const u64d ol[1] = {old};
-                    const bool pr[1] = {true};
-                    stream_resolve<LOGT, 1>(tab, rl, s_nfix, fix, oc, ov, oo, ol, bad, pr, a.ctr);
+                    if (!SCATTER_DBG(a, 2)) {
+                        unsigned old;
+                        const unsigned res = stream_insert<LOGT>(tb, own.x, pos1, old);
+                        if (res) stream_report(res, old, true, own.x, own.y, pos1, mrow, fix, FCAP, lst);
+                    }
                 }
                 nN = __popcll(m);
             }
@@ -400,170 +389,231 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
                     nonpiv = a.qinv_r[e.x] < 0;
                 }
                 const u64d m = __ballot(nonpiv);
-                const unsigned off = (unsigned)(nN + __popcll(m & lanemask_lt())) << 3;
-                u64d old = EMPTY64;
-                const u64d want = stream_pack(e.x, (int)off);
+                const int pos1 = nN + __popcll(m & lanemask_lt()) + 1;
                 if (nonpiv) {
-                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)e.y << 32) | (unsigned)e.x, (long long *)(rowp + off));
+                    __builtin_nontemporal_store(((long long)(unsigned)e.y << 32) | (unsigned)e.x, (long long *)(rowp + ((unsigned)(pos1 - 1) << 3)));
                     mylead = min(mylead, e.x);
-                    if (!SCATTER_DBG(a, 2)) old = atomicCAS(&tab[stream_slot<LOGT>(stream_hash<LOGT>(e.x))], EMPTY64, want);
-                }
-                const bool bad[1] = {old != EMPTY64 && old != want};
-                if (__ballot(bad[0]) != 0) {
-                    const int oc[1] = {e.x}, ov[1] = {e.y};
-                    const unsigned oo[1] = {off};
-                    const u64d ol[1] = {old};
-                    const bool pr[1] = {true};
-                    stream_resolve<LOGT, 1>(tab, rl, s_nfix, fix, oc, ov, oo, ol, bad, pr, a.ctr);
+                    unsigned old;
+                    const unsigned res = stream_insert<LOGT>(tb, e.x, pos1, old);
+                    if (res) stream_report(res, old, true, e.x, e.y, pos1, mrow, fix, FCAP, lst);
                 }
                 nN += __popcll(m);
             }
         }
-        // ---- the pivot rows: multiply, store at the entry's stream position, one CAS for the duplicate check
+        STAMP(1); // own entries
+        // ---- (3) the pivot rows: multiply, store at the entry's stream position, CAS for the duplicate check
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
             if (r * NG < ll) { // scalar: there are records for this round
+                const int np = rec[r].x & 0xffff;
                 const int nm = -rec[r].y;
-                const bool allok = __ballot(!gok[r]) == 0;
-                int bc[3], bv[3];
-                unsigned uoff[3]; // byte offset of the entry in the Schur row
-                u64d old[3], want[3];
-                bool bad[3];
-                const int last = max(rec[r].w - 1, 0);
+                const int last = max(np - 1, 0);
+                const int pre1 = (int)((unsigned)rec[r].x >> 16) + 1;
+                // a pivot row may consist of its pivot alone: such a group (and a group that repeats such a record) sits out
+                const bool gok = np > 0;
+                int bc[3], bv[3], bp[3];
+                unsigned old[3], res[3];
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     bc[j] = u[r][j].x;
                     bv[j] = stream_mul<SMALL>(F, nm, u[r][j].y);
-                    uoff[j] = (unsigned)(rec[r].x + min(gl + j * G, last)) << 3;
-                    want[j] = stream_pack(bc[j], (int)uoff[j]);
-                    old[j] = EMPTY64;
+                    bp[j] = pre1 + min(gl + j * G, last);
+                    res[j] = 0;
+                    old[j] = 0;
                 }
-                if (allok) {
+                if (gok) {
 #pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        if (!SCATTER_DBG(a, 2)) old[j] = atomicCAS(&tab[stream_slot<LOGT>(stream_hash<LOGT>(bc[j]))], EMPTY64, want[j]);
-                        if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)bv[j] << 32) | (unsigned)bc[j], (long long *)(rowp + uoff[j]));
-                    }
-                    mylead = min(mylead, min(bc[0], min(bc[1], bc[2])));
-                } else if (gok[r]) { // a group without entries in this round: the others go on under their own predicate
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        old[j] = atomicCAS(&tab[stream_slot<LOGT>(stream_hash<LOGT>(bc[j]))], EMPTY64, want[j]);
-                        __builtin_nontemporal_store(((long long)(unsigned)bv[j] << 32) | (unsigned)bc[j], (long long *)(rowp + uoff[j]));
-                    }
+                    for (int j = 0; j < 3; j++)
+                        if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)bv[j] << 32) | (unsigned)bc[j], (long long *)(rowp + ((unsigned)(bp[j] - 1) << 3)));
+                    if (!SCATTER_DBG(a, 2)) stream_insert_n<LOGT, 3>(tb, bc, bp, old, res);
                     mylead = min(mylead, min(bc[0], min(bc[1], bc[2])));
                 }
-#pragma unroll
-                for (int j = 0; j < 3; j++) bad[j] = old[j] != EMPTY64 && old[j] != want[j];
-                if (__ballot(bad[0] | bad[1] | bad[2]) != 0) {
+                if (__ballot((res[0] | res[1] | res[2]) != 0) != 0) { // rare: duplicates, double losers
                     const bool gprim = gg + r * NG < ll;
-                    const bool pr[3] = {gprim && gl <= last, gprim && gl + G <= last, gprim && gl + 2 * G <= last};
-                    stream_resolve<LOGT, 3>(tab, rl, s_nfix, fix, bc, bv, uoff, old, bad, pr, a.ctr);
+#pragma unroll
+                    for (int j = 0; j < 3; j++) stream_report(res[j], old[j], gprim && gl + j * G <= last, bc[j], bv[j], bp[j], mrow, fix, FCAP, lst);
                 }
-                if (__ballot(gok[r] && rec[r].w > 3 * G) != 0) { // pivot rows longer than 24 entries
+                if (__ballot(np > 3 * G) != 0) { // pivot rows longer than 24 entries
                     const int2 *up = a.UPN + (unsigned)rec[r].z;
-                    const int np = gok[r] ? rec[r].w : 0;
-                    for (int k = gl + 3 * G; k < np; k += G) {
+                    const bool gprim = gg + r * NG < ll;
+                    for (int k = gl + 3 * G; k < np && gprim; k += G) {
                         const int2 uu = up[k];
                         const int vv = stream_mul<SMALL>(F, nm, uu.y);
-                        const int pp = rec[r].x + k;
-                        __builtin_nontemporal_store(((long long)(unsigned)vv << 32) | (unsigned)uu.x, (long long *)(rowp + ((unsigned)pp << 3)));
+                        const int pp1 = pre1 + k;
+                        __builtin_nontemporal_store(((long long)(unsigned)vv << 32) | (unsigned)uu.x, (long long *)(rowp + ((unsigned)(pp1 - 1) << 3)));
                         mylead = min(mylead, uu.x);
-                        stream_add_1<LOGT>(tab, s_nfix, fix, uu.x, vv, pp, a.ctr);
+                        unsigned o2;
+                        const unsigned r2 = stream_insert<LOGT>(tb, uu.x, pp1, o2);
+                        if (r2) stream_report(r2, o2, true, uu.x, vv, pp1, mrow, fix, FCAP, lst);
                     }
                 }
             }
         }
-        // ---- more pivot rows than NG * MAXR: one round at a time, per-lane probing (wave-uniform trip count)
+        // ---- more pivot rows than NG * MAXR: one round at a time, loaded as it goes (wave-uniform trip count)
         for (int e0 = MAXR * NG; e0 < ll; e0 += NG) {
             const int e = e0 + gg;
             int4 le = make_int4(0, 0, 0, 0);
             if (e < ll) le = a.Lpool[d.l_start + e];
-            const int np = le.y != 0 ? le.w : 0;
+            const int np = le.x & 0xffff;
             const int nm = -le.y;
+            const int pre1 = (int)((unsigned)le.x >> 16) + 1;
             const int2 *up = a.UPN + (unsigned)le.z;
             for (int k = gl; k < np; k += G) {
                 const int2 uu = up[k];
                 const int vv = stream_mul<SMALL>(F, nm, uu.y);
-                const int pp = le.x + k;
-                __builtin_nontemporal_store(((long long)(unsigned)vv << 32) | (unsigned)uu.x, (long long *)(rowp + ((unsigned)pp << 3)));
+                const int pp1 = pre1 + k;
+                __builtin_nontemporal_store(((long long)(unsigned)vv << 32) | (unsigned)uu.x, (long long *)(rowp + ((unsigned)(pp1 - 1) << 3)));
                 mylead = min(mylead, uu.x);
-                stream_add_1<LOGT>(tab, s_nfix, fix, uu.x, vv, pp, a.ctr);
+                unsigned o2;
+                const unsigned r2 = stream_insert<LOGT>(tb, uu.x, pp1, o2);
+                if (r2) stream_report(r2, o2, true, uu.x, vv, pp1, mrow, fix, FCAP, lst);
             }
         }
-        stream_drain<LOGT>(tab, rl, s_nfix, fix, a.ctr);
+        STAMP(2); // rounds of pivot rows
         const int t_cur = d.t, E = d.bound, ln_cur = ln;
-        // ---- end of the row: leftmost column, duplicates
+        // ---- (4) end of the row: leftmost column, losers of both tables, duplicates
         mylead = wave_min_i32(mylead);
         int lead_out = mylead;
         if (!WAVE_ROW) {
-            if (lane == 0) misc[par * 8 + 4 + wave] = mylead;
+            if (lane == 0) mrow[4 + wave] = mylead;
             lds_barrier();
 #pragma unroll
-            for (int w2 = 0; w2 < WPB; w2++) lead_out = min(lead_out, misc[par * 8 + 4 + w2]);
+            for (int w2 = 0; w2 < WPB; w2++) lead_out = min(lead_out, mrow[4 + w2]);
         }
-        const int nfix = SCATTER_DBG(a, 4) ? 0 : *(volatile int *)s_nfix;
-        int n_out = E;
-        bool redo = false;
-        if (nfix != 0) { // uniform over the row's team
-            redo = nfix > FCAP;
-            if (!redo) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores of the row have left
-                if (!WAVE_ROW) lds_barrier();
-                if (WAVE_ROW || wave == 0) n_out = stream_fixup<FCAP>(F, fix, nfix, (int *)tab, (u64d *)rowp, E, &lead_out);
-                if (!WAVE_ROW) lds_barrier(); // the scratch in the table is dead: it may be cleared
+        const int nlist = __builtin_amdgcn_readfirstlane(*(volatile int *)(mrow + 1));
+        bool redo = nlist > SLCAP;
+        if (nlist != 0 && !redo && (WAVE_ROW || wave == 0)) {
+            // entries that lost in both tables are in neither: compare them among themselves (a handful)
+            for (int b = 0; b < nlist; b += 64) {
+                const int i = b + lane;
+                int4 me = make_int4(-1, 0, -1, 0);
+                if (i < nlist) me = lst[i];
+                int owner = -1;
+                for (int j = 0; j < nlist; j++) {
+                    const int4 o = lst[j];
+                    if (j < i && owner < 0 && o.x == me.x && o.z != me.z) owner = o.z;
+                }
+                if (owner >= 0) stream_fix_push(mrow, fix, FCAP, owner, me.z, me.y);
             }
         }
-        if (rtid == 0) {
+        if (!WAVE_ROW && nlist != 0) lds_barrier(); // (uniform over the team)
+        const int nfix = SCATTER_DBG(a, 4) ? 0 : __builtin_amdgcn_readfirstlane(*(volatile int *)mrow);
+        const int n_out = E; // duplicates are merged by k_stream_fix, which corrects the length then
+        redo = redo || nfix > FCAP;
+        if (WAVE_ROW || wave == 0) {
             if (redo) {
-                // too many duplicate columns for the fix-up list: the hash-table kernel of this size class takes the row
-                const int at = atomicAdd(a.redo_count, 1);
-                a.redo_desc[at] = d;
+                // too many duplicate columns for the lists: the hash-table kernel of this size class takes the row
+                if (lane == 0) {
+                    const int at = atomicAdd(a.redo_count, 1);
+                    a.redo_desc[at] = d;
+                }
                 c_redo += 1;
             } else {
-                a.Slen[t_cur] = n_out;
-                a.Slead[t_cur] = n_out > 0 ? lead_out : INT_MAX;
+                if (lane < nfix) a.fixbuf[(size_t)t_cur * SFIX + lane] = fix[lane];
+                if (lane == 0) {
+                    a.Slen[t_cur] = n_out;
+                    a.Slead[t_cur] = n_out > 0 ? lead_out : INT_MAX;
+                    if (nfix) a.fixcnt[t_cur] = nfix; // (zero from the binning pass otherwise)
+                }
                 c_nnz += (u64d)n_out;
                 c_rows += n_out > 0;
                 // entries streamed: the own entries + the non-pivot parts of the applied pivot rows (= E - nN, the records of the
                 // combine kernel all carry a multiplier); segments: the row + one per record
                 c_ent += (u64d)ln_cur + (u64d)(E - nN);
                 c_seg += 1 + (u64d)ll;
-                c_fix += nfix;
             }
         }
-        // ---- reset: the table, and the other parity's words (nobody reads them any more: every wave is past its barrier)
-        for (int s = rtid * 2; s < T; s += TPR * 2) *(int4 *)(tab + s) = make_int4(-1, -1, -1, -1);
+        STAMP(3); // end of the row: lead, lists, fix-ups
+        // ---- (5) reset: the tables, and the other parity's words (nobody reads them any more: every wave is past its barrier)
+        for (int s = rtid * 4; s < T1 + T1 / 4; s += TPR * 4) *(int4 *)(tb.t1 + s) = make_int4(0, 0, 0, 0);
         if (WAVE_ROW) {
-            if (lane == 0) *s_nfix = 0;
+            if (lane < 2) mrow[lane] = 0;
             __builtin_amdgcn_wave_barrier();
         } else {
             par ^= 1;
             if (rtid < 8) misc[par * 8 + rtid] = rtid >= 4 ? INT_MAX : 0;
             lds_barrier();
         }
+        STAMP(4); // table reset + barrier
+        // ---- (6) rotate the pipeline
         d = dn;
-        dn = desc_unpack(dnn_regs);
+        dn = dnn;
+        dnn = stream_desc_unpack(d3_reg);
         own = own_n;
 #pragma unroll
-        for (int r = 0; r < MAXR; r++) rec[r] = rec_n[r];
+        for (int r = 0; r < MAXR; r++) {
+            rec[r] = rec_n[r];
+            rec_n[r] = rec_nn[r];
+#pragma unroll
+            for (int j = 0; j < 3; j++) u[r][j] = u_n[r][j];
+        }
+#ifdef SPASM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(5); // rotation: waits for the loads issued at the top
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        c_ent += __shfl_xor(c_ent, o);
-        c_seg += __shfl_xor(c_seg, o);
-        c_nnz += __shfl_xor(c_nnz, o);
-        c_rows += __shfl_xor(c_rows, o);
-        c_fix += __shfl_xor(c_fix, o);
-        c_redo += __shfl_xor(c_redo, o);
+#ifdef SPASM_STAMPS
+    if (lane == 0 && a.stamps) {
+        for (int i = 0; i < NSTAMP; i++) atomicAdd(&a.stamps[(size_t)a.cls * 2 * NSTAMP + i], st_sum[i]);
+        atomicAdd(&a.stamps[(size_t)a.cls * 2 * NSTAMP + NSTAMP], 1ull);
     }
-    if (lane == 0) {
+#endif
+    if (lane == 0 && (WAVE_ROW || wave == 0)) {
         if (c_nnz) atomicAdd(&ctr_shard(a.ctr)->nnz_out, c_nnz);
         if (c_rows) atomicAdd(&ctr_shard(a.ctr)->nonempty_out, c_rows);
-        if (c_fix) atomicAdd(&ctr_shard(a.ctr)->stream_fix, c_fix);
         if (c_redo) atomicAdd(&ctr_shard(a.ctr)->stream_redo, c_redo);
         if (c_ent | c_seg) {
             atomicAdd(&ctr_shard(a.ctr)->class_ent[a.cls], c_ent);
             atomicAdd(&ctr_shard(a.ctr)->class_seg[a.cls], c_seg);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The duplicates the streaming kernels found, merged row by row: a wave looks at 64 row slots and works through those that
+// have any (about a third of the rows of 1000 entries, a few percent of the short ones).
+// ------------------------------------------------------------------------------------------------
+struct StreamFixArgs {
+    int nrows;
+    const int *fixcnt;
+    const int2 *fixbuf;
+    const i64d *sstart;
+    int2 *Sent;
+    int *Slen;
+    int *Slead;
+    RoundCounters *ctr;
+    ZpField F;
+};
+
+__global__ __launch_bounds__(256) void k_stream_fix(StreamFixArgs a)
+{
+    __shared__ int s_scratch[4][8 * SFIX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t0 = (blockIdx.x * 4 + wave) * 64;
+    if (t0 >= a.nrows) return;
+    const int mine = t0 + lane < a.nrows ? a.fixcnt[t0 + lane] : 0;
+    u64d m = __ballot(mine > 0);
+    u64d holes = 0;
+    int emptied = 0, merged = 0;
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int t = t0 + l;
+        const int n = __builtin_amdgcn_readlane(mine, l);
+        const int E = a.Slen[t];
+        int lead = a.Slead[t];
+        const int n_out = stream_fixup<SFIX>(a.F, a.fixbuf + (size_t)t * SFIX, n, s_scratch[wave], (u64d *)(a.Sent + a.sstart[t]), E, &lead);
+        if (lane == 0) {
+            a.Slen[t] = n_out;
+            a.Slead[t] = n_out > 0 ? lead : INT_MAX;
+        }
+        holes += (u64d)(E - n_out);
+        emptied += (n_out == 0 && E > 0);
+        merged += n;
+    }
+    if (lane == 0 && merged) {
+        atomicAdd(&ctr_shard(a.ctr)->nnz_out, (u64d)0 - holes); // (mod 2^64: the streaming kernel counted the stream lengths)
+        if (emptied) atomicAdd(&ctr_shard(a.ctr)->nonempty_out, -emptied);
+        atomicAdd(&ctr_shard(a.ctr)->stream_fix, merged);
     }
 }
