@@ -838,7 +838,7 @@ struct Round {
             fa.Slead = S.lead.p;
             fa.ctr = ctr.p;
             fa.F = F;
-            hipLaunchKernelGGL(k_stream_fix, dim3(cdiv(nrows, 256)), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k_stream_fix, dim3(cdiv(nrows, 64)), dim3(256), 0, s, fa);
             HIPCHK(hipGetLastError());
         };
         auto launch_big = [&](hipStream_t s) {

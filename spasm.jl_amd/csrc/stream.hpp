@@ -185,6 +185,15 @@ __device__ __forceinline__ RowDesc stream_desc_unpack(int v)
     return d;
 }
 
+// c * K mod 2^32 on the full-rate 24-bit multiplier.  As inline assembly because the compiler folds the shift that follows
+// ((x << 14) | pos) into the constant and then needs v_mul_lo_u32 (quarter rate) for the 38-bit K << 14.
+__device__ __forceinline__ unsigned stream_mul24(int c, unsigned k)
+{
+    unsigned x;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(x) : "v"(c), "s"(k));
+    return x;
+}
+
 // the two direct-mapped tables of a row
 template <int LOGT> struct StreamTabs {
     static constexpr int L2 = LOGT - 2;
@@ -193,57 +202,49 @@ template <int LOGT> struct StreamTabs {
     // first table: the word wanted for (column, position + 1) and its slot
     __device__ __forceinline__ unsigned want1(int c, int pos1, unsigned &slot) const
     {
-        const unsigned x = __umul24((unsigned)c, STREAM_K1);
-        slot = (x >> (24 - LOGT)) & ((1u << LOGT) - 1);
+        const unsigned x = stream_mul24(c, STREAM_K1);
+        slot = __builtin_amdgcn_ubfe(x, 24 - LOGT, LOGT);
         return (x << 14) | (unsigned)pos1;
     }
     __device__ __forceinline__ unsigned want2(int c, int pos1, unsigned &slot) const
     {
-        const unsigned x = __umul24((unsigned)c, STREAM_K2);
-        slot = (x >> (24 - L2)) & ((1u << L2) - 1);
+        const unsigned x = stream_mul24(c, STREAM_K2);
+        slot = __builtin_amdgcn_ubfe(x, 24 - L2, L2);
         return (x << 14) | (unsigned)pos1;
     }
 };
 
-// Outcome of an entry's insertion: 0 = in (new, or met itself), otherwise what is left to do.
-//   1: duplicate of the entry at position (old & 0x3fff) - 1        2: lost in both tables
-// `old` is the word found by the CAS that decided.  N entries of a lane go together: all first-table CAS are in flight at
-// once, then the second-table CAS of those that met another column -- two LDS round trips per batch instead of 2 N.
+// Insertion of N entries of a lane: all first-table CAS are in flight at once, then the second-table CAS of those that met
+// another column -- two LDS round trips per batch instead of 2 N.  Outcome per entry, as ONE word and without branches:
+//   t = 0 if the CAS found the slot empty, else (word found) ^ (word wanted):  t = 0  the entry is in (new, or it met itself: a
+//   lane past the end of a pivot row repeats its last entry);  0 < t < 2^14  same column under another position: a duplicate;
+//   t >= 2^14  another column.
+// left[j] = 0 when entry j needs nothing more; otherwise the rare side decodes it with stream_outcome().
 template <int LOGT, int N>
-__device__ __forceinline__ void stream_insert_n(const StreamTabs<LOGT> &tb, const int (&c)[N], const int (&pos1)[N], unsigned (&old)[N], unsigned (&res)[N])
+__device__ __forceinline__ void stream_insert_n(const StreamTabs<LOGT> &tb, const int (&c)[N], const int (&pos1)[N], unsigned (&old)[N], unsigned (&left)[N])
 {
     unsigned w1[N], s1[N];
 #pragma unroll
     for (int j = 0; j < N; j++) w1[j] = tb.want1(c[j], pos1[j], s1[j]);
 #pragma unroll
     for (int j = 0; j < N; j++) old[j] = atomicCAS(&tb.t1[s1[j]], 0u, w1[j]);
-    bool go2[N];
+    unsigned t1[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) t1[j] = old[j] == 0 ? 0u : old[j] ^ w1[j];
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        const unsigned d1 = old[j] ^ w1[j];
-        const bool other = old[j] != 0 && d1 != 0; // the slot holds something else
-        res[j] = (other && d1 < 0x4000u) ? 1u : 0u; // same column, another position
-        go2[j] = other && d1 >= 0x4000u;            // another column: second table
-    }
-    unsigned w2[N], o2[N];
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        o2[j] = 0;
-        if (go2[j]) {
+        left[j] = t1[j];
+        if (t1[j] >= 0x4000u) { // another column in the slot: second table
             unsigned s2;
-            w2[j] = tb.want2(c[j], pos1[j], s2);
-            o2[j] = atomicCAS(&tb.t2[s2], 0u, w2[j]);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        if (go2[j]) {
-            const unsigned d2 = o2[j] ^ w2[j];
-            old[j] = o2[j];
-            if (o2[j] != 0 && d2 != 0) res[j] = d2 < 0x4000u ? 1u : 2u;
+            const unsigned w2 = tb.want2(c[j], pos1[j], s2);
+            const unsigned o2 = atomicCAS(&tb.t2[s2], 0u, w2);
+            old[j] = o2;
+            left[j] = o2 == 0 ? 0u : o2 ^ w2;
         }
     }
 }
+// what is left of an insertion: 0 nothing, 1 duplicate of the entry at position (old & 0x3fff) - 1, 2 lost in both tables
+__device__ __forceinline__ unsigned stream_outcome(unsigned left) { return left == 0 ? 0u : (left < 0x4000u ? 1u : 2u); }
 template <int LOGT>
 __device__ __forceinline__ unsigned stream_insert(const StreamTabs<LOGT> &tb, int c, int pos1, unsigned &old)
 {
@@ -251,7 +252,7 @@ __device__ __forceinline__ unsigned stream_insert(const StreamTabs<LOGT> &tb, in
     unsigned oo[1], rr[1];
     stream_insert_n<LOGT, 1>(tb, cc, pp, oo, rr);
     old = oo[0];
-    return rr[0];
+    return stream_outcome(rr[0]);
 }
 
 // the slow side of an insertion (rare): duplicates to the fix-up list, double losers to the row's list.  prim = false for a
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
                 if (__ballot((res[0] | res[1] | res[2]) != 0) != 0) { // rare: duplicates, double losers
                     const bool gprim = gg + r * NG < ll;
 #pragma unroll
-                    for (int j = 0; j < 3; j++) stream_report(res[j], old[j], gprim && gl + j * G <= last, bc[j], bv[j], bp[j], mrow, fix, FCAP, lst);
+                    for (int j = 0; j < 3; j++) stream_report(stream_outcome(res[j]), old[j], gprim && gl + j * G <= last, bc[j], bv[j], bp[j], mrow, fix, FCAP, lst);
                 }
                 if (__ballot(np > 3 * G) != 0) { // pivot rows longer than 24 entries
                     const int2 *up = a.UPN + (unsigned)rec[r].z;
@@ -480,26 +481,30 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
 #pragma unroll
             for (int w2 = 0; w2 < WPB; w2++) lead_out = min(lead_out, mrow[4 + w2]);
         }
-        const int nlist = __builtin_amdgcn_readfirstlane(*(volatile int *)(mrow + 1));
-        bool redo = nlist > SLCAP;
-        if (nlist != 0 && !redo && (WAVE_ROW || wave == 0)) {
-            // entries that lost in both tables are in neither: compare them among themselves (a handful)
-            for (int b = 0; b < nlist; b += 64) {
-                const int i = b + lane;
-                int4 me = make_int4(-1, 0, -1, 0);
-                if (i < nlist) me = lst[i];
-                int owner = -1;
-                for (int j = 0; j < nlist; j++) {
-                    const int4 o = lst[j];
-                    if (j < i && owner < 0 && o.x == me.x && o.z != me.z) owner = o.z;
-                }
-                if (owner >= 0) stream_fix_push(mrow, fix, FCAP, owner, me.z, me.y);
-            }
-        }
-        if (!WAVE_ROW && nlist != 0) lds_barrier(); // (uniform over the team)
-        const int nfix = SCATTER_DBG(a, 4) ? 0 : __builtin_amdgcn_readfirstlane(*(volatile int *)mrow);
+        // the lists are wave 0's business from here on (the other waves go on to reset the tables: nothing below touches those)
+        bool redo = false;
+        int nfix = 0;
         const int n_out = E; // duplicates are merged by k_stream_fix, which corrects the length then
-        redo = redo || nfix > FCAP;
+        if (WAVE_ROW || wave == 0) {
+            const int nlist = __builtin_amdgcn_readfirstlane(*(volatile int *)(mrow + 1));
+            redo = nlist > SLCAP;
+            if (nlist != 0 && !redo) {
+                // entries that lost in both tables are in neither: compare them among themselves (a handful)
+                for (int b = 0; b < nlist; b += 64) {
+                    const int i = b + lane;
+                    int4 me = make_int4(-1, 0, -1, 0);
+                    if (i < nlist) me = lst[i];
+                    int owner = -1;
+                    for (int j = 0; j < nlist; j++) {
+                        const int4 o = lst[j];
+                        if (j < i && owner < 0 && o.x == me.x && o.z != me.z) owner = o.z;
+                    }
+                    if (owner >= 0) stream_fix_push(mrow, fix, FCAP, owner, me.z, me.y);
+                }
+            }
+            nfix = SCATTER_DBG(a, 4) ? 0 : __builtin_amdgcn_readfirstlane(*(volatile int *)mrow);
+            redo = redo || nfix > FCAP;
+        }
         if (WAVE_ROW || wave == 0) {
             if (redo) {
                 // too many duplicate columns for the lists: the hash-table kernel of this size class takes the row
@@ -589,9 +594,10 @@ __global__ __launch_bounds__(256) void k_stream_fix(StreamFixArgs a)
 {
     __shared__ int s_scratch[4][8 * SFIX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t0 = (blockIdx.x * 4 + wave) * 64;
+    // 16 row slots per wave: the rows with duplicates are worked through one after the other, each a chain of global round trips
+    const int t0 = (blockIdx.x * 4 + wave) * 16;
     if (t0 >= a.nrows) return;
-    const int mine = t0 + lane < a.nrows ? a.fixcnt[t0 + lane] : 0;
+    const int mine = (lane < 16 && t0 + lane < a.nrows) ? a.fixcnt[t0 + lane] : 0;
     u64d m = __ballot(mine > 0);
     u64d holes = 0;
     int emptied = 0, merged = 0;
