@@ -133,33 +133,35 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
 
 // grid = min(rows, resident workgroups): the kernels walk their row list with a grid stride, and a workgroup that is not resident
 // from the start would do its share after everybody else (the LDS bound alone can be above what the registers admit)
-template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW = 1> void launch_stream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
+template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1> void launch_wstream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
     static int per_cu = 0;
     if (!per_cu) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_stream<LOGT, TPR, WPB, MAXR, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_stream<LOGT, TPR, WPB, MAXR, SMALL, MINW>, WPB * 64, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>, WPB * 64, lds));
         per_cu = std::max(nb, 1);
     }
     const int rows_per_block = TPR == 64 ? WPB : 1;
     const int grid = std::max(1, std::min((nrows + rows_per_block - 1) / rows_per_block, num_cu * per_cu));
-    hipLaunchKernelGGL((k_stream<LOGT, TPR, WPB, MAXR, SMALL, MINW>), dim3(grid), dim3(WPB * 64), lds, s, a);
+    hipLaunchKernelGGL((k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>), dim3(grid), dim3(WPB * 64), lds, s, a);
     HIPCHK(hipGetLastError());
 }
 
 // the streaming twins of the hash-table classes 0..4 (row bounds up to 160 << c): first table of 512 << c words (at most 5/16
-// full), same threads per row as the hash class
+// full); a wave per row up to 640 entries, then 2 and 4 waves
 const int kNumStreamClasses = 5;
 inline int stream_logt(int c) { return 9 + c; }
+inline int stream_tpr(int c) { return c <= 2 ? 64 : (c == 3 ? 128 : 256); }
+inline int stream_wpb(int c) { return c == 3 ? 2 : 4; }
 template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
     switch (cls) {
-    case 0: launch_stream<9, 64, 4, 1, SMALL>(a, nrows, num_cu, lds, s); break;
-    case 1: launch_stream<10, 64, 4, 2, SMALL>(a, nrows, num_cu, lds, s); break;
-    case 2: launch_stream<11, 64, 4, 4, SMALL, 3>(a, nrows, num_cu, lds, s); break;
-    case 3: launch_stream<12, 128, 2, 4, SMALL, 3>(a, nrows, num_cu, lds, s); break;
-    case 4: launch_stream<13, 256, 4, 4, SMALL, 3>(a, nrows, num_cu, lds, s); break;
+    case 0: launch_wstream<9, 64, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 1: launch_wstream<10, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 2: launch_wstream<11, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 3: launch_wstream<12, 128, 2, 8, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 4: launch_wstream<13, 256, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
     default: break;
     }
 }
@@ -201,7 +203,15 @@ struct Round {
     DevBuf<int> sflag;              // per row slot: the streaming scatter may take the row
     DevBuf<int2> fixbuf;            // per row slot: SFIX duplicates found by the streaming kernels, merged by k_stream_fix
     DevBuf<int> fixcnt;
-    bool use_stream = true;         // SPASM_AMD_STREAM=0 turns the streaming scatter off
+    bool use_stream = true;         // SPASM_AMD_STREAM=0 turns W and the streaming scatter off
+    // W = -(I + U_PP)^-1 U_PN (stream.hpp): its rows live behind U_PN in the UPN buffer
+    bool use_w = false;
+    bool force_lists = false;       // keep to the multiplier lists even when W is there (exact trip counters: they count list entries)
+    DevBuf<int4> Wrec, wcol;
+    DevBuf<i64d> Wstart;
+    DevBuf<int> Wlen, wreject_list;
+    DevMat Zrows;                   // npiv rows without entries: what W is scattered "from"
+    i64 wtotal = 0;
     DevBuf<u64d> pool_ctr;          // NPOOL sharded bump counters
     int npool_active = NPOOL;       // regions in use by the current solve
     u64d region_cap = 0;
@@ -543,6 +553,66 @@ struct Round {
         }
     }
 
+    // W = -(I + U_PP)^-1 U_PN, once per round, after prepare_uinv: row i = - sum over the entries (j, u) of row i of Uinv of u * U_PN[j],
+    // i.e. a scatter round over npiv rows without entries of their own whose "multiplier lists" are the rows of Uinv.  Costs about
+    // uinv_nnz / npiv times the entries of U_PN: worth it when many more rows than pivots are reduced.
+    void prepare_w(i64 expected_rows = ((i64)1 << 62))
+    {
+        use_w = false;
+        wtotal = 0;
+        if (!use_uinv || !use_stream || m >= (1 << 24) || npiv == 0 || expected_rows < 2 * (i64)npiv) return;
+        const i64 nrec = (i64)UinvPool.n;
+        Wrec.ensure((size_t)nrec + 1);
+        alloc_solve(npiv, 1 << 16);
+        {
+            const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), npool_words = NPOOL * POOL_STRIDE;
+            const int span = std::max(std::max(nctr_words, npool_words), npiv + 1);
+            hipLaunchKernelGGL(k_solve_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, npiv, (unsigned *)ctr.p, nctr_words, pool_ctr.p,
+                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p, sflag.p);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_uinv_records, dim3(cdiv(((i64)npiv + 1) * 8, 256)), dim3(256), 0, stream, npiv, UinvStart.p, UinvLen.p, UinvPool.p, uhdr.p,
+                           Wrec.p, bound.p, (i64d)free_cols);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(Lstart.p, UinvStart.p, (size_t)npiv * sizeof(i64d), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(Llen.p, UinvLen.p, (size_t)npiv * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        run_bounds(npiv);
+        const i64 tot = fetch_total_bound(npiv);
+        // offsets into the U_PN + W buffer are 32-bit; a W much larger than U means long chains: the lists cope better
+        if (utotal + tot >= (i64)0xffffffffLL || tot > 64 * std::max<i64>(utotal, 1 << 16)) return;
+        size_t fr = 0, totmem = 0;
+        HIPCHK(hipMemGetInfo(&fr, &totmem));
+        if ((size_t)(tot + utotal) * 2 * sizeof(int2) > fr / 2) return;
+        S.ent.ensure((size_t)tot + 1);
+        Zrows.n = npiv;
+        Zrows.m = m;
+        Zrows.start.ensure((size_t)npiv + 1);
+        Zrows.len.ensure((size_t)npiv + 1);
+        Zrows.orig.ensure((size_t)npiv + 1);
+        Zrows.ent.ensure(1);
+        HIPCHK(hipMemsetAsync(Zrows.start.p, 0, ((size_t)npiv + 1) * sizeof(i64d), stream));
+        HIPCHK(hipMemsetAsync(Zrows.len.p, 0, ((size_t)npiv + 1) * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(Zrows.orig.p, 0, ((size_t)npiv + 1) * sizeof(int), stream));
+        run_scatter(Zrows, nullptr, npiv, Wrec.p);
+        fetch_counters(); // synchronises; throws if a table filled up
+        // behind U_PN in one buffer, so that a record's offset means the same to every scatter kernel
+        DevBuf<int2> both;
+        both.alloc((size_t)(utotal + tot) + 1);
+        if (utotal > 0) HIPCHK(hipMemcpyAsync(both.p, UPN.p, (size_t)utotal * sizeof(int2), hipMemcpyDeviceToDevice, stream));
+        if (tot > 0) HIPCHK(hipMemcpyAsync(both.p + utotal, S.ent.p, (size_t)tot * sizeof(int2), hipMemcpyDeviceToDevice, stream));
+        Wstart.ensure((size_t)npiv + 1);
+        Wlen.ensure((size_t)npiv + 1);
+        HIPCHK(hipMemcpyAsync(Wstart.p, sstart.p, ((size_t)npiv + 1) * sizeof(i64d), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(Wlen.p, S.len.p, (size_t)npiv * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        wcol.ensure((size_t)m + 1);
+        hipLaunchKernelGGL(k_wcolinfo, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, qinv_r.p, Wstart.p, Wlen.p, (i64d)utotal, wcol.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        UPN = std::move(both);
+        wtotal = tot;
+        use_w = true;
+    }
+
     void run_solve(const DevMat &M, const int *rows, const int *self_idx, int nrows)
     {
         {
@@ -616,6 +686,40 @@ struct Round {
                 c.dbg = dbg ? atoi(dbg) : 0;
             }
             c.F = F;
+            const bool wmode = use_w && !force_lists && !self_idx && !want_idx;
+            if (wmode) {
+                // the plan along the rows of W; what it leaves (streams beyond the streaming classes, rows that are bound to be full
+                // of duplicate columns) goes through the multiplier lists below
+                wreject_list.ensure((size_t)nrows + 1);
+                WPlanArgs wp;
+                wp.nrows = nrows;
+                wp.rstart = rstart.p;
+                wp.rlen = rlen.p;
+                wp.ent = M.ent.p;
+                wp.pbits = pbits.p;
+                wp.wcol = wcol.p;
+                wp.Lpool = Lpool.p;
+                wp.lpool_cap = region_cap;
+                wp.pool_ctr = pool_ctr.p;
+                wp.npool = npool_active;
+                wp.Lstart = Lstart.p;
+                wp.Llen = Llen.p;
+                wp.bound = bound.p;
+                wp.pmask = pmask.p;
+                wp.sflag = sflag.p;
+                wp.free_cols = free_cols;
+                wp.max_bound = (int)kClasses[kNumStreamClasses - 1].cap;
+                wp.overflow_list = wreject_list.p;
+                wp.overflow_count = &ctr.p->wplan_reject;
+                wp.ctr = ctr.p;
+                wp.F = F;
+                constexpr int TEAM = 16, TPB = 256;
+                hipLaunchKernelGGL((k_wplan<TEAM, TPB>), dim3(std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 16)), dim3(TPB), 0, stream, wp);
+                HIPCHK(hipGetLastError());
+                c.retry = wreject_list.p;
+                c.retry_count = &ctr.p->wplan_reject;
+                c.sflag = nullptr; // rows with multiplier lists go to the hash-table kernels
+            }
             {
                 constexpr int TEAM = 16, LOGC = 8, TPB = 256; // up to 128 distinct pivots per row
                 const int grid = std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 8);
@@ -709,16 +813,19 @@ struct Round {
         return tot;
     }
 
-    void run_scatter(const DevMat &M, const int *rows, int nrows)
+    // `recs`: the records the row lists index (the multiplier pool; the records of W's rows when W itself is built)
+    void run_scatter(const DevMat &M, const int *rows, int nrows, const int4 *recs = nullptr)
     {
+        const bool building_w = recs != nullptr;
+        if (!recs) recs = Lpool.p;
         S.n = nrows;
         S.m = m;
         nlaunch = 0;
         if (nrows == 0) return;
         HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
         int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1; // 12-byte slots: the 2^14 table exceeds LDS
-        // the stream positions come from the combine kernel; the duplicate check identifies a column by 24 bits
-        const bool streaming = use_stream && use_uinv && m < (1 << 24);
+        // the streaming kernel goes along the rows of W (the plan kernel marks the rows it can take)
+        const bool streaming = use_w && !building_w && !force_lists;
         BinArgs b;
         b.nrows = nrows;
         b.bound = bound.p;
@@ -748,7 +855,7 @@ struct Round {
         a.qinv_r = qinv_r.p;
         a.uhdr = uhdr.p;
         a.UPN = UPN.p;
-        a.Lpool = Lpool.p;
+        a.Lpool = recs;
         a.Sent = S.ent.p;
         a.Slen = S.len.p;
         a.Slead = S.lead.p;
@@ -756,7 +863,7 @@ struct Round {
         a.F = F;
         {
             const char *dbg = getenv("SPASM_DBG"); // timing ablations of the scatter kernel (wrong results when set)
-            a.dbg = dbg ? atoi(dbg) : 0;
+            a.dbg = dbg && !building_w ? atoi(dbg) : 0;
         }
         a.stamps = nullptr;
 #ifdef SPASM_STAMPS
@@ -768,7 +875,7 @@ struct Round {
         sa.ent = M.ent.p;
         sa.qinv_r = qinv_r.p;
         sa.UPN = UPN.p;
-        sa.Lpool = Lpool.p;
+        sa.Lpool = recs;
         sa.Sent = S.ent.p;
         sa.Slen = S.len.p;
         sa.Slead = S.lead.p;
@@ -820,7 +927,7 @@ struct Round {
             sa.desc = class_desc.p + (size_t)(NSTREAM0 + c) * nrows;
             sa.redo_count = class_count.p + c;
             sa.redo_desc = class_desc.p + (size_t)c * nrows;
-            const size_t lds = stream_lds_bytes(stream_logt(c), kClasses[c].tpr, kClasses[c].wpb);
+            const size_t lds = stream_lds_bytes(stream_logt(c), stream_tpr(c), stream_wpb(c));
             if (F.small) launch_stream_class<true>(c, sa, nrows, num_cu, lds, s);
             else launch_stream_class<false>(c, sa, nrows, num_cu, lds, s);
         };
@@ -900,7 +1007,7 @@ struct Round {
             std::vector<u64d> h(NCLASS * 2 * NSTAMP);
             HIPCHK(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(u64d), hipMemcpyDeviceToHost));
             static const char *names[NSTAMP] = {"prologue", "issue", "wait-loads", "own", "rounds", "remainder", "sweep", "-"};
-            static const char *snames[NSTAMP] = {"issue", "own", "rounds", "rowend", "reset", "rotate", "-", "-"};
+            static const char *snames[NSTAMP] = {"top+own", "chunks", "next-req", "rowend", "reset", "rotate", "-", "-"};
             for (int c = NSTREAM0; c < NCLASS; c++) {
                 const double waves = (double)h[(size_t)c * 2 * NSTAMP + NSTAMP];
                 if (waves == 0) continue;
@@ -1259,6 +1366,9 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     std::unique_ptr<Round> R(new Round());
     R->F = zp_field_make(prime);
     R->stream = stream;
+    // the trip counters of the round statistics (applications, nnz_reduced, read_bytes) count multiplier-list entries: they are
+    // exact only when the rounds keep to the lists, which costs about a third more time per round
+    if (const char *e = getenv("SPASM_AMD_ROUND_STATS")) R->force_lists = atoi(e) != 0;
     int round = 0;
     i64 cur_live = n;
     while (cur->n > 0 && m > 0) {
@@ -1280,6 +1390,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         R->mark_local(*cur, 0);
         R->build_U(*cur, R->pivrow.p);
         R->prepare_uinv(R->nnp);
+        R->prepare_w(R->nnp);
         const int nnp = R->nnp;
         // The multiplier records and the slots of the Schur rows of ALL non-pivot rows normally fit (config 3: 0.5 + 4.6 GB).
         // Rounds whose rows reach tens of thousands of pivots (Macaulay-like) can need more than the device has: the rows
@@ -1929,6 +2040,9 @@ struct spasm_amd_schur_plan {
     i64 nnz_in = 0;
     i64 prime = 0;
     bool ran = false;
+    // the reference's trip counters of this round, counted once on the multiplier lists when the plan is made (the runs go
+    // along the rows of W, where no list exists to count)
+    u64d exact_applications = 0, exact_nnz_reduced = 0, exact_segments = 0;
 };
 
 namespace {
@@ -1947,6 +2061,26 @@ struct spasm_amd_shard {
 };
 
 namespace {
+
+// dry run of the solve on the multiplier lists: sizes the record pool and the Schur slots (the bounds along W are no larger)
+// and counts the reference's trip counters once
+void plan_dry_run(spasm_amd_schur_plan *P, i64 pool_guess)
+{
+    Round &R = P->R;
+    const bool fl = R.force_lists;
+    R.force_lists = true;
+    const i64 tot = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, pool_guess);
+    const RoundCounters c = R.read_counters();
+    P->exact_applications = c.applications;
+    P->exact_nnz_reduced = c.nnz_reduced;
+    P->exact_segments = c.segments;
+    R.force_lists = fl;
+    i64 tot2 = 0;
+    // along W a row's stream is the sum of the runs of its entries on pivot columns: two runs that share pivot rows count them
+    // twice, so these bounds can exceed the lists' -- size for both
+    if (R.use_w && !fl) tot2 = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, pool_guess);
+    R.S.ent.ensure((size_t)std::max(tot, tot2) + 1);
+}
 
 spasm_amd_shard *shard_create(const struct spasm_csr *A, int lo, int hi, int stride = 1)
 {
@@ -2066,9 +2200,9 @@ spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries
     HIPCHK(hipEventRecord(R.ev[0], s));
     R.build_U(PM, P->rowsrc.p);
     R.prepare_uinv(); // a plan is run many times: Uinv always pays
+    R.prepare_w();
     HIPCHK(hipEventRecord(R.ev[1], s));
-    const i64 tb = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, 4 * std::max<i64>(P->nnz_in, 1 << 14));
-    R.S.ent.ensure((size_t)tb + 1);
+    plan_dry_run(P, 4 * std::max<i64>(P->nnz_in, 1 << 14));
     S->plan = nullptr; // ownership passes to the caller
     S->imported = true;
     return P;
@@ -2180,10 +2314,9 @@ spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi, int
     R.mark_local(P->A, 0, lo, hi, 1, stride);
     R.build_U(P->A, R.pivrow.p);
     R.prepare_uinv(); // a plan is run many times: Uinv always pays
+    R.prepare_w();
     HIPCHK(hipEventRecord(R.ev[1], s));
-    // dry run of the solve sizes the multiplier pool and the Schur slots once
-    const i64 tot = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, 4 * spasm_nnz(A));
-    R.S.ent.ensure((size_t)tot + 1);
+    plan_dry_run(P.get(), 4 * spasm_nnz(A));
     return P.release();
 }
 
@@ -2379,6 +2512,9 @@ SPASM_API int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spas
     try {
         if (!plan->ran) throw EngineError("run the plan first");
         plan->R.fetch_counters();
+        plan->R.hctr.applications = plan->exact_applications;
+        plan->R.hctr.nnz_reduced = plan->exact_nnz_reduced;
+        plan->R.hctr.segments = plan->exact_segments;
         fill_stats(*stats, plan->R, 0, plan->hi > plan->lo ? (plan->hi - plan->lo + plan->stride - 1) / plan->stride : 0, plan->nnz_in);
         return 0;
     } catch (const std::exception &e) {

@@ -60,6 +60,7 @@ struct RoundCounters {
     int solve_overflow;  // rows whose reach did not fit the LDS list of the first solve class
     int solve_failed;    // rows whose reach did not fit the largest solve class
     int lpool_overflow;  // multiplier pool exhausted
+    int wplan_reject;    // rows the W plan leaves to the multiplier-list path
     int scatter_overflow;// rows whose bound exceeds the largest hash table class
     int nonempty_out;    // non-empty Schur rows
     u64d nnz_out;        // entries of the Schur complement
@@ -1716,7 +1717,7 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         // ---- one pass over the occupied slots (dcount <= MAXD of them): reduce, drop the zero multipliers, fetch the
         // headers of the applied pivot rows (gathers of a batch in flight together), records out
         int nout = 0;
-        i64d bound = nN; // the row's entry stream: its nN own entries on non-pivot columns first, then the pivot rows in record order
+        i64d bound = 0; // the row's entry stream: the pivot rows in record order; its nN own entries on non-pivot columns fill it from the end
         u64d r_red = 0;
         for (int i0 = 0; i0 < dcount; i0 += 4 * TEAM) {
             int kk[4], vv[4], pos[4];
@@ -1758,6 +1759,7 @@ __global__ __launch_bounds__(TPB) void k_combine(CombineArgs a)
         }
         for (int o = TEAM / 2; o > 0; o >>= 1) r_red += __shfl_xor(r_red, o, TEAM);
         r_red += (u64d)ln;
+        bound += nN;
         const bool any_zero_own = team_ballot<TEAM>(zero_own) != 0;
         if (tl == 0) {
             if (!room) {

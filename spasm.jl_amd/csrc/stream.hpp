@@ -54,8 +54,8 @@ struct StreamArgs {
 };
 
 constexpr int SLCAP = 64; // entries of a row's list of second-table losers
-constexpr int SFIX = 16;  // duplicates a row may collect before it is handed to the hash-table kernel (a row of 2560 random columns
-                          // out of 10^6 expects 3)
+constexpr int SFIX = 64;  // duplicates a row may collect before it is handed to the hash-table kernel: random columns collide rarely (a row
+                          // of 2560 out of 10^6 expects 3), but two runs of W that share a pivot row share its ~17 columns
 
 // LDS of one row: first table (4 B x 2^logt), second table (a quarter), 64 B of counters, fix-up list, loser list
 __host__ __device__ constexpr size_t stream_row_bytes(int logt) { return ((size_t)5 << logt) + 64 + (size_t)SFIX * 8 + (size_t)SLCAP * 16; }
@@ -267,17 +267,176 @@ __device__ __forceinline__ void stream_report(unsigned res, unsigned old, bool p
     }
 }
 
-// TPR = threads cooperating on one row: 64 (a wave per row, WPB independent rows per workgroup, no barriers) or WPB * 64
-// MAXR = rounds of pivot rows kept in registers per row; round r hands pivot row gg + r * NG of the row's record list to
-//        the 8-lane group gg.  Rows with more records finish in a loop that loads as it goes.
-template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW>
-__global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
+// ------------------------------------------------------------------------------------------------
+// W = -(I + U_PP)^-1 * U_PN, one row per pivot: with it the Schur row of B[k] needs no chain of eliminations,
+//        x_a = B[k]_N + sum over the entries (c, a_c) of B[k] on pivot columns of a_c * W[qinv(c)]
+// (x_b * U_PN with x_b = B[k]_P * Uinv, re-associated; same x_a, reference src/SpaSM.jl:704-707).  A row of config 3 applies
+// ~34 pivot rows of ~17 entries through its multiplier list; it has ~3.4 entries on pivot columns, and their rows of W hold the
+// same ~580 entries in 3.4 contiguous runs: no multiplier list to build, and a wave streams a run 64 entries at a time with
+// every lane busy.  W is built once per round by the hash-table scatter kernel from the rows of Uinv (k_uinv_records below
+// turns them into its records); the entries of W live behind those of U_PN in one buffer, so a record {position << 16 | len,
+// -a_c, offset, len} reads the same for every scatter kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_uinv_records(int npiv, const i64d *__restrict__ UinvStart, const int *__restrict__ UinvLen, const int2 *__restrict__ UinvPool,
+                               const UHdr *__restrict__ uhdr, int4 *__restrict__ rec, i64d *__restrict__ bound, i64d free_cols)
+{
+    constexpr int TEAM = 8;
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i > npiv) return;
+    if (i == npiv) { if (tl == 0) bound[i] = 0; return; }
+    const i64d st = UinvStart[i];
+    const int ln = UinvLen[i];
+    i64d b = 0;
+    for (int k = tl; k < ln; k += TEAM) {
+        const int2 e = UinvPool[st + k];
+        UHdr h; h.off = 0; h.npn = 0;
+        if (e.y != 0) h = uhdr[e.x];
+        rec[st + k] = make_int4(0, e.y, (int)h.off, h.npn);
+        b += h.npn;
+    }
+    for (int o = TEAM / 2; o > 0; o >>= 1) b += __shfl_xor(b, o, TEAM);
+    if (tl == 0) bound[i] = b < free_cols ? b : free_cols;
+}
+
+// per column: {pivot index or -1, length of its row of W, offset of that row in the U_PN + W buffer, -}
+__global__ void k_wcolinfo(int m, const int *__restrict__ qinv_r, const i64d *__restrict__ Wstart, const int *__restrict__ Wlen, i64d wbase,
+                           int4 *__restrict__ wcol)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int q = qinv_r[j];
+    int4 r = make_int4(q, 0, 0, 0);
+    if (q >= 0) { r.y = Wlen[q]; r.z = (int)(unsigned)(wbase + Wstart[q]); }
+    wcol[j] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The plan of a row's Schur row under W: one record per entry on a pivot column, their stream positions (runs first, in record
+// order; the row's own non-pivot entries fill the stream from its end), the bound = length of the stream.  Takes the place of
+// the combine kernel: no Uinv rows to merge, no headers to gather.  TEAM lanes per row, two passes over the row's entries
+// (the first counts, so that the records can be allocated; the entries come back from L2).
+// ------------------------------------------------------------------------------------------------
+struct WPlanArgs {
+    int nrows;
+    const i64d *rstart;        // per row slot: start / length of the row's own entries
+    const int *rlen;
+    const int2 *ent;
+    const unsigned *pbits;     // bit j: column j is a pivot column of this round
+    const int4 *wcol;
+    int4 *Lpool;               // records {position << 16 | len, -a_c, offset in the U_PN + W buffer, len}
+    u64d lpool_cap;
+    u64d *pool_ctr;
+    int npool;
+    i64d *Lstart;
+    int *Llen;
+    i64d *bound;
+    long long *pmask;
+    int *sflag;
+    int free_cols;
+    int max_bound;             // rows with a longer stream are left to the multiplier-list path
+    int *overflow_list;        // rows this kernel leaves to the combine kernel
+    int *overflow_count;
+    RoundCounters *ctr;
+    ZpField F;
+};
+
+template <int TEAM, int TPB>
+__global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
+{
+    constexpr int TEAMS = TPB / TEAM;
+    const int tl = threadIdx.x % TEAM;
+    const int team = threadIdx.x / TEAM;
+    const ZpField F = a.F;
+    for (i64d t64 = (i64d)blockIdx.x * TEAMS + team; t64 < a.nrows; t64 += (i64d)gridDim.x * TEAMS) {
+        const int t = (int)t64;
+        const i64d st = a.rstart[t];
+        const int ln = a.rlen[t];
+        // ---- pass 1: entries on pivot columns (P) and on the others (nN)
+        int P = 0, nN = 0;
+        bool zero_own = false;
+        u64d pm = 0;
+        for (int k0 = 0; k0 < ln; k0 += TEAM) {
+            const int k = k0 + tl;
+            bool isP = false, isN = false;
+            if (k < ln) {
+                const int2 e = a.ent[st + k];
+                isP = (a.pbits[(unsigned)e.x >> 5] >> (e.x & 31)) & 1u;
+                isN = !isP;
+                zero_own |= e.y == 0;
+            }
+            const u64d mP = team_ballot<TEAM>(isP);
+            if (k0 < 64) pm |= mP << (k0 & 63);
+            P += __popcll(mP);
+            nN += __popcll(team_ballot<TEAM>(isN));
+        }
+        const bool anyzero = team_ballot<TEAM>(zero_own) != 0;
+        u64d base = 0;
+        if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)P, a.npool);
+        base = __shfl(base, 0, TEAM);
+        const bool room = base != ~0ull;
+        // ---- pass 2: the records, with the running total of the run lengths as stream position
+        i64d run = 0;
+        int w = 0;
+        for (int k0 = 0; k0 < ln && room; k0 += TEAM) {
+            const int k = k0 + tl;
+            int2 e = make_int2(0, 0);
+            bool isP = false;
+            if (k < ln) {
+                e = a.ent[st + k];
+                isP = (a.pbits[(unsigned)e.x >> 5] >> (e.x & 31)) & 1u;
+            }
+            int4 ci = make_int4(-1, 0, 0, 0);
+            if (isP) ci = a.wcol[e.x];
+            const int len = isP ? ci.y : 0;
+            int tot;
+            const int incl = team_incl_scan<TEAM>(len, tot);
+            const u64d mP = team_ballot<TEAM>(isP);
+            if (isP) {
+                const i64d pre = run + incl - len;
+                const unsigned px = (pre < 0x8000 ? (unsigned)pre : 0x7fffu) << 16 | (unsigned)min(len, 0xffff);
+                a.Lpool[base + w + __popcll(mP & ((1ull << tl) - 1ull))] = make_int4((int)px, zp_neg(F, e.y), ci.z, len);
+            }
+            w += __popcll(mP);
+            run += tot;
+        }
+        if (tl == 0) {
+            if (!room) {
+                atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1);
+                a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0;
+            } else {
+                const i64d bound = run + nN;
+                const bool ok = bound <= (i64d)a.free_cols && bound <= (i64d)a.max_bound && !anyzero && P <= 64;
+                if (ok) {
+                    a.Lstart[t] = (i64d)base;
+                    a.Llen[t] = P;
+                    a.bound[t] = bound;
+                    a.pmask[t] = ln <= 32 ? (long long)pm : -1;
+                    a.sflag[t] = 1;
+                } else {
+                    // too long, too many duplicates to expect, or a zero among its entries: the multiplier-list path takes the row
+                    a.Llen[t] = -1; a.Lstart[t] = 0; a.bound[t] = 0;
+                    a.overflow_list[atomicAdd(a.overflow_count, 1)] = t;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SCATTER along the rows of W (or along any record list: a record names a run of entries and its multiplier).  The runs of a
+// row are cut into chunks of 64 entries; a wave takes chunks (its share of them when several waves work on the row), loads
+// the next batch while it works on the current one, and treats every entry as k_stream did: multiply, store at its stream
+// position, one CAS in the direct-mapped tables for the duplicate check.
+// TPR = threads per row (64: a wave per row, WPB rows per workgroup; else the workgroup).  D = chunk loads in flight per wave.
+// ------------------------------------------------------------------------------------------------
+template <int LOGT, int TPR, int WPB, int D, bool SMALL, int MINW>
+__global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
 {
     constexpr bool WAVE_ROW = (TPR == 64);
     static_assert(WAVE_ROW || TPR == WPB * 64, "a row is owned by one wave or by the whole workgroup");
     constexpr int T1 = 1 << LOGT;
-    constexpr int G = 8;
-    constexpr int NG = TPR / G;
+    constexpr int NW = WAVE_ROW ? 1 : WPB; // waves sharing a row
     constexpr int FCAP = SFIX;
     constexpr size_t TABB = (size_t)5 * T1, MISCB = 64, FIXB = (size_t)FCAP * 8;
     constexpr size_t SLOT = stream_row_bytes(LOGT);
@@ -286,15 +445,13 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rtid = WAVE_ROW ? lane : tid;
+    const int rw = WAVE_ROW ? 0 : wave; // this wave's number among the waves of its row
     unsigned char *base = s_raw + (WAVE_ROW ? (size_t)wave * SLOT : 0);
     StreamTabs<LOGT> tb;
     tb.bind(base);
-    // misc[par * 8 + 0] = fix-ups pushed, [+ 1] = losers listed, [+ 4 + w] = leftmost column seen by wave w (block-per-row);
-    // two parities so that a row's words can be reset while the waves are still reading the previous row's
     int *misc = (int *)(base + TABB);
     int2 *fix = (int2 *)(base + TABB + MISCB);
     int4 *lst = (int4 *)(base + TABB + MISCB + FIXB);
-    const int gg = rtid / G, gl = rtid % G;
     const ZpField F = a.F;
 
     const int count = *a.class_count;
@@ -305,34 +462,48 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
 
     const int first = WAVE_ROW ? (int)blockIdx.x * WPB + wave : (int)blockIdx.x;
     const int stride = WAVE_ROW ? (int)gridDim.x * WPB : (int)gridDim.x;
-    // statistics: wave-uniform values only (they live in SGPRs)
     u64d c_nnz = 0, c_ent = 0, c_seg = 0;
     int c_rows = 0, c_redo = 0;
     int par = 0;
 
-    // ---- pipeline registers: descriptors of this row and the next two (SGPRs; a fourth in flight), records of this row and
-    // the next, pivot-row entries and first own entries of this row.  Everything is loaded unconditionally with clamped
-    // indices (beyond the last row: the last descriptor again), see k_scatter.
+    // ---- pipeline: descriptors of this row and the next two (a fourth in flight), records and first own entries of this row
+    // and the next.  Unconditional loads with clamped indices (beyond the last row: the last descriptor again).
     RowDesc d, dn, dnn;
-    int3 rec[MAXR], rec_n[MAXR]; // {position << 16 | npn, multiplier, offset in UPN} (the 4th word of a record is the hash kernel's)
-    int2 u[MAXR][3];
-    int2 own;
-    auto load_rec = [&](const RowDesc &dd, int r) { return *(const int3 *)&a.Lpool[dd.l_start + min(gg + r * NG, max(dd.llen - 1, 0))]; };
-    auto load_u = [&](const int3 &rc, int j) {
-        const int last = max((rc.x & 0xffff) - 1, 0);
-        return a.UPN[(size_t)(unsigned)rc.z + (unsigned)min(gl + j * G, last)];
-    };
-    {
-        d = stream_desc_unpack(stream_desc_load(a.desc + min(first, count - 1)));
-        dn = stream_desc_unpack(stream_desc_load(a.desc + min(first + stride, count - 1)));
-        dnn = stream_desc_unpack(stream_desc_load(a.desc + min(first + 2 * stride, count - 1)));
+    int4 rec, rec_n;
+    int2 own, own_n;
+    auto load_rec = [&](const RowDesc &dd) { return a.Lpool[dd.l_start + min(lane, max(dd.llen - 1, 0))]; };
+    auto load_own = [&](const RowDesc &dd) { return a.ent[dd.ent_start + min(lane, max(dd.len - 1, 0))]; };
+    d = stream_desc_unpack(stream_desc_load(a.desc + min(first, count - 1)));
+    dn = stream_desc_unpack(stream_desc_load(a.desc + min(first + stride, count - 1)));
+    dnn = stream_desc_unpack(stream_desc_load(a.desc + min(first + 2 * stride, count - 1)));
+    rec = load_rec(d);
+    own = load_own(d);
+    rec_n = load_rec(dn);
+    own_n = load_own(dn);
+    // the ring of chunk loads and what each slot holds (wave-uniform: stream position of the run, multiplier, run length, chunk)
+    int2 ring[D];
+    int r_pre[D], r_nm[D], r_len[D], r_k[D];
 #pragma unroll
-        for (int r = 0; r < MAXR; r++) { rec[r] = load_rec(d, r); rec_n[r] = load_rec(dn, r); }
-        own = a.ent[d.ent_start + min(lane, max(d.len - 1, 0))];
+    for (int j = 0; j < D; j++) { ring[j] = make_int2(0, 0); r_pre[j] = 0; r_nm[j] = 0; r_len[j] = 1; r_k[j] = 0; }
+    if (first < count) { // the first row's first chunks
+        const int ll0 = d.llen;
+        const int mylen0 = lane < ll0 ? rec.w : 0;
+        int F0;
+        const int cend0 = team_incl_scan<64>((mylen0 + 63) >> 6, F0);
+        const int cstart0 = cend0 - ((mylen0 + 63) >> 6);
+        const int my0 = F0 > rw ? (F0 - rw + NW - 1) / NW : 0;
 #pragma unroll
-        for (int r = 0; r < MAXR; r++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) u[r][j] = load_u(rec[r], j);
+        for (int j = 0; j < D; j++) {
+            if (j < my0) {
+                const int f = rw + j * NW;
+                const int s = max(__popcll(__ballot(cstart0 <= f && lane < ll0)) - 1, 0);
+                r_k[j] = f - __builtin_amdgcn_readlane(cstart0, s);
+                r_len[j] = __builtin_amdgcn_readlane(rec.w, s);
+                r_nm[j] = -__builtin_amdgcn_readlane(rec.y, s);
+                r_pre[j] = (int)((unsigned)__builtin_amdgcn_readlane(rec.x, s) >> 16);
+                ring[j] = a.UPN[(size_t)(unsigned)__builtin_amdgcn_readlane(rec.z, s) + (unsigned)min(r_k[j] * 64 + lane, r_len[j] - 1)];
+            }
+        }
     }
 
 #ifdef SPASM_STAMPS
@@ -340,139 +511,164 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
     u64d st_last = stamp_now();
 #endif
     for (int w = first; w < count; w += stride) {
-        // ---- (1) the loads of the rows ahead
         const int d3_reg = stream_desc_load(a.desc + min(w + 3 * stride, count - 1));
-        int3 rec_nn[MAXR];
-        int2 u_n[MAXR][3];
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) rec_nn[r] = load_rec(dnn, r);
-#pragma unroll
-        for (int r = 0; r < MAXR; r++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                u_n[r][j] = make_int2(gl + j * G + r * 1024 + gg * 32, 1);
-                if (!SCATTER_DBG(a, 8)) u_n[r][j] = load_u(rec_n[r], j);
-            }
-        const int2 own_n = a.ent[dn.ent_start + min(lane, max(dn.len - 1, 0))];
-        const int ln = d.len, ll = d.llen;
+        const int4 rec_nn = load_rec(dnn);
+        const int2 own_nn = load_own(dnn);
+        const int ln = d.len, ll = d.llen, E = d.bound, t_cur = d.t;
         int *const mrow = misc + par * 8;
-        int q_own = 0;
-        if (d.pmask >= 0) q_own = ((d.pmask >> lane) & 1) ? 0 : -1;
-        else if (lane < ln) q_own = a.qinv_r[own.x];
         unsigned char *const rowp = (unsigned char *)(a.Sent + d.s_start);
         int mylead = INT_MAX;
+        // ---- the chunks of the row's runs: lane r holds record r
+        const int mylen = lane < ll ? rec.w : 0;
+        int F_chunks;
+        const int cend = team_incl_scan<64>((mylen + 63) >> 6, F_chunks); // chunks up to and including this record's
+        const int cstart = cend - ((mylen + 63) >> 6);
+        // ---- the row's chunks, D loads in flight: this wave's g-th chunk is chunk f = rw + g * NW of the row, i.e. chunk
+        // k = f - cstart[s] of record s = the last record with cstart <= f.  The first D were requested while the previous row
+        // was being finished (below); slot g % D is refilled with chunk g + D as soon as chunk g is done.
+        auto locate = [&](int f, int &pre, int &nm, int &len, int &k, unsigned &off) {
+            const int s = max(__popcll(__ballot(cstart <= f && lane < ll)) - 1, 0);
+            k = f - __builtin_amdgcn_readlane(cstart, s);
+            len = __builtin_amdgcn_readlane(rec.w, s);
+            nm = -__builtin_amdgcn_readlane(rec.y, s);
+            pre = (int)((unsigned)__builtin_amdgcn_readlane(rec.x, s) >> 16);
+            off = (unsigned)__builtin_amdgcn_readlane(rec.z, s);
+        };
+        const int my_chunks = F_chunks > rw ? (F_chunks - rw + NW - 1) / NW : 0;
+        // ---- the row's own entries on non-pivot columns: they fill the stream from its end (their rank is a ballot), one wave
         int nN = 0;
-        unsigned rare = 0; // any lane, any entry: something to report
-        STAMP(0); // issue of the loads of the rows ahead
-        // ---- (2) the row's own entries on non-pivot columns: stream positions 0 .. nN-1, one wave (their rank is a ballot)
         if (WAVE_ROW || wave == 0) {
-            {
-                const bool nonpiv = lane < ln && q_own < 0;
+            int q_own = 0;
+            if (d.pmask >= 0) q_own = ((d.pmask >> lane) & 1) ? 0 : -1;
+            else if (lane < ln) q_own = a.qinv_r[own.x];
+            // first chunk straight-line, the rest in a loop: at a loop header the compiler waits for EVERY load in flight
+            // (s_waitcnt vmcnt(0)), the requests for the rows ahead included
+            auto own_chunk = [&](const int2 e, const bool nonpiv) {
                 const u64d m = __ballot(nonpiv);
-                const int pos1 = __popcll(m & lanemask_lt()) + 1;
+                const int cnt = __popcll(m);
+                const int pos1 = E - nN - cnt + __popcll(m & lanemask_lt()) + 1;
                 if (nonpiv) {
-                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)own.y << 32) | (unsigned)own.x, (long long *)(rowp + ((unsigned)(pos1 - 1) << 3)));
-                    mylead = min(mylead, own.x);
+                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)e.y << 32) | (unsigned)e.x, (long long *)(rowp + ((unsigned)(pos1 - 1) << 3)));
+                    mylead = min(mylead, e.x);
                     if (!SCATTER_DBG(a, 2)) {
                         unsigned old;
-                        const unsigned res = stream_insert<LOGT>(tb, own.x, pos1, old);
-                        if (res) stream_report(res, old, true, own.x, own.y, pos1, mrow, fix, FCAP, lst);
+                        const unsigned res = stream_insert<LOGT>(tb, e.x, pos1, old);
+                        if (res) stream_report(res, old, true, e.x, e.y, pos1, mrow, fix, FCAP, lst);
                     }
                 }
-                nN = __popcll(m);
-            }
-            for (int k0 = 64; k0 < ln; k0 += 64) { // rows longer than a wave (wave-uniform trip count)
-                const int k = k0 + lane;
-                int2 e = make_int2(0, 0);
-                bool nonpiv = false;
-                if (k < ln) {
-                    e = a.ent[d.ent_start + k];
-                    nonpiv = a.qinv_r[e.x] < 0;
-                }
-                const u64d m = __ballot(nonpiv);
-                const int pos1 = nN + __popcll(m & lanemask_lt()) + 1;
-                if (nonpiv) {
-                    __builtin_nontemporal_store(((long long)(unsigned)e.y << 32) | (unsigned)e.x, (long long *)(rowp + ((unsigned)(pos1 - 1) << 3)));
-                    mylead = min(mylead, e.x);
-                    unsigned old;
-                    const unsigned res = stream_insert<LOGT>(tb, e.x, pos1, old);
-                    if (res) stream_report(res, old, true, e.x, e.y, pos1, mrow, fix, FCAP, lst);
-                }
-                nN += __popcll(m);
-            }
-        }
-        STAMP(1); // own entries
-        // ---- (3) the pivot rows: multiply, store at the entry's stream position, CAS for the duplicate check
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) {
-            if (r * NG < ll) { // scalar: there are records for this round
-                const int np = rec[r].x & 0xffff;
-                const int nm = -rec[r].y;
-                const int last = max(np - 1, 0);
-                const int pre1 = (int)((unsigned)rec[r].x >> 16) + 1;
-                // a pivot row may consist of its pivot alone: such a group (and a group that repeats such a record) sits out
-                const bool gok = np > 0;
-                int bc[3], bv[3], bp[3];
-                unsigned old[3], res[3];
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    bc[j] = u[r][j].x;
-                    bv[j] = stream_mul<SMALL>(F, nm, u[r][j].y);
-                    bp[j] = pre1 + min(gl + j * G, last);
-                    res[j] = 0;
-                    old[j] = 0;
-                }
-                if (gok) {
-#pragma unroll
-                    for (int j = 0; j < 3; j++)
-                        if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)bv[j] << 32) | (unsigned)bc[j], (long long *)(rowp + ((unsigned)(bp[j] - 1) << 3)));
-                    if (!SCATTER_DBG(a, 2)) stream_insert_n<LOGT, 3>(tb, bc, bp, old, res);
-                    mylead = min(mylead, min(bc[0], min(bc[1], bc[2])));
-                }
-                if (__ballot((res[0] | res[1] | res[2]) != 0) != 0) { // rare: duplicates, double losers
-                    const bool gprim = gg + r * NG < ll;
-#pragma unroll
-                    for (int j = 0; j < 3; j++) stream_report(stream_outcome(res[j]), old[j], gprim && gl + j * G <= last, bc[j], bv[j], bp[j], mrow, fix, FCAP, lst);
-                }
-                if (__ballot(np > 3 * G) != 0) { // pivot rows longer than 24 entries
-                    const int2 *up = a.UPN + (unsigned)rec[r].z;
-                    const bool gprim = gg + r * NG < ll;
-                    for (int k = gl + 3 * G; k < np && gprim; k += G) {
-                        const int2 uu = up[k];
-                        const int vv = stream_mul<SMALL>(F, nm, uu.y);
-                        const int pp1 = pre1 + k;
-                        __builtin_nontemporal_store(((long long)(unsigned)vv << 32) | (unsigned)uu.x, (long long *)(rowp + ((unsigned)(pp1 - 1) << 3)));
-                        mylead = min(mylead, uu.x);
-                        unsigned o2;
-                        const unsigned r2 = stream_insert<LOGT>(tb, uu.x, pp1, o2);
-                        if (r2) stream_report(r2, o2, true, uu.x, vv, pp1, mrow, fix, FCAP, lst);
+                nN += cnt;
+            };
+            own_chunk(own, lane < ln && q_own < 0);
+            if (ln > 64) {
+                for (int k0 = 64; k0 < ln; k0 += 64) { // (rows longer than a wave: wave-uniform trip count)
+                    const int k = k0 + lane;
+                    int2 e = make_int2(0, 0);
+                    bool nonpiv = false;
+                    if (k < ln) {
+                        e = a.ent[d.ent_start + k];
+                        nonpiv = a.qinv_r[e.x] < 0;
                     }
+                    own_chunk(e, nonpiv);
                 }
             }
         }
-        // ---- more pivot rows than NG * MAXR: one round at a time, loaded as it goes (wave-uniform trip count)
-        for (int e0 = MAXR * NG; e0 < ll; e0 += NG) {
-            const int e = e0 + gg;
-            int4 le = make_int4(0, 0, 0, 0);
-            if (e < ll) le = a.Lpool[d.l_start + e];
-            const int np = le.x & 0xffff;
-            const int nm = -le.y;
-            const int pre1 = (int)((unsigned)le.x >> 16) + 1;
-            const int2 *up = a.UPN + (unsigned)le.z;
-            for (int k = gl; k < np; k += G) {
-                const int2 uu = up[k];
-                const int vv = stream_mul<SMALL>(F, nm, uu.y);
-                const int pp1 = pre1 + k;
-                __builtin_nontemporal_store(((long long)(unsigned)vv << 32) | (unsigned)uu.x, (long long *)(rowp + ((unsigned)(pp1 - 1) << 3)));
-                mylead = min(mylead, uu.x);
-                unsigned o2;
-                const unsigned r2 = stream_insert<LOGT>(tb, uu.x, pp1, o2);
-                if (r2) stream_report(r2, o2, true, uu.x, vv, pp1, mrow, fix, FCAP, lst);
+        // Chunks are taken Q at a time: the first-table CAS of all Q are in flight together, then the second-table ones.  The
+        // first D chunks come from the ring, in straight-line code (a loop header would cost a vmcnt(0)); what a row has beyond
+        // them (few rows do) is loaded and used group by group in a loop.
+        constexpr int Q = D >= 4 ? 4 : D;
+        static_assert(D % Q == 0, "whole groups of slots");
+        auto do_group = [&](const int2 (&e)[Q], const int (&g_pre)[Q], const int (&g_nm)[Q], const int (&g_len)[Q], const int (&g_k)[Q], int nthere) {
+            int cc[Q], vv[Q], pp[Q];
+            unsigned oo[Q], left[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                cc[q] = e[q].x;
+                vv[q] = stream_mul<SMALL>(F, g_nm[q], e[q].y);
+                pp[q] = g_pre[q] + min(g_k[q] * 64 + lane, g_len[q] - 1) + 1;
+                oo[q] = 0;
+                left[q] = 0;
+            }
+            if (nthere >= Q) { // a full group (wave-uniform)
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q], (long long *)(rowp + ((unsigned)(pp[q] - 1) << 3)));
+                    mylead = min(mylead, cc[q]);
+                }
+                if (!SCATTER_DBG(a, 2)) stream_insert_n<LOGT, Q>(tb, cc, pp, oo, left);
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+                    if (q < nthere) {
+                        __builtin_nontemporal_store(((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q], (long long *)(rowp + ((unsigned)(pp[q] - 1) << 3)));
+                        mylead = min(mylead, cc[q]);
+                        const int c1[1] = {cc[q]}, p1[1] = {pp[q]};
+                        unsigned o1[1], l1[1];
+                        stream_insert_n<LOGT, 1>(tb, c1, p1, o1, l1);
+                        oo[q] = o1[0];
+                        left[q] = l1[0];
+                    }
+            }
+            unsigned any = 0;
+#pragma unroll
+            for (int q = 0; q < Q; q++) any |= left[q];
+            if (__ballot(any != 0) != 0) { // rare: duplicates, double losers; a lane past the end of its run holds a copy
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+                    stream_report(stream_outcome(left[q]), oo[q], q < nthere && g_k[q] * 64 + lane < g_len[q], cc[q], vv[q], pp[q], mrow, fix, FCAP, lst);
+            }
+        };
+#pragma unroll
+        for (int j0 = 0; j0 < D; j0 += Q) {
+            if (j0 < my_chunks) { // (wave-uniform)
+                int2 e[Q];
+                int g_pre[Q], g_nm[Q], g_len[Q], g_k[Q];
+#pragma unroll
+                for (int q = 0; q < Q; q++) { e[q] = ring[j0 + q]; g_pre[q] = r_pre[j0 + q]; g_nm[q] = r_nm[j0 + q]; g_len[q] = r_len[j0 + q]; g_k[q] = r_k[j0 + q]; }
+                do_group(e, g_pre, g_nm, g_len, g_k, my_chunks - j0);
             }
         }
-        STAMP(2); // rounds of pivot rows
-        const int t_cur = d.t, E = d.bound, ln_cur = ln;
-        // ---- (4) end of the row: leftmost column, losers of both tables, duplicates
+        if (my_chunks > D) {
+            for (int g0 = D; g0 < my_chunks; g0 += Q) {
+                int2 e[Q];
+                int g_pre[Q], g_nm[Q], g_len[Q], g_k[Q];
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    unsigned off;
+                    locate(rw + min(g0 + q, my_chunks - 1) * NW, g_pre[q], g_nm[q], g_len[q], g_k[q], off);
+                    e[q] = a.UPN[(size_t)off + (unsigned)min(g_k[q] * 64 + lane, g_len[q] - 1)];
+                }
+                do_group(e, g_pre, g_nm, g_len, g_k, my_chunks - g0);
+            }
+        }
+        STAMP(1); // the chunks
+        // ---- the first D chunks of the NEXT row are requested now: they fly while this row is finished
+        {
+            const int ll_n = dn.llen;
+            const int mylen_n = lane < ll_n ? rec_n.w : 0;
+            int Fn;
+            const int cend_n = team_incl_scan<64>((mylen_n + 63) >> 6, Fn);
+            const int cstart_n = cend_n - ((mylen_n + 63) >> 6);
+            const int my_n = Fn > rw ? (Fn - rw + NW - 1) / NW : 0;
+            // always D requests (slots past the row's last chunk repeat it, a row without chunks reads entry 0): with a number of
+            // loads that depends on the row the compiler can only wait for ALL of them when the next older load is needed
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+                const int f = min(rw + j * NW, max(Fn - 1, 0));
+                const int s = max(__popcll(__ballot(cstart_n <= f && lane < ll_n)) - 1, 0);
+                const bool have = Fn > 0 && w + stride < count;
+                r_k[j] = f - __builtin_amdgcn_readlane(cstart_n, s);
+                r_len[j] = have ? __builtin_amdgcn_readlane(rec_n.w, s) : 1;
+                r_nm[j] = -__builtin_amdgcn_readlane(rec_n.y, s);
+                r_pre[j] = (int)((unsigned)__builtin_amdgcn_readlane(rec_n.x, s) >> 16);
+                const unsigned off = have ? (unsigned)__builtin_amdgcn_readlane(rec_n.z, s) : 0u;
+                if (!have) r_k[j] = 0;
+                if (SCATTER_DBG(a, 8)) ring[j] = make_int2(r_k[j] * 64 + lane + 4096 * j, 1);
+                else ring[j] = a.UPN[(size_t)off + (unsigned)min(r_k[j] * 64 + lane, r_len[j] - 1)];
+            }
+            (void)my_n;
+        }
+        STAMP(2); // requests for the next row
+        // ---- end of the row: leftmost column, losers of both tables, duplicates
         mylead = wave_min_i32(mylead);
         int lead_out = mylead;
         if (!WAVE_ROW) {
@@ -482,11 +678,9 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
             for (int w2 = 0; w2 < WPB; w2++) lead_out = min(lead_out, mrow[4 + w2]);
         }
         // the lists are wave 0's business from here on (the other waves go on to reset the tables: nothing below touches those)
-        bool redo = false;
-        int nfix = 0;
-        const int n_out = E; // duplicates are merged by k_stream_fix, which corrects the length then
         if (WAVE_ROW || wave == 0) {
-            const int nlist = __builtin_amdgcn_readfirstlane(*(volatile int *)(mrow + 1));
+            bool redo = false;
+            const int nlist = __builtin_amdgcn_readfirstlane(((lds_vint *)mrow)[1]); // (an LDS-qualified read: a generic one drains vmcnt too)
             redo = nlist > SLCAP;
             if (nlist != 0 && !redo) {
                 // entries that lost in both tables are in neither: compare them among themselves (a handful)
@@ -502,10 +696,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
                     if (owner >= 0) stream_fix_push(mrow, fix, FCAP, owner, me.z, me.y);
                 }
             }
-            nfix = SCATTER_DBG(a, 4) ? 0 : __builtin_amdgcn_readfirstlane(*(volatile int *)mrow);
+            const int nfix = SCATTER_DBG(a, 4) ? 0 : __builtin_amdgcn_readfirstlane(((lds_vint *)mrow)[0]);
             redo = redo || nfix > FCAP;
-        }
-        if (WAVE_ROW || wave == 0) {
             if (redo) {
                 // too many duplicate columns for the lists: the hash-table kernel of this size class takes the row
                 if (lane == 0) {
@@ -516,20 +708,18 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
             } else {
                 if (lane < nfix) a.fixbuf[(size_t)t_cur * SFIX + lane] = fix[lane];
                 if (lane == 0) {
-                    a.Slen[t_cur] = n_out;
-                    a.Slead[t_cur] = n_out > 0 ? lead_out : INT_MAX;
+                    a.Slen[t_cur] = E; // duplicates are merged by k_stream_fix, which corrects the length then
+                    a.Slead[t_cur] = E > 0 ? lead_out : INT_MAX;
                     if (nfix) a.fixcnt[t_cur] = nfix; // (zero from the binning pass otherwise)
                 }
-                c_nnz += (u64d)n_out;
-                c_rows += n_out > 0;
-                // entries streamed: the own entries + the non-pivot parts of the applied pivot rows (= E - nN, the records of the
-                // combine kernel all carry a multiplier); segments: the row + one per record
-                c_ent += (u64d)ln_cur + (u64d)(E - nN);
+                c_nnz += (u64d)E;
+                c_rows += E > 0;
+                c_ent += (u64d)ln + (u64d)(E - nN); // entries streamed: the own entries + the runs
                 c_seg += 1 + (u64d)ll;
             }
         }
-        STAMP(3); // end of the row: lead, lists, fix-ups
-        // ---- (5) reset: the tables, and the other parity's words (nobody reads them any more: every wave is past its barrier)
+        STAMP(3); // end of the row
+        // ---- reset: the tables, and the other parity's words (nobody reads them any more: every wave is past its barrier)
         for (int s = rtid * 4; s < T1 + T1 / 4; s += TPR * 4) *(int4 *)(tb.t1 + s) = make_int4(0, 0, 0, 0);
         if (WAVE_ROW) {
             if (lane < 2) mrow[lane] = 0;
@@ -540,22 +730,13 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_stream(StreamArgs a)
             lds_barrier();
         }
         STAMP(4); // table reset + barrier
-        // ---- (6) rotate the pipeline
+        // ---- rotate the pipeline
         d = dn;
         dn = dnn;
         dnn = stream_desc_unpack(d3_reg);
-        own = own_n;
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) {
-            rec[r] = rec_n[r];
-            rec_n[r] = rec_nn[r];
-#pragma unroll
-            for (int j = 0; j < 3; j++) u[r][j] = u_n[r][j];
-        }
-#ifdef SPASM_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        STAMP(5); // rotation: waits for the loads issued at the top
+        rec = rec_n; rec_n = rec_nn;
+        own = own_n; own_n = own_nn;
+        STAMP(5); // rotation: waits for the descriptor / records / own entries requested at the top
     }
 #ifdef SPASM_STAMPS
     if (lane == 0 && a.stamps) {

@@ -245,6 +245,7 @@ def test_config5_macaulay_style_scaled_down(S, O):
 def test_rounds_in_row_batches_when_memory_is_short(S, O, monkeypatch, kind, n, m, kw, prime):
     """A round whose multiplier records / Schur slots exceed the device memory is reduced in batches of rows that are
     appended to the next round's matrix. Forced here by a 16 MB budget; U, rank and kernel must not change."""
+    monkeypatch.setenv("SPASM_AMD_ROUND_STATS", "1")  # exact trip counters: the rounds keep to the multiplier lists
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xB47C4, **kw)
     ref = S.echelonize(A, enable_dense=False)
     ref_rounds = S.last_rounds()
