@@ -148,20 +148,22 @@ template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1> void laun
     HIPCHK(hipGetLastError());
 }
 
-// the streaming twins of the hash-table classes 0..4 (row bounds up to 160 << c): first table of 512 << c words (at most 5/16
-// full); a wave per row up to 640 entries, then 2 and 4 waves
-const int kNumStreamClasses = 5;
-inline int stream_logt(int c) { return 9 + c; }
-inline int stream_tpr(int c) { return c <= 2 ? 64 : (c == 3 ? 128 : 256); }
-inline int stream_wpb(int c) { return c == 3 ? 2 : 4; }
+// the streaming twins of the hash-table classes (row bounds up to 160 << c): first table of 256 << c words (at most 5/8 full); a
+// wave per row up to 640 entries, then 2 and 4 waves
+const int kNumStreamClasses = 7;
+inline int stream_logt(int c) { return 8 + c; }
+inline int stream_tpr(int c) { return c <= 2 ? 64 : 256; }
+inline int stream_wpb(int c) { (void)c; return 4; }
 template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
     switch (cls) {
-    case 0: launch_wstream<9, 64, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;
-    case 1: launch_wstream<10, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
-    case 2: launch_wstream<11, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
-    case 3: launch_wstream<12, 128, 2, 8, SMALL>(a, nrows, num_cu, lds, s); break;
-    case 4: launch_wstream<13, 256, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 0: launch_wstream<8, 64, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 1: launch_wstream<9, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 2: launch_wstream<10, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 3: launch_wstream<11, 256, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 4: launch_wstream<12, 256, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 5: launch_wstream<13, 256, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 6: launch_wstream<14, 256, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
     default: break;
     }
 }
@@ -242,6 +244,7 @@ struct Round {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t side = nullptr;     // the few rows of the largest table classes run beside the others
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_cls_done[NHASHMAX] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_cls[NCLASS + 1];  // one in front of every scatter launch (class_timing) and one behind the last
     int launch_cls[NCLASS];         // class id of launch i
     int nlaunch = 0;
@@ -267,6 +270,7 @@ struct Round {
         for (auto &e : ev_cls) if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        for (auto &e : ev_cls_done) if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
     }
 
@@ -890,7 +894,7 @@ struct Round {
         // workgroup: launched after the others they are a tail on a nearly empty chip (0.27 of 4.1 ms; 74 of 760 us for a
         // 1/8 shard).  They go first, on a side stream, and the wide classes fill the rest of the chip meanwhile.
         const int first_side = 6;
-        const bool use_side = !class_timing && nhash > first_side;
+        const bool use_side = !class_timing && (nhash > first_side || streaming);
         if (use_side) {
             if (!side) {
                 HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
@@ -975,16 +979,28 @@ struct Round {
             hipLaunchKernelGGL(k_scatter_big, dim3(bigsc_blocks), dim3(256), 0, s, bb);
             HIPCHK(hipGetLastError());
         };
-        if (use_side) {
-            for (int c = nhash - 1; c >= first_side; c--) { launch_stream_cls(c, side); launch_class(c, side); } // longest rows first
+        if (use_side && streaming) {
+            // the streaming kernels on the main stream, longest rows first; the hash-table kernel of a class -- it only gets what its
+            // streaming twin hands back -- follows that twin on the side stream, beside the streaming kernels of the shorter rows
+            if (!ev_cls_done[0]) for (auto &e : ev_cls_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (int c = nhash - 1; c >= 0; c--) {
+                launch_stream_cls(c, stream);
+                HIPCHK(hipEventRecord(ev_cls_done[c], stream));
+                HIPCHK(hipStreamWaitEvent(side, ev_cls_done[c], 0));
+                launch_class(c, side);
+            }
+            launch_stream_fix(stream);
             launch_big(side);
             HIPCHK(hipEventRecord(ev_join, side));
-            for (int c = 0; c < first_side; c++) launch_stream_cls(c, stream);
-            launch_stream_fix(stream);
+            HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
+        } else if (use_side) {
+            for (int c = nhash - 1; c >= first_side; c--) launch_class(c, side); // longest rows first
+            launch_big(side);
+            HIPCHK(hipEventRecord(ev_join, side));
             for (int c = 0; c < first_side; c++) launch_class(c, stream);
             HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
         } else {
-            for (int c = 0; c < nhash; c++) launch_stream_cls(c, stream);
+            for (int c = nhash - 1; c >= 0; c--) launch_stream_cls(c, stream);
             launch_stream_fix(stream);
             for (int c = 0; c < nhash; c++) launch_class(c, stream);
             launch_big(stream);

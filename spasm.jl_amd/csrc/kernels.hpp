@@ -989,6 +989,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
         STAMP(2); // waiting for them
 #endif
         int r_ent = 0, r_seg = 0; // this row's contribution to the counters, 32-bit until the row is done
+        bool anylong = false;
         // (C) accumulate: the own entry, then per round the (up to) 3 entries of this lane as one batch
         {
             const int oc[1] = {own.x};
@@ -1012,10 +1013,25 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_scatter(ScatterArgs a)
                 }
                 if (SCATTER_DBG(a, 2)) asm volatile("" ::"v"(bc[0]), "v"(bv[0]));
                 else table_try_n<LOGT, 3, SMALL>(tab, rl, bc, bv, valid, a.ctr);
-                const int2 *up = a.UPN + (unsigned)rec[r].z;
-                for (int k = gl + 3 * G; k < npn[r]; k += G) { // pivot rows longer than 24 entries
-                    const int2 uu = up[k];
-                    table_add<LOGT, SMALL>(tab, uu.x, ZpAcc<SMALL>::mul_lazy(F, nm, uu.y), a.ctr);
+                anylong |= npn[r] > 3 * G;
+            }
+        }
+        // runs longer than 24 entries (rows of W: a row the streaming kernel handed back has a few runs of ~170): the rest of a run is
+        // taken by all 64 lanes of the wave whose group had its head, through the retry list like everything else
+        if (__ballot(anylong) != 0) {
+            const int nrec = min(ll, NG * MAXR);
+            for (int e = 0; e < nrec; e++) { // (wave-uniform)
+                if (((e % NG) * G) / 64 != (WAVE_ROW ? 0 : wave)) continue; // the head went to a group of another wave
+                const int4 le = a.Lpool[d.l_start + e];
+                if (le.y == 0 || le.w <= 3 * G) continue;
+                const int nm2 = -le.y;
+                const int2 *up2 = a.UPN + (unsigned)le.z;
+                for (int k0 = 3 * G; k0 < le.w; k0 += 64) {
+                    const int k = k0 + lane;
+                    const int2 uu = up2[min(k, le.w - 1)];
+                    const int oc[1] = {uu.x};
+                    const Acc ov[1] = {ZpAcc<SMALL>::mul_lazy(F, nm2, uu.y)};
+                    table_try_n<LOGT, 1, SMALL>(tab, rl, oc, ov, k < le.w ? 1u : 0u, a.ctr);
                 }
             }
         }

@@ -57,8 +57,8 @@ constexpr int SLCAP = 64; // entries of a row's list of second-table losers
 constexpr int SFIX = 64;  // duplicates a row may collect before it is handed to the hash-table kernel: random columns collide rarely (a row
                           // of 2560 out of 10^6 expects 3), but two runs of W that share a pivot row share its ~17 columns
 
-// LDS of one row: first table (4 B x 2^logt), second table (a quarter), 64 B of counters, fix-up list, loser list
-__host__ __device__ constexpr size_t stream_row_bytes(int logt) { return ((size_t)5 << logt) + 64 + (size_t)SFIX * 8 + (size_t)SLCAP * 16; }
+// LDS of one row: three tables of 2^logt, 2^(logt-1) and 2^(logt-2) words, 64 B of counters, fix-up list, loser list
+__host__ __device__ constexpr size_t stream_row_bytes(int logt) { return ((size_t)7 << logt) + 64 + (size_t)SFIX * 8 + (size_t)SLCAP * 16; }
 __host__ __device__ constexpr size_t stream_lds_bytes(int logt, int tpr, int wpb) { return tpr == 64 ? stream_row_bytes(logt) * (size_t)wpb : stream_row_bytes(logt); }
 
 // the row's fix-up list: {owner position << 14 | own position, value}; positions are below 2^14
@@ -68,7 +68,7 @@ __device__ __forceinline__ void stream_fix_push(int *s_nfix, int2 *fix, int fcap
     if (i < fcap) fix[i] = make_int2((int)(((unsigned)owner_pos << 14) | (unsigned)pos), v);
 }
 
-constexpr unsigned STREAM_K1 = 0x9E3779u, STREAM_K2 = 0x85EBCBu; // odd: c -> c * K mod 2^24 is a bijection
+constexpr unsigned STREAM_K1 = 0x9E3779u, STREAM_K2 = 0x85EBCBu, STREAM_K3 = 0xC2B2AFu; // odd: c -> c * K mod 2^24 is a bijection
 
 // multiplier * entry as THE balanced residue (it is stored as it stands)
 template <bool SMALL> __device__ __forceinline__ int stream_mul(const ZpField &F, int nm, int y);
@@ -194,30 +194,29 @@ __device__ __forceinline__ unsigned stream_mul24(int c, unsigned k)
     return x;
 }
 
-// the two direct-mapped tables of a row
+// The three direct-mapped tables of a row: 2^LOGT words at most 5/8 full, then a half and a quarter of that for the entries that
+// met another column in the table before (about 30 %, then 6 %, then 0.4 % of the entries: those go to the row's list).
 template <int LOGT> struct StreamTabs {
-    static constexpr int L2 = LOGT - 2;
-    unsigned *t1, *t2;
-    __device__ __forceinline__ void bind(unsigned char *p) { t1 = (unsigned *)p; t2 = t1 + (1 << LOGT); }
-    // first table: the word wanted for (column, position + 1) and its slot
-    __device__ __forceinline__ unsigned want1(int c, int pos1, unsigned &slot) const
+    static constexpr int WORDS = (1 << LOGT) + (1 << (LOGT - 1)) + (1 << (LOGT - 2));
+    unsigned *t1;
+    __device__ __forceinline__ void bind(unsigned char *p) { t1 = (unsigned *)p; }
+    // level lv (0, 1, 2): the word wanted for (column, position + 1) and its slot (index into t1[], the tables lie back to back)
+    template <int LV> __device__ __forceinline__ unsigned want(int c, int pos1, unsigned &slot) const
     {
-        const unsigned x = stream_mul24(c, STREAM_K1);
-        slot = __builtin_amdgcn_ubfe(x, 24 - LOGT, LOGT);
-        return (x << 14) | (unsigned)pos1;
-    }
-    __device__ __forceinline__ unsigned want2(int c, int pos1, unsigned &slot) const
-    {
-        const unsigned x = stream_mul24(c, STREAM_K2);
-        slot = __builtin_amdgcn_ubfe(x, 24 - L2, L2);
+        constexpr int L = LOGT - LV;
+        constexpr unsigned K = LV == 0 ? STREAM_K1 : (LV == 1 ? STREAM_K2 : STREAM_K3);
+        constexpr unsigned BASE = LV == 0 ? 0u : (LV == 1 ? (1u << LOGT) : (1u << LOGT) + (1u << (LOGT - 1)));
+        const unsigned x = stream_mul24(c, K);
+        slot = BASE + __builtin_amdgcn_ubfe(x, 24 - L, L);
         return (x << 14) | (unsigned)pos1;
     }
 };
 
 // Insertion of N entries of a lane: all first-table CAS are in flight at once, then the second-table CAS of those that met
-// another column -- two LDS round trips per batch instead of 2 N.  Outcome per entry, as ONE word and without branches:
+// another column, then the third -- three LDS round trips per batch instead of up to 3 N.  Outcome per entry, as ONE word and
+// without branches:
 //   t = 0 if the CAS found the slot empty, else (word found) ^ (word wanted):  t = 0  the entry is in (new, or it met itself: a
-//   lane past the end of a pivot row repeats its last entry);  0 < t < 2^14  same column under another position: a duplicate;
+//   lane past the end of a run repeats its last entry);  0 < t < 2^14  same column under another position: a duplicate;
 //   t >= 2^14  another column.
 // left[j] = 0 when entry j needs nothing more; otherwise the rare side decodes it with stream_outcome().
 template <int LOGT, int N>
@@ -225,25 +224,33 @@ __device__ __forceinline__ void stream_insert_n(const StreamTabs<LOGT> &tb, cons
 {
     unsigned w1[N], s1[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) w1[j] = tb.want1(c[j], pos1[j], s1[j]);
+    for (int j = 0; j < N; j++) w1[j] = tb.template want<0>(c[j], pos1[j], s1[j]);
 #pragma unroll
     for (int j = 0; j < N; j++) old[j] = atomicCAS(&tb.t1[s1[j]], 0u, w1[j]);
-    unsigned t1[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) t1[j] = old[j] == 0 ? 0u : old[j] ^ w1[j];
+    for (int j = 0; j < N; j++) left[j] = old[j] == 0 ? 0u : old[j] ^ w1[j];
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        left[j] = t1[j];
-        if (t1[j] >= 0x4000u) { // another column in the slot: second table
+        if (left[j] >= 0x4000u) { // another column in the slot: second table
             unsigned s2;
-            const unsigned w2 = tb.want2(c[j], pos1[j], s2);
-            const unsigned o2 = atomicCAS(&tb.t2[s2], 0u, w2);
+            const unsigned w2 = tb.template want<1>(c[j], pos1[j], s2);
+            const unsigned o2 = atomicCAS(&tb.t1[s2], 0u, w2);
             old[j] = o2;
             left[j] = o2 == 0 ? 0u : o2 ^ w2;
         }
     }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (left[j] >= 0x4000u) { // and again: third table
+            unsigned s3;
+            const unsigned w3 = tb.template want<2>(c[j], pos1[j], s3);
+            const unsigned o3 = atomicCAS(&tb.t1[s3], 0u, w3);
+            old[j] = o3;
+            left[j] = o3 == 0 ? 0u : o3 ^ w3;
+        }
+    }
 }
-// what is left of an insertion: 0 nothing, 1 duplicate of the entry at position (old & 0x3fff) - 1, 2 lost in both tables
+// what is left of an insertion: 0 nothing, 1 duplicate of the entry at position (old & 0x3fff) - 1, 2 lost in all three tables
 __device__ __forceinline__ unsigned stream_outcome(unsigned left) { return left == 0 ? 0u : (left < 0x4000u ? 1u : 2u); }
 template <int LOGT>
 __device__ __forceinline__ unsigned stream_insert(const StreamTabs<LOGT> &tb, int c, int pos1, unsigned &old)
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
     constexpr int T1 = 1 << LOGT;
     constexpr int NW = WAVE_ROW ? 1 : WPB; // waves sharing a row
     constexpr int FCAP = SFIX;
-    constexpr size_t TABB = (size_t)5 * T1, MISCB = 64, FIXB = (size_t)FCAP * 8;
+    constexpr size_t TABB = (size_t)7 * T1, MISCB = 64, FIXB = (size_t)FCAP * 8;
     constexpr size_t SLOT = stream_row_bytes(LOGT);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int tid = threadIdx.x;
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
 
     const int count = *a.class_count;
     if ((WAVE_ROW ? (int)blockIdx.x * WPB : (int)blockIdx.x) >= count) return;
-    for (int s = rtid * 4; s < T1 + T1 / 4; s += TPR * 4) *(int4 *)(tb.t1 + s) = make_int4(0, 0, 0, 0);
+    for (int s = rtid * 4; s < StreamTabs<LOGT>::WORDS; s += TPR * 4) *(int4 *)(tb.t1 + s) = make_int4(0, 0, 0, 0);
     if (rtid < 16) misc[rtid] = (rtid & 7) >= 4 ? INT_MAX : 0;
     __syncthreads();
 
@@ -572,6 +579,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
                 }
             }
         }
+        STAMP(0); // requests for the rows ahead, chunk table, own entries
         // Chunks are taken Q at a time: the first-table CAS of all Q are in flight together, then the second-table ones.  The
         // first D chunks come from the ring, in straight-line code (a loop header would cost a vmcnt(0)); what a row has beyond
         // them (few rows do) is loaded and used group by group in a loop.
@@ -720,7 +728,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
         }
         STAMP(3); // end of the row
         // ---- reset: the tables, and the other parity's words (nobody reads them any more: every wave is past its barrier)
-        for (int s = rtid * 4; s < T1 + T1 / 4; s += TPR * 4) *(int4 *)(tb.t1 + s) = make_int4(0, 0, 0, 0);
+        for (int s = rtid * 4; s < StreamTabs<LOGT>::WORDS; s += TPR * 4) *(int4 *)(tb.t1 + s) = make_int4(0, 0, 0, 0);
         if (WAVE_ROW) {
             if (lane < 2) mrow[lane] = 0;
             __builtin_amdgcn_wave_barrier();
