@@ -152,15 +152,15 @@ template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1> void laun
 // wave per row up to 640 entries, then 2 and 4 waves
 const int kNumStreamClasses = 7;
 inline int stream_logt(int c) { return 8 + c; }
-inline int stream_tpr(int c) { return c <= 2 ? 64 : 256; }
-inline int stream_wpb(int c) { (void)c; return 4; }
+inline int stream_tpr(int c) { return c <= 2 ? 64 : (c == 3 ? 128 : 256); }
+inline int stream_wpb(int c) { return c == 3 ? 2 : 4; }
 template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
     switch (cls) {
     case 0: launch_wstream<8, 64, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;
     case 1: launch_wstream<9, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
     case 2: launch_wstream<10, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
-    case 3: launch_wstream<11, 256, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;
+    case 3: launch_wstream<11, 128, 2, 8, SMALL>(a, nrows, num_cu, lds, s); break;
     case 4: launch_wstream<12, 256, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
     case 5: launch_wstream<13, 256, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
     case 6: launch_wstream<14, 256, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
@@ -713,6 +713,7 @@ struct Round {
                 wp.sflag = sflag.p;
                 wp.free_cols = free_cols;
                 wp.max_bound = (int)kClasses[kNumStreamClasses - 1].cap;
+                wp.wave_row_bound = (int)kClasses[2].cap;
                 wp.overflow_list = wreject_list.p;
                 wp.overflow_count = &ctr.p->wplan_reject;
                 wp.ctr = ctr.p;

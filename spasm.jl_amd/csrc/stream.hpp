@@ -319,8 +319,9 @@ __global__ void k_wcolinfo(int m, const int *__restrict__ qinv_r, const i64d *__
 }
 
 // ------------------------------------------------------------------------------------------------
-// The plan of a row's Schur row under W: one record per entry on a pivot column, their stream positions (runs first, in record
-// order; the row's own non-pivot entries fill the stream from its end), the bound = length of the stream.  Takes the place of
+// The plan of a row's Schur row under W: the run of every entry on a pivot column, cut into chunks of 64 entries with one record
+// each, their stream positions (runs first, in record order; the row's own non-pivot entries fill the stream from its end), the
+// bound = length of the stream.  Takes the place of
 // the combine kernel: no Uinv rows to merge, no headers to gather.  TEAM lanes per row, two passes over the row's entries
 // (the first counts, so that the records can be allocated; the entries come back from L2).
 // ------------------------------------------------------------------------------------------------
@@ -342,6 +343,7 @@ struct WPlanArgs {
     int *sflag;
     int free_cols;
     int max_bound;             // rows with a longer stream are left to the multiplier-list path
+    int wave_row_bound;        // streams up to this length are handled by one wave
     int *overflow_list;        // rows this kernel leaves to the combine kernel
     int *overflow_count;
     RoundCounters *ctr;
@@ -359,30 +361,34 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
         const int t = (int)t64;
         const i64d st = a.rstart[t];
         const int ln = a.rlen[t];
-        // ---- pass 1: entries on pivot columns (P) and on the others (nN)
-        int P = 0, nN = 0;
+        // ---- pass 1: entries on pivot columns and the chunks of their runs (C), entries on the other columns (nN)
+        int C = 0, nN = 0;
         bool zero_own = false;
         u64d pm = 0;
         for (int k0 = 0; k0 < ln; k0 += TEAM) {
             const int k = k0 + tl;
             bool isP = false, isN = false;
+            int nch = 0;
             if (k < ln) {
                 const int2 e = a.ent[st + k];
                 isP = (a.pbits[(unsigned)e.x >> 5] >> (e.x & 31)) & 1u;
                 isN = !isP;
                 zero_own |= e.y == 0;
+                if (isP) nch = (a.wcol[e.x].y + 63) >> 6;
             }
             const u64d mP = team_ballot<TEAM>(isP);
             if (k0 < 64) pm |= mP << (k0 & 63);
-            P += __popcll(mP);
+            int tot;
+            (void)team_incl_scan<TEAM>(nch, tot);
+            C += tot;
             nN += __popcll(team_ballot<TEAM>(isN));
         }
         const bool anyzero = team_ballot<TEAM>(zero_own) != 0;
         u64d base = 0;
-        if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)P, a.npool);
+        if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)C, a.npool);
         base = __shfl(base, 0, TEAM);
         const bool room = base != ~0ull;
-        // ---- pass 2: the records, with the running total of the run lengths as stream position
+        // ---- pass 2: one record per chunk of 64 entries of a run: {stream position << 16 | entries, -a_c, offset, entries}
         i64d run = 0;
         int w = 0;
         for (int k0 = 0; k0 < ln && room; k0 += TEAM) {
@@ -396,24 +402,31 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
             int4 ci = make_int4(-1, 0, 0, 0);
             if (isP) ci = a.wcol[e.x];
             const int len = isP ? ci.y : 0;
-            int tot;
+            const int nch = (len + 63) >> 6;
+            int tot, ctot;
             const int incl = team_incl_scan<TEAM>(len, tot);
-            const u64d mP = team_ballot<TEAM>(isP);
-            if (isP) {
-                const i64d pre = run + incl - len;
-                const unsigned px = (pre < 0x8000 ? (unsigned)pre : 0x7fffu) << 16 | (unsigned)min(len, 0xffff);
-                a.Lpool[base + w + __popcll(mP & ((1ull << tl) - 1ull))] = make_int4((int)px, zp_neg(F, e.y), ci.z, len);
+            const int cincl = team_incl_scan<TEAM>(nch, ctot);
+            const int nm = zp_neg(F, e.y);
+            i64d pre = run + incl - len;
+            int4 *out = a.Lpool + base + w + (cincl - nch);
+            for (int q = 0; q < nch; q++) { // (the lanes of a team have runs of different lengths)
+                const int clen = min(64, len - 64 * q);
+                const unsigned px = (pre < 0x8000 ? (unsigned)pre : 0x7fffu) << 16 | (unsigned)clen;
+                out[q] = make_int4((int)px, nm, (int)((unsigned)ci.z + 64u * (unsigned)q), clen);
+                pre += clen;
             }
-            w += __popcll(mP);
+            w += ctot;
             run += tot;
         }
+        const int P = C; // records of the row
         if (tl == 0) {
             if (!room) {
                 atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1);
                 a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0;
             } else {
                 const i64d bound = run + nN;
-                const bool ok = bound <= (i64d)a.free_cols && bound <= (i64d)a.max_bound && !anyzero && P <= 64;
+                // a wave holds 64 chunk records: one wave per row up to wave_row_bound entries, four beyond
+                const bool ok = bound <= (i64d)a.free_cols && bound <= (i64d)a.max_bound && !anyzero && P <= (bound <= (i64d)a.wave_row_bound ? 64 : 256);
                 if (ok) {
                     a.Lstart[t] = (i64d)base;
                     a.Llen[t] = P;
@@ -431,21 +444,21 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// SCATTER along the rows of W (or along any record list: a record names a run of entries and its multiplier).  The runs of a
-// row are cut into chunks of 64 entries; a wave takes chunks (its share of them when several waves work on the row), loads
-// the next batch while it works on the current one, and treats every entry as k_stream did: multiply, store at its stream
-// position, one CAS in the direct-mapped tables for the duplicate check.
-// TPR = threads per row (64: a wave per row, WPB rows per workgroup; else the workgroup).  D = chunk loads in flight per wave.
+// SCATTER along the rows of W.  A row's record list names its chunks (up to 64 consecutive entries of a run, their multiplier
+// and stream position); record w + g * NW is the g-th chunk of wave w of the NW waves that share the row, and lane g of that wave
+// holds it.  Every entry is treated as k_stream treated it: multiply, store at its stream position, one CAS in the
+// direct-mapped tables for the duplicate check.  D chunk loads per wave are in flight: those of a row are requested while the
+// row before it is being finished.
+// TPR = threads per row (64: a wave per row, WPB rows per workgroup; else the workgroup).
 // ------------------------------------------------------------------------------------------------
 template <int LOGT, int TPR, int WPB, int D, bool SMALL, int MINW>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
 {
     constexpr bool WAVE_ROW = (TPR == 64);
     static_assert(WAVE_ROW || TPR == WPB * 64, "a row is owned by one wave or by the whole workgroup");
-    constexpr int T1 = 1 << LOGT;
     constexpr int NW = WAVE_ROW ? 1 : WPB; // waves sharing a row
     constexpr int FCAP = SFIX;
-    constexpr size_t TABB = (size_t)7 * T1, MISCB = 64, FIXB = (size_t)FCAP * 8;
+    constexpr size_t TABB = (size_t)4 * StreamTabs<LOGT>::WORDS, MISCB = 64, FIXB = (size_t)FCAP * 8;
     constexpr size_t SLOT = stream_row_bytes(LOGT);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int tid = threadIdx.x;
@@ -469,16 +482,16 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
 
     const int first = WAVE_ROW ? (int)blockIdx.x * WPB + wave : (int)blockIdx.x;
     const int stride = WAVE_ROW ? (int)gridDim.x * WPB : (int)gridDim.x;
-    u64d c_nnz = 0, c_ent = 0, c_seg = 0;
+    u64d c_nnz = 0, c_ent = 0, c_seg = 0; // (wave-uniform: they live in SGPRs)
     int c_rows = 0, c_redo = 0;
     int par = 0;
 
-    // ---- pipeline: descriptors of this row and the next two (a fourth in flight), records and first own entries of this row
-    // and the next.  Unconditional loads with clamped indices (beyond the last row: the last descriptor again).
+    // ---- pipeline: descriptors of this row and the next two (a fourth in flight), this wave's chunk records and the first own
+    // entries of this row and the next.  Unconditional loads with clamped indices (beyond the last row: the last descriptor again).
     RowDesc d, dn, dnn;
     int4 rec, rec_n;
     int2 own, own_n;
-    auto load_rec = [&](const RowDesc &dd) { return a.Lpool[dd.l_start + min(lane, max(dd.llen - 1, 0))]; };
+    auto load_rec = [&](const RowDesc &dd) { return a.Lpool[dd.l_start + min(rw + lane * NW, max(dd.llen - 1, 0))]; };
     auto load_own = [&](const RowDesc &dd) { return a.ent[dd.ent_start + min(lane, max(dd.len - 1, 0))]; };
     d = stream_desc_unpack(stream_desc_load(a.desc + min(first, count - 1)));
     dn = stream_desc_unpack(stream_desc_load(a.desc + min(first + stride, count - 1)));
@@ -487,31 +500,23 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
     own = load_own(d);
     rec_n = load_rec(dn);
     own_n = load_own(dn);
-    // the ring of chunk loads and what each slot holds (wave-uniform: stream position of the run, multiplier, run length, chunk)
+    // the ring of chunk loads.  Always D requests per row (slots past the wave's last chunk repeat it, a wave without chunks reads
+    // entry 0): with a number of loads that depends on the row the compiler can only wait for ALL loads in flight when an older
+    // one is needed.
     int2 ring[D];
-    int r_pre[D], r_nm[D], r_len[D], r_k[D];
-#pragma unroll
-    for (int j = 0; j < D; j++) { ring[j] = make_int2(0, 0); r_pre[j] = 0; r_nm[j] = 0; r_len[j] = 1; r_k[j] = 0; }
-    if (first < count) { // the first row's first chunks
-        const int ll0 = d.llen;
-        const int mylen0 = lane < ll0 ? rec.w : 0;
-        int F0;
-        const int cend0 = team_incl_scan<64>((mylen0 + 63) >> 6, F0);
-        const int cstart0 = cend0 - ((mylen0 + 63) >> 6);
-        const int my0 = F0 > rw ? (F0 - rw + NW - 1) / NW : 0;
+    auto request = [&](const int4 &rc, int nmine, bool live) {
 #pragma unroll
         for (int j = 0; j < D; j++) {
-            if (j < my0) {
-                const int f = rw + j * NW;
-                const int s = max(__popcll(__ballot(cstart0 <= f && lane < ll0)) - 1, 0);
-                r_k[j] = f - __builtin_amdgcn_readlane(cstart0, s);
-                r_len[j] = __builtin_amdgcn_readlane(rec.w, s);
-                r_nm[j] = -__builtin_amdgcn_readlane(rec.y, s);
-                r_pre[j] = (int)((unsigned)__builtin_amdgcn_readlane(rec.x, s) >> 16);
-                ring[j] = a.UPN[(size_t)(unsigned)__builtin_amdgcn_readlane(rec.z, s) + (unsigned)min(r_k[j] * 64 + lane, r_len[j] - 1)];
-            }
+            const int g = min(j, max(nmine - 1, 0));
+            const bool have = live && nmine > 0;
+            const unsigned off = have ? (unsigned)__builtin_amdgcn_readlane(rc.z, g) : 0u;
+            const int clen = have ? __builtin_amdgcn_readlane(rc.w, g) : 1;
+            if (SCATTER_DBG(a, 8)) ring[j] = make_int2(lane + 4096 * j, 1);
+            else ring[j] = a.UPN[(size_t)off + (unsigned)min(lane, clen - 1)];
         }
-    }
+    };
+    auto chunks_of = [&](int ll) { return ll > rw ? (ll - rw + NW - 1) / NW : 0; };
+    request(rec, chunks_of(d.llen), first < count);
 
 #ifdef SPASM_STAMPS
     u64d st_sum[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -525,23 +530,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
         int *const mrow = misc + par * 8;
         unsigned char *const rowp = (unsigned char *)(a.Sent + d.s_start);
         int mylead = INT_MAX;
-        // ---- the chunks of the row's runs: lane r holds record r
-        const int mylen = lane < ll ? rec.w : 0;
-        int F_chunks;
-        const int cend = team_incl_scan<64>((mylen + 63) >> 6, F_chunks); // chunks up to and including this record's
-        const int cstart = cend - ((mylen + 63) >> 6);
-        // ---- the row's chunks, D loads in flight: this wave's g-th chunk is chunk f = rw + g * NW of the row, i.e. chunk
-        // k = f - cstart[s] of record s = the last record with cstart <= f.  The first D were requested while the previous row
-        // was being finished (below); slot g % D is refilled with chunk g + D as soon as chunk g is done.
-        auto locate = [&](int f, int &pre, int &nm, int &len, int &k, unsigned &off) {
-            const int s = max(__popcll(__ballot(cstart <= f && lane < ll)) - 1, 0);
-            k = f - __builtin_amdgcn_readlane(cstart, s);
-            len = __builtin_amdgcn_readlane(rec.w, s);
-            nm = -__builtin_amdgcn_readlane(rec.y, s);
-            pre = (int)((unsigned)__builtin_amdgcn_readlane(rec.x, s) >> 16);
-            off = (unsigned)__builtin_amdgcn_readlane(rec.z, s);
-        };
-        const int my_chunks = F_chunks > rw ? (F_chunks - rw + NW - 1) / NW : 0;
+        const int my_chunks = chunks_of(ll);
         // ---- the row's own entries on non-pivot columns: they fill the stream from its end (their rank is a ballot), one wave
         int nN = 0;
         if (WAVE_ROW || wave == 0) {
@@ -579,20 +568,23 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
                 }
             }
         }
-        STAMP(0); // requests for the rows ahead, chunk table, own entries
-        // Chunks are taken Q at a time: the first-table CAS of all Q are in flight together, then the second-table ones.  The
-        // first D chunks come from the ring, in straight-line code (a loop header would cost a vmcnt(0)); what a row has beyond
-        // them (few rows do) is loaded and used group by group in a loop.
+        STAMP(0); // requests for the rows ahead, own entries
+        // ---- the chunks, Q at a time: the first-table CAS of all Q are in flight together, then the second- and third-table ones.
+        // The first D come from the ring, in straight-line code (a loop header would cost a vmcnt(0)); what a wave has beyond them
+        // (few rows) is loaded and used group by group in a loop.
         constexpr int Q = D >= 4 ? 4 : D;
         static_assert(D % Q == 0, "whole groups of slots");
-        auto do_group = [&](const int2 (&e)[Q], const int (&g_pre)[Q], const int (&g_nm)[Q], const int (&g_len)[Q], const int (&g_k)[Q], int nthere) {
-            int cc[Q], vv[Q], pp[Q];
+        auto do_group = [&](const int2 (&e)[Q], int g0, int nthere) {
+            int cc[Q], vv[Q], pp[Q], cl[Q];
             unsigned oo[Q], left[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) {
+                const int g = min(g0 + q, max(my_chunks - 1, 0));
+                const int rx = __builtin_amdgcn_readlane(rec.x, g);
+                cl[q] = rx & 0xffff;
                 cc[q] = e[q].x;
-                vv[q] = stream_mul<SMALL>(F, g_nm[q], e[q].y);
-                pp[q] = g_pre[q] + min(g_k[q] * 64 + lane, g_len[q] - 1) + 1;
+                vv[q] = stream_mul<SMALL>(F, -__builtin_amdgcn_readlane(rec.y, g), e[q].y);
+                pp[q] = (int)((unsigned)rx >> 16) + min(lane, cl[q] - 1) + 1;
                 oo[q] = 0;
                 left[q] = 0;
             }
@@ -619,64 +611,38 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
             unsigned any = 0;
 #pragma unroll
             for (int q = 0; q < Q; q++) any |= left[q];
-            if (__ballot(any != 0) != 0) { // rare: duplicates, double losers; a lane past the end of its run holds a copy
+            if (__ballot(any != 0) != 0) { // rare: duplicates, triple losers; a lane past the end of its chunk holds a copy
 #pragma unroll
                 for (int q = 0; q < Q; q++)
-                    stream_report(stream_outcome(left[q]), oo[q], q < nthere && g_k[q] * 64 + lane < g_len[q], cc[q], vv[q], pp[q], mrow, fix, FCAP, lst);
+                    stream_report(stream_outcome(left[q]), oo[q], q < nthere && lane < cl[q], cc[q], vv[q], pp[q], mrow, fix, FCAP, lst);
             }
         };
 #pragma unroll
         for (int j0 = 0; j0 < D; j0 += Q) {
             if (j0 < my_chunks) { // (wave-uniform)
                 int2 e[Q];
-                int g_pre[Q], g_nm[Q], g_len[Q], g_k[Q];
 #pragma unroll
-                for (int q = 0; q < Q; q++) { e[q] = ring[j0 + q]; g_pre[q] = r_pre[j0 + q]; g_nm[q] = r_nm[j0 + q]; g_len[q] = r_len[j0 + q]; g_k[q] = r_k[j0 + q]; }
-                do_group(e, g_pre, g_nm, g_len, g_k, my_chunks - j0);
+                for (int q = 0; q < Q; q++) e[q] = ring[j0 + q];
+                do_group(e, j0, my_chunks - j0);
             }
         }
         if (my_chunks > D) {
             for (int g0 = D; g0 < my_chunks; g0 += Q) {
+                // (more than 64 chunks per wave do not occur: the plan kernel leaves such rows to the lists)
                 int2 e[Q];
-                int g_pre[Q], g_nm[Q], g_len[Q], g_k[Q];
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    unsigned off;
-                    locate(rw + min(g0 + q, my_chunks - 1) * NW, g_pre[q], g_nm[q], g_len[q], g_k[q], off);
-                    e[q] = a.UPN[(size_t)off + (unsigned)min(g_k[q] * 64 + lane, g_len[q] - 1)];
+                    const int g = min(g0 + q, my_chunks - 1);
+                    e[q] = a.UPN[(size_t)(unsigned)__builtin_amdgcn_readlane(rec.z, g) + (unsigned)min(lane, __builtin_amdgcn_readlane(rec.w, g) - 1)];
                 }
-                do_group(e, g_pre, g_nm, g_len, g_k, my_chunks - g0);
+                do_group(e, g0, my_chunks - g0);
             }
         }
         STAMP(1); // the chunks
         // ---- the first D chunks of the NEXT row are requested now: they fly while this row is finished
-        {
-            const int ll_n = dn.llen;
-            const int mylen_n = lane < ll_n ? rec_n.w : 0;
-            int Fn;
-            const int cend_n = team_incl_scan<64>((mylen_n + 63) >> 6, Fn);
-            const int cstart_n = cend_n - ((mylen_n + 63) >> 6);
-            const int my_n = Fn > rw ? (Fn - rw + NW - 1) / NW : 0;
-            // always D requests (slots past the row's last chunk repeat it, a row without chunks reads entry 0): with a number of
-            // loads that depends on the row the compiler can only wait for ALL of them when the next older load is needed
-#pragma unroll
-            for (int j = 0; j < D; j++) {
-                const int f = min(rw + j * NW, max(Fn - 1, 0));
-                const int s = max(__popcll(__ballot(cstart_n <= f && lane < ll_n)) - 1, 0);
-                const bool have = Fn > 0 && w + stride < count;
-                r_k[j] = f - __builtin_amdgcn_readlane(cstart_n, s);
-                r_len[j] = have ? __builtin_amdgcn_readlane(rec_n.w, s) : 1;
-                r_nm[j] = -__builtin_amdgcn_readlane(rec_n.y, s);
-                r_pre[j] = (int)((unsigned)__builtin_amdgcn_readlane(rec_n.x, s) >> 16);
-                const unsigned off = have ? (unsigned)__builtin_amdgcn_readlane(rec_n.z, s) : 0u;
-                if (!have) r_k[j] = 0;
-                if (SCATTER_DBG(a, 8)) ring[j] = make_int2(r_k[j] * 64 + lane + 4096 * j, 1);
-                else ring[j] = a.UPN[(size_t)off + (unsigned)min(r_k[j] * 64 + lane, r_len[j] - 1)];
-            }
-            (void)my_n;
-        }
+        request(rec_n, chunks_of(dn.llen), w + stride < count);
         STAMP(2); // requests for the next row
-        // ---- end of the row: leftmost column, losers of both tables, duplicates
+        // ---- end of the row: leftmost column, losers of all tables, duplicates
         mylead = wave_min_i32(mylead);
         int lead_out = mylead;
         if (!WAVE_ROW) {
@@ -691,7 +657,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
             const int nlist = __builtin_amdgcn_readfirstlane(((lds_vint *)mrow)[1]); // (an LDS-qualified read: a generic one drains vmcnt too)
             redo = nlist > SLCAP;
             if (nlist != 0 && !redo) {
-                // entries that lost in both tables are in neither: compare them among themselves (a handful)
+                // entries that lost in all tables are in none: compare them among themselves (a handful)
                 for (int b = 0; b < nlist; b += 64) {
                     const int i = b + lane;
                     int4 me = make_int4(-1, 0, -1, 0);
