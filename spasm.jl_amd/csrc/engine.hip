@@ -214,6 +214,8 @@ struct Round {
     DevBuf<int> Wlen, wreject_list;
     DevMat Zrows;                   // npiv rows without entries: what W is scattered "from"
     i64 wtotal = 0;
+    i64 own_total = 0;              // entries of the part of the UPN buffer behind W that takes the rows' own non-pivot entries
+    DevBuf<u64d> own_ctr;           // its bump counters
     DevBuf<u64d> pool_ctr;          // NPOOL sharded bump counters
     int npool_active = NPOOL;       // regions in use by the current solve
     u64d region_cap = 0;
@@ -560,7 +562,8 @@ struct Round {
     // W = -(I + U_PP)^-1 U_PN, once per round, after prepare_uinv: row i = - sum over the entries (j, u) of row i of Uinv of u * U_PN[j],
     // i.e. a scatter round over npiv rows without entries of their own whose "multiplier lists" are the rows of Uinv.  Costs about
     // uinv_nnz / npiv times the entries of U_PN: worth it when many more rows than pivots are reduced.
-    void prepare_w(i64 expected_rows = ((i64)1 << 62))
+    // own_entries: upper bound of the entries of the rows that will be reduced along W (their non-pivot entries are copied behind W)
+    void prepare_w(i64 expected_rows, i64 own_entries)
     {
         use_w = false;
         wtotal = 0;
@@ -582,11 +585,13 @@ struct Round {
         HIPCHK(hipMemcpyAsync(Llen.p, UinvLen.p, (size_t)npiv * sizeof(int), hipMemcpyDeviceToDevice, stream));
         run_bounds(npiv);
         const i64 tot = fetch_total_bound(npiv);
-        // offsets into the U_PN + W buffer are 32-bit; a W much larger than U means long chains: the lists cope better
-        if (utotal + tot >= (i64)0xffffffffLL || tot > 64 * std::max<i64>(utotal, 1 << 16)) return;
+        // room for the rows' own entries: what they have, half as much again for uneven regions, and a block per team of the plan kernel
+        const i64 own_room = own_entries + own_entries / 2 + (i64)num_cu * 16 * 16 * 256 + NPOOL;
+        // offsets into the U_PN + W + own buffer are 32-bit; a W much larger than U means long chains: the lists cope better
+        if (utotal + tot + own_room >= (i64)0xffffffffLL || tot > 64 * std::max<i64>(utotal, 1 << 16)) return;
         size_t fr = 0, totmem = 0;
         HIPCHK(hipMemGetInfo(&fr, &totmem));
-        if ((size_t)(tot + utotal) * 2 * sizeof(int2) > fr / 2) return;
+        if ((size_t)(tot + utotal + own_room) * 2 * sizeof(int2) > fr / 2) return;
         S.ent.ensure((size_t)tot + 1);
         Zrows.n = npiv;
         Zrows.m = m;
@@ -601,7 +606,7 @@ struct Round {
         fetch_counters(); // synchronises; throws if a table filled up
         // behind U_PN in one buffer, so that a record's offset means the same to every scatter kernel
         DevBuf<int2> both;
-        both.alloc((size_t)(utotal + tot) + 1);
+        both.alloc((size_t)(utotal + tot + own_room) + 1);
         if (utotal > 0) HIPCHK(hipMemcpyAsync(both.p, UPN.p, (size_t)utotal * sizeof(int2), hipMemcpyDeviceToDevice, stream));
         if (tot > 0) HIPCHK(hipMemcpyAsync(both.p + utotal, S.ent.p, (size_t)tot * sizeof(int2), hipMemcpyDeviceToDevice, stream));
         Wstart.ensure((size_t)npiv + 1);
@@ -614,6 +619,8 @@ struct Round {
         HIPCHK(hipStreamSynchronize(stream));
         UPN = std::move(both);
         wtotal = tot;
+        own_total = own_room;
+        own_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
         use_w = true;
     }
 
@@ -671,7 +678,7 @@ struct Round {
             c.UinvPool = UinvPool.p;
             c.Lpool = Lpool.p;
             c.Lidx = want_idx ? Lidx.p : nullptr;
-            c.sflag = sflag.p;
+            c.sflag = nullptr; // (only the plan along W marks rows for the streaming kernel)
             c.lpool_cap = region_cap;
             c.pool_ctr = pool_ctr.p;
             c.npool = npool_active;
@@ -706,6 +713,11 @@ struct Round {
                 wp.lpool_cap = region_cap;
                 wp.pool_ctr = pool_ctr.p;
                 wp.npool = npool_active;
+                wp.upn = UPN.p;
+                wp.own_base = (unsigned)(utotal + wtotal);
+                wp.own_cap = (u64d)own_total / (u64d)npool_active;
+                wp.own_ctr = own_ctr.p;
+                HIPCHK(hipMemsetAsync(own_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
                 wp.Lstart = Lstart.p;
                 wp.Llen = Llen.p;
                 wp.bound = bound.p;
@@ -723,7 +735,6 @@ struct Round {
                 HIPCHK(hipGetLastError());
                 c.retry = wreject_list.p;
                 c.retry_count = &ctr.p->wplan_reject;
-                c.sflag = nullptr; // rows with multiplier lists go to the hash-table kernels
             }
             {
                 constexpr int TEAM = 16, LOGC = 8, TPB = 256; // up to 128 distinct pivots per row
@@ -1407,7 +1418,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         R->mark_local(*cur, 0);
         R->build_U(*cur, R->pivrow.p);
         R->prepare_uinv(R->nnp);
-        R->prepare_w(R->nnp);
+        R->prepare_w(R->nnp, cur_nnz);
         const int nnp = R->nnp;
         // The multiplier records and the slots of the Schur rows of ALL non-pivot rows normally fit (config 3: 0.5 + 4.6 GB).
         // Rounds whose rows reach tens of thousands of pivots (Macaulay-like) can need more than the device has: the rows
@@ -2217,7 +2228,7 @@ spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries
     HIPCHK(hipEventRecord(R.ev[0], s));
     R.build_U(PM, P->rowsrc.p);
     R.prepare_uinv(); // a plan is run many times: Uinv always pays
-    R.prepare_w();
+    R.prepare_w((i64)1 << 62, P->nnz_in);
     HIPCHK(hipEventRecord(R.ev[1], s));
     plan_dry_run(P, 4 * std::max<i64>(P->nnz_in, 1 << 14));
     S->plan = nullptr; // ownership passes to the caller
@@ -2331,7 +2342,7 @@ spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi, int
     R.mark_local(P->A, 0, lo, hi, 1, stride);
     R.build_U(P->A, R.pivrow.p);
     R.prepare_uinv(); // a plan is run many times: Uinv always pays
-    R.prepare_w();
+    R.prepare_w((i64)1 << 62, P->nnz_in);
     HIPCHK(hipEventRecord(R.ev[1], s));
     plan_dry_run(P.get(), 4 * spasm_nnz(A));
     return P.release();

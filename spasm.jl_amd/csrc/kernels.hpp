@@ -621,7 +621,8 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a)
             d.ent_start = a.start[row];
             d.l_start = a.Lstart[t];
             d.s_start = a.sstart[t];
-            d.len = a.len[row];
+            // (a row planned along W has its own entries among its chunks: the scatter kernels must not take them from the matrix again)
+            d.len = (a.sflag && a.sflag[t]) ? 0 : a.len[row];
             d.llen = a.Llen[t];
             d.t = t;
             d.bound = (int)(a.bound[t] < (i64d)INT_MAX ? a.bound[t] : (i64d)INT_MAX);

@@ -332,10 +332,14 @@ struct WPlanArgs {
     const int2 *ent;
     const unsigned *pbits;     // bit j: column j is a pivot column of this round
     const int4 *wcol;
-    int4 *Lpool;               // records {position << 16 | len, -a_c, offset in the U_PN + W buffer, len}
-    u64d lpool_cap;
+    int4 *Lpool;               // records {position << 16 | entries, -multiplier, offset in the U_PN + W + own buffer, entries}
+    u64d lpool_cap;            // records per pool region
     u64d *pool_ctr;
     int npool;
+    int2 *upn;                 // the U_PN + W + own buffer: the rows' own entries on non-pivot columns are copied behind W
+    unsigned own_base;         // where that part starts
+    u64d own_cap;              // entries per region of it
+    u64d *own_ctr;             // its bump counters (NPOOL, POOL_STRIDE apart)
     i64d *Lstart;
     int *Llen;
     i64d *bound;
@@ -350,57 +354,109 @@ struct WPlanArgs {
     ZpField F;
 };
 
+// The plan of a row's Schur row under W: its stream = the row's own entries on non-pivot columns (copied, compacted, behind W: they
+// are then chunks like the others, with multiplier 1) followed by the run of every entry on a pivot column; one record per chunk
+// of 64 consecutive entries; the bound = length of the stream.  Takes the place of the combine kernel: no Uinv rows to merge, no
+// headers to gather.  TEAM lanes per row; rows of up to 2 TEAM entries (all of config 3) stay in registers between the
+// counting and the writing pass, longer ones are read twice.  Records and own entries are carved from blocks a team takes from
+// the pools now and then (one returning atomic per ~16 rows instead of two per row).
 template <int TEAM, int TPB>
 __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
 {
     constexpr int TEAMS = TPB / TEAM;
+    constexpr u64d RBLK = 64, OBLK = 256;
     const int tl = threadIdx.x % TEAM;
     const int team = threadIdx.x / TEAM;
     const ZpField F = a.F;
-    for (i64d t64 = (i64d)blockIdx.x * TEAMS + team; t64 < a.nrows; t64 += (i64d)gridDim.x * TEAMS) {
+    u64d rpos = 0, rend = 0, opos = 0, oend = 0; // the team's current blocks (uniform in the team)
+    auto take = [&](u64d &pos, u64d &end, u64d need, u64d blk, u64d *ctr, u64d cap) -> u64d {
+        if (pos + need > end) {
+            const u64d n = need > blk ? need : blk;
+            u64d b = 0;
+            if (tl == 0) b = pool_alloc(ctr, cap, n, a.npool);
+            b = __shfl(b, 0, TEAM);
+            if (b == ~0ull) return ~0ull;
+            pos = b;
+            end = b + n;
+        }
+        const u64d r = pos;
+        pos += need;
+        return r;
+    };
+    auto is_piv = [&](int c) -> bool { return (a.pbits[(unsigned)c >> 5] >> (c & 31)) & 1u; };
+    // pipeline: (start, length) and the first 2 TEAM entries of the next row are loaded one row ahead
+    const i64d first = (i64d)blockIdx.x * TEAMS + team, stride = (i64d)gridDim.x * TEAMS;
+    i64d st_n = 0;
+    int ln_n = 0;
+    int2 ea_n = make_int2(0, 0), eb_n = make_int2(0, 0);
+    if (first < a.nrows) {
+        st_n = a.rstart[first];
+        ln_n = a.rlen[first];
+        if (tl < ln_n) ea_n = a.ent[st_n + tl];
+        if (tl + TEAM < ln_n) eb_n = a.ent[st_n + tl + TEAM];
+    }
+    for (i64d t64 = first; t64 < a.nrows; t64 += stride) {
         const int t = (int)t64;
-        const i64d st = a.rstart[t];
-        const int ln = a.rlen[t];
-        // ---- pass 1: entries on pivot columns and the chunks of their runs (C), entries on the other columns (nN)
+        const i64d st = st_n;
+        const int ln = ln_n;
+        const int2 ea = ea_n, eb = eb_n;
+        if (t64 + stride < a.nrows) {
+            st_n = a.rstart[t64 + stride];
+            ln_n = a.rlen[t64 + stride];
+            ea_n = make_int2(0, 0);
+            eb_n = make_int2(0, 0);
+            if (tl < ln_n) ea_n = a.ent[st_n + tl];
+            if (tl + TEAM < ln_n) eb_n = a.ent[st_n + tl + TEAM];
+        }
+        // ---- pass 1: count.  C chunks of runs, nN entries on non-pivot columns
         int C = 0, nN = 0;
         bool zero_own = false;
         u64d pm = 0;
+        int4 ci_a = make_int4(-1, 0, 0, 0), ci_b = ci_a;
+        bool pa = false, pb = false;
         for (int k0 = 0; k0 < ln; k0 += TEAM) {
             const int k = k0 + tl;
-            bool isP = false, isN = false;
-            int nch = 0;
-            if (k < ln) {
-                const int2 e = a.ent[st + k];
-                isP = (a.pbits[(unsigned)e.x >> 5] >> (e.x & 31)) & 1u;
-                isN = !isP;
-                zero_own |= e.y == 0;
-                if (isP) nch = (a.wcol[e.x].y + 63) >> 6;
-            }
+            const bool valid = k < ln;
+            int2 e = k0 == 0 ? ea : (k0 == TEAM ? eb : make_int2(0, 0));
+            if (k0 >= 2 * TEAM && valid) e = a.ent[st + k];
+            const bool isP = valid && is_piv(e.x);
+            int4 ci = make_int4(-1, 0, 0, 0);
+            if (isP) ci = a.wcol[e.x];
+            if (k0 == 0) { ci_a = ci; pa = isP; }
+            if (k0 == TEAM) { ci_b = ci; pb = isP; }
+            zero_own |= valid && e.y == 0;
             const u64d mP = team_ballot<TEAM>(isP);
             if (k0 < 64) pm |= mP << (k0 & 63);
             int tot;
-            (void)team_incl_scan<TEAM>(nch, tot);
+            (void)team_incl_scan<TEAM>(isP ? (ci.y + 63) >> 6 : 0, tot);
             C += tot;
-            nN += __popcll(team_ballot<TEAM>(isN));
+            nN += __popcll(team_ballot<TEAM>(valid && !isP));
         }
         const bool anyzero = team_ballot<TEAM>(zero_own) != 0;
-        u64d base = 0;
-        if (tl == 0) base = pool_alloc(a.pool_ctr, a.lpool_cap, (u64d)C, a.npool);
-        base = __shfl(base, 0, TEAM);
-        const bool room = base != ~0ull;
-        // ---- pass 2: one record per chunk of 64 entries of a run: {stream position << 16 | entries, -a_c, offset, entries}
-        i64d run = 0;
-        int w = 0;
+        const int own_chunks = (nN + 63) >> 6;
+        const int R = C + own_chunks;
+        const u64d base = take(rpos, rend, (u64d)R, RBLK, a.pool_ctr, a.lpool_cap);
+        const u64d obase = base == ~0ull ? ~0ull : take(opos, oend, (u64d)nN, OBLK, a.own_ctr, a.own_cap);
+        // ---- pass 2: write.  The stream: own entries first (positions 0 .. nN-1), then the runs in entry order
+        i64d run = nN;
+        int w = own_chunks, no = 0;
+        const bool room = base != ~0ull && obase != ~0ull;
         for (int k0 = 0; k0 < ln && room; k0 += TEAM) {
             const int k = k0 + tl;
-            int2 e = make_int2(0, 0);
-            bool isP = false;
-            if (k < ln) {
-                e = a.ent[st + k];
-                isP = (a.pbits[(unsigned)e.x >> 5] >> (e.x & 31)) & 1u;
+            const bool valid = k < ln;
+            int2 e = k0 == 0 ? ea : (k0 == TEAM ? eb : make_int2(0, 0));
+            if (k0 >= 2 * TEAM && valid) e = a.ent[st + k];
+            bool isP = k0 == 0 ? pa : (k0 == TEAM ? pb : false);
+            int4 ci = k0 == 0 ? ci_a : (k0 == TEAM ? ci_b : make_int4(-1, 0, 0, 0));
+            if (k0 >= 2 * TEAM) {
+                isP = valid && is_piv(e.x);
+                if (isP) ci = a.wcol[e.x];
             }
-            int4 ci = make_int4(-1, 0, 0, 0);
-            if (isP) ci = a.wcol[e.x];
+            // the entry itself, when it sits on a non-pivot column
+            const u64d mN = team_ballot<TEAM>(valid && !isP);
+            if (valid && !isP) a.upn[(size_t)a.own_base + obase + no + __popcll(mN & ((1ull << tl) - 1ull))] = e;
+            no += __popcll(mN);
+            // its run, when it sits on a pivot column
             const int len = isP ? ci.y : 0;
             const int nch = (len + 63) >> 6;
             int tot, ctot;
@@ -418,18 +474,23 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
             w += ctot;
             run += tot;
         }
-        const int P = C; // records of the row
+        if (room) // the own entries as chunks with multiplier 1 (the scatter kernels subtract record.y times the entry)
+            for (int q = tl; q < own_chunks; q += TEAM) {
+                const int clen = min(64, nN - 64 * q);
+                a.Lpool[base + q] = make_int4((int)(((unsigned)(64 * q) << 16) | (unsigned)clen), -1, (int)(a.own_base + (unsigned)obase + 64u * (unsigned)q), clen);
+            }
         if (tl == 0) {
-            if (!room) {
+            if (base == ~0ull) { // the record pool is full: the host grows it and runs the plan again
                 atomicAdd(&ctr_shard(a.ctr)->lpool_overflow, 1);
                 a.Llen[t] = 0; a.Lstart[t] = 0; a.bound[t] = 0;
             } else {
-                const i64d bound = run + nN;
-                // a wave holds 64 chunk records: one wave per row up to wave_row_bound entries, four beyond
-                const bool ok = bound <= (i64d)a.free_cols && bound <= (i64d)a.max_bound && !anyzero && P <= (bound <= (i64d)a.wave_row_bound ? 64 : 256);
+                const i64d bound = run;
+                // a wave holds 64 chunk records: one wave per row up to wave_row_bound entries, four beyond.  (No room for the own
+                // entries -- the regions of that buffer fill unevenly -- also sends the row to the lists.)
+                const bool ok = room && bound <= (i64d)a.free_cols && bound <= (i64d)a.max_bound && !anyzero && R <= (bound <= (i64d)a.wave_row_bound ? 64 : 256);
                 if (ok) {
                     a.Lstart[t] = (i64d)base;
-                    a.Llen[t] = P;
+                    a.Llen[t] = R;
                     a.bound[t] = bound;
                     a.pmask[t] = ln <= 32 ? (long long)pm : -1;
                     a.sflag[t] = 1;
@@ -486,20 +547,16 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
     int c_rows = 0, c_redo = 0;
     int par = 0;
 
-    // ---- pipeline: descriptors of this row and the next two (a fourth in flight), this wave's chunk records and the first own
-    // entries of this row and the next.  Unconditional loads with clamped indices (beyond the last row: the last descriptor again).
+    // ---- pipeline: descriptors of this row and the next two (a fourth in flight), this wave's chunk records of this row and the
+    // next.  Unconditional loads with clamped indices (beyond the last row: the last descriptor again).
     RowDesc d, dn, dnn;
     int4 rec, rec_n;
-    int2 own, own_n;
     auto load_rec = [&](const RowDesc &dd) { return a.Lpool[dd.l_start + min(rw + lane * NW, max(dd.llen - 1, 0))]; };
-    auto load_own = [&](const RowDesc &dd) { return a.ent[dd.ent_start + min(lane, max(dd.len - 1, 0))]; };
     d = stream_desc_unpack(stream_desc_load(a.desc + min(first, count - 1)));
     dn = stream_desc_unpack(stream_desc_load(a.desc + min(first + stride, count - 1)));
     dnn = stream_desc_unpack(stream_desc_load(a.desc + min(first + 2 * stride, count - 1)));
     rec = load_rec(d);
-    own = load_own(d);
     rec_n = load_rec(dn);
-    own_n = load_own(dn);
     // the ring of chunk loads.  Always D requests per row (slots past the wave's last chunk repeat it, a wave without chunks reads
     // entry 0): with a number of loads that depends on the row the compiler can only wait for ALL loads in flight when an older
     // one is needed.
@@ -525,50 +582,12 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
     for (int w = first; w < count; w += stride) {
         const int d3_reg = stream_desc_load(a.desc + min(w + 3 * stride, count - 1));
         const int4 rec_nn = load_rec(dnn);
-        const int2 own_nn = load_own(dnn);
-        const int ln = d.len, ll = d.llen, E = d.bound, t_cur = d.t;
+        const int ll = d.llen, E = d.bound, t_cur = d.t;
         int *const mrow = misc + par * 8;
         unsigned char *const rowp = (unsigned char *)(a.Sent + d.s_start);
         int mylead = INT_MAX;
         const int my_chunks = chunks_of(ll);
-        // ---- the row's own entries on non-pivot columns: they fill the stream from its end (their rank is a ballot), one wave
-        int nN = 0;
-        if (WAVE_ROW || wave == 0) {
-            int q_own = 0;
-            if (d.pmask >= 0) q_own = ((d.pmask >> lane) & 1) ? 0 : -1;
-            else if (lane < ln) q_own = a.qinv_r[own.x];
-            // first chunk straight-line, the rest in a loop: at a loop header the compiler waits for EVERY load in flight
-            // (s_waitcnt vmcnt(0)), the requests for the rows ahead included
-            auto own_chunk = [&](const int2 e, const bool nonpiv) {
-                const u64d m = __ballot(nonpiv);
-                const int cnt = __popcll(m);
-                const int pos1 = E - nN - cnt + __popcll(m & lanemask_lt()) + 1;
-                if (nonpiv) {
-                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)e.y << 32) | (unsigned)e.x, (long long *)(rowp + ((unsigned)(pos1 - 1) << 3)));
-                    mylead = min(mylead, e.x);
-                    if (!SCATTER_DBG(a, 2)) {
-                        unsigned old;
-                        const unsigned res = stream_insert<LOGT>(tb, e.x, pos1, old);
-                        if (res) stream_report(res, old, true, e.x, e.y, pos1, mrow, fix, FCAP, lst);
-                    }
-                }
-                nN += cnt;
-            };
-            own_chunk(own, lane < ln && q_own < 0);
-            if (ln > 64) {
-                for (int k0 = 64; k0 < ln; k0 += 64) { // (rows longer than a wave: wave-uniform trip count)
-                    const int k = k0 + lane;
-                    int2 e = make_int2(0, 0);
-                    bool nonpiv = false;
-                    if (k < ln) {
-                        e = a.ent[d.ent_start + k];
-                        nonpiv = a.qinv_r[e.x] < 0;
-                    }
-                    own_chunk(e, nonpiv);
-                }
-            }
-        }
-        STAMP(0); // requests for the rows ahead, own entries
+        STAMP(0); // requests for the rows ahead
         // ---- the chunks, Q at a time: the first-table CAS of all Q are in flight together, then the second- and third-table ones.
         // The first D come from the ring, in straight-line code (a loop header would cost a vmcnt(0)); what a wave has beyond them
         // (few rows) is loaded and used group by group in a loop.
@@ -688,7 +707,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
                 }
                 c_nnz += (u64d)E;
                 c_rows += E > 0;
-                c_ent += (u64d)ln + (u64d)(E - nN); // entries streamed: the own entries + the runs
+                c_ent += (u64d)E; // entries streamed: the own entries and the runs
                 c_seg += 1 + (u64d)ll;
             }
         }
@@ -709,7 +728,6 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
         dn = dnn;
         dnn = stream_desc_unpack(d3_reg);
         rec = rec_n; rec_n = rec_nn;
-        own = own_n; own_n = own_nn;
         STAMP(5); // rotation: waits for the descriptor / records / own entries requested at the top
     }
 #ifdef SPASM_STAMPS
