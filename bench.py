@@ -7,8 +7,9 @@ all work buffers already resident in HBM.  With N GPUs (one process per GPU, lau
 torch.distributed.run) the non-pivot rows are block-partitioned over the ranks (BASELINE config 4,
 strong scaling: the matrix is fixed); every rank elects the same pivots and holds the same U, rows
 never move.  For N > 1 every rank uploads only its row block and the round's pivot rows are exchanged once in
-the setup (all-reduce(MIN) of the election keys + all-gather of the elected rows, RCCL over xGMI;
-SPASM_BENCH_EXCHANGE=0 replicates the matrix instead); the timed region has no data-path collective.
+the setup (all-reduce(MIN) of the election keys + all-gather of the elected rows, RCCL over xGMI, timed on its own and
+reported as `pivot_row_exchange_rank0`; SPASM_BENCH_EXCHANGE=0 replicates the matrix instead, explicitly); the timed
+region has no data-path collective.  A failing exchange ends the run with a non-zero exit code.
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the scatter launch of
 the busiest hash-table class): algorithmic bytes per launch over its HIP-event duration on the
@@ -90,27 +91,22 @@ def main():
         # exchanged with an all-gather (RCCL over xGMI), after which U is identical on all ranks
         from spasm_jl_amd import sharded
 
-        try:
-            engine = sharded.GpuShardEngine(A, lo, hi, stride=stride)
+        # (an exchange that fails is fatal: a run that silently replicated the matrix instead would not measure config 4)
+        engine = sharded.GpuShardEngine(A, lo, hi, stride=stride)
+        xt = []
+        for rep in range(3):  # the exchange alone, timed: all-reduce(MIN) of the keys + all-gather of the rows + import (U, Uinv, W build)
+            if rep:
+                engine.close()
+                engine = sharded.GpuShardEngine(A, lo, hi, stride=stride)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
             t_x = time.time()
             npiv_x, exchange = sharded.exchange_pivot_rows(engine)
             torch.cuda.synchronize()
-            exchange["seconds_incl_U_build"] = round(time.time() - t_x, 4)
-            plan = engine.plan
-            ok = 1
-        except Exception as exc:  # the exchange could only be rehearsed over gloo on a 1-GPU box: keep the run measurable
-            exchange = {"error": repr(exc), "fallback": "matrix replicated on every rank"}
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int64, device=cdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:  # all ranks take the same path
-            if engine is not None:
-                engine.close()
-                engine = None
-            exchange = exchange if "error" in exchange else {"error": "another rank failed", "fallback": "matrix replicated on every rank"}
-            plan = lib.spasm_amd_schur_plan_create_strided(A.data, lo, hi, stride)
-            if not plan:
-                raise SystemExit("plan_create failed: " + S._abi.last_error())
+            xt.append(time.time() - t_x)
+        exchange["seconds_incl_U_build"] = [round(x, 4) for x in xt]
+        plan = engine.plan
     else:
         plan = lib.spasm_amd_schur_plan_create_strided(A.data, lo, hi, stride)
         if not plan:
@@ -192,7 +188,10 @@ def main():
             "ms_per_launch": round(k_ms, 4),
             "round_algorithmic_read_GBs": round(d["read_bytes"] / ((d["ms_solve"] + d["ms_scatter"]) * 1e-3) / 1e9, 1)
             if (d["ms_solve"] + d["ms_scatter"]) > 0 else None,
-            "round_ms": {"solve": round(d["ms_solve"], 4), "scatter": round(d["ms_scatter"], 4)},
+            # per-round setup the timed steps do not repeat (a plan keeps Uinv and W): wall time with host synchronisations
+            "round_ms": {"solve": round(d["ms_solve"], 4), "scatter": round(d["ms_scatter"], 4),
+                         "uinv_build": round(d["ms_uinv"], 4), "w_build": round(d["ms_w"], 4)},
+            "ms_per_round_incl_setup": round(ms_per_step + d["ms_uinv"] + d["ms_w"], 4),
             "per_class_ms": {"hash": [round(x, 4) for x in d["ms_class"][:8]], "stream": [round(x, 4) for x in d["ms_class"][8:15]]},
             "per_class_rows": {"hash": d["rows_class"][:8], "stream": d["rows_class"][8:15]},
             "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"], "stream_fix_ms": round(d["ms_class"][15], 4),
@@ -208,7 +207,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int32 (GF(p) balanced residues, lazy i32 accumulation)",
+            "dtype": "int32 (GF(p) balanced residues)",
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE config 3: {n}x{m} CSR, {args.row_nnz} nnz/row, p={args.prime}, seed 0x5A5A0003, Schur round 0",
@@ -238,21 +237,22 @@ def main():
 
 
 def cpu_baseline(A, target_seconds):
-    """The oracle (CPU restatement of libspasm's reach + scatter Schur round, OpenMP) on a bounded sample:
-    the same matrix and the same pivots, but only the non-pivot rows of a leading row block are reduced."""
+    """The oracle (CPU restatement of libspasm's reach + scatter Schur round, OpenMP) on a bounded sample: the same matrix
+    and the same pivots, but only the non-pivot rows of a leading row block are reduced.  Timed with all host threads
+    (the reported value) and with one thread; a real libspasm named by $SPASM_LIB is timed beside it when it loads."""
     import oracle_ffi as O
 
     n = A.n
     probe = min(n, 20000)
     _, info = O.schur_round(A, row_lo=0, row_hi=probe)
     rate = info["nnz_reduced"] / max(info["sec_schur"], 1e-9)
-    rows = int(min(n, max(probe, probe * target_seconds / max(info["sec_schur"], 1e-9))))
+    rows = int(min(n, max(probe, probe * 0.6 * target_seconds / max(info["sec_schur"], 1e-9))))
     if rows > probe:
         _, info = O.schur_round(A, row_lo=0, row_hi=rows)
         rate = info["nnz_reduced"] / max(info["sec_schur"], 1e-9)
     else:
         rows = probe
-    return {
+    out = {
         "value": rate,
         "unit": "nnz/s",
         "cores": info["threads"],
@@ -260,6 +260,40 @@ def cpu_baseline(A, target_seconds):
         "sample": f"non-pivot rows among the first {rows} of {n} rows, same pivots/U as the full round "
                   f"({info['nnz_reduced']} nnz reduced in {info['sec_schur']:.2f} s; libspasm-algorithm CPU restatement, not libspasm)",
     }
+    # one thread (SURVEY 8d asks for both): a sample sized for ~0.3 of the budget
+    try:
+        rows1 = int(min(n, max(2000, rows * 0.3 * target_seconds / max(info["sec_schur"], 1e-9) / max(info["threads"], 1) * 4)))
+        O.set_threads(1)
+        _, i1 = O.schur_round(A, row_lo=0, row_hi=rows1)
+        out["one_thread"] = {"value": i1["nnz_reduced"] / max(i1["sec_schur"], 1e-9), "cores": 1,
+                             "sample": f"first {rows1} rows, {i1['nnz_reduced']} nnz reduced in {i1['sec_schur']:.2f} s"}
+    except Exception as exc:  # noqa: BLE001 - the baseline is reported, never required
+        out["one_thread"] = {"error": repr(exc)}
+    finally:
+        try:
+            O.set_threads(0)
+        except Exception:  # noqa: BLE001
+            pass
+    # the real thing, if somebody put it on the box: spasm_echelonize of the same matrix, whole factorization
+    lib_path = os.environ.get("SPASM_LIB")
+    if lib_path:
+        out["libspasm"] = real_libspasm_baseline(lib_path, A)
+    return out
+
+
+def real_libspasm_baseline(path, A):
+    """Time a genuine libspasm (cbouilla/spasm) on the host: spasm_echelonize on the same CSR.  The struct layouts are the
+    ones SpaSM.jl mirrors (include/spasm_amd.h); nothing here is needed by the product."""
+    try:
+        lib = C.CDLL(path)
+        lib.spasm_echelonize.restype = C.c_void_p
+        lib.spasm_echelonize.argtypes = [C.c_void_p, C.c_void_p]
+        t0 = time.time()
+        fact = lib.spasm_echelonize(A.data, None)
+        dt = time.time() - t0
+        return {"seconds_echelonize": round(dt, 3), "ok": bool(fact), "path": path}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc), "path": path}
 
 
 if __name__ == "__main__":

@@ -169,6 +169,10 @@ struct spasm_amd_round_stats {
     i64 seg_class[16];
     i64 stream_fix;       /* duplicate columns the streaming kernels merged after the fact */
     i64 stream_redo;      /* rows the streaming kernels handed back to the hash-table kernels */
+    /* per-round setup of the Schur complement, wall time with its host synchronisations: Uinv = (I + U_PP)^-1 and
+     * W = -Uinv * U_PN (included in ms_pivots of an echelonize round; a plan builds them once, when it is created) */
+    double ms_uinv;
+    double ms_w;
 };
 
 typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;
@@ -247,6 +251,12 @@ void spasm_amd_shard_free(spasm_amd_shard *sh);
 
 /* Per-round records of the most recent spasm_echelonize call on this thread. */
 int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds);
+
+/* The device's field arithmetic (csrc/zp.hpp, the restatement of spasm_ZZp.c as SpaSM.jl gives it, src/SpaSM.jl:383-390) on n
+ * test vectors: a, b, c are balanced residues; out receives 8 ints per vector: a*b, a*b+c, a+b, a-b, -a, a^-1 (0 for a = 0),
+ * a*b through the scatter kernels' lazy product + short reduction, 64*a*b through a lazy accumulator + full reduction.
+ * Returns 0 on success. */
+int spasm_amd_zp_probe(i64 prime, int n, const int *a, const int *b, const int *c, int *out);
 
 #ifdef __cplusplus
 }

@@ -604,6 +604,16 @@ ORC_API struct spasm_csr *orc_kernel(const struct spasm_lu *fact)
     return K;
 }
 
+/* n > 0: use n OpenMP threads from now on; n <= 0: back to all of them (the 1-thread CPU baseline of bench.py) */
+ORC_API void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+    (void)n;
+#endif
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

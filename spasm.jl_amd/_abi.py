@@ -91,6 +91,8 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
         ("seg_class", C.c_int64 * 16),
         ("stream_fix", C.c_int64),
         ("stream_redo", C.c_int64),
+        ("ms_uinv", C.c_double),
+        ("ms_w", C.c_double),
     ]
 
     def as_dict(self):
@@ -167,6 +169,7 @@ SIGNATURES = {
     "spasm_amd_schur_plan_fetch": (_P(CsrStruct), [C.c_void_p, _P(C.c_int32)]),
     "spasm_amd_schur_plan_free": (None, [C.c_void_p]),
     "spasm_amd_last_rounds": (C.c_int32, [_P(RoundStats), C.c_int32]),
+    "spasm_amd_zp_probe": (C.c_int32, [C.c_int64, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "spasm_amd_shard_create": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32]),
     "spasm_amd_shard_create_strided": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),
     "spasm_amd_shard_elect": (C.c_int32, [C.c_void_p, C.c_void_p]),

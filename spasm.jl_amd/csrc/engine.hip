@@ -461,7 +461,25 @@ struct Round {
 
     // rows of Uinv: the chain solve applied to the unit rows e_r (once per round, after build_U)
     // expected_rows = rows the solve will process: building Uinv costs npiv chain solves, so it pays only for more rows than that
+    double ms_uinv = 0, ms_w = 0;   // wall time of the last prepare_uinv / prepare_w, host synchronisations included
+
     void prepare_uinv(i64 expected_rows = ((i64)1 << 62))
+    {
+        HIPCHK(hipStreamSynchronize(stream));
+        const double t0 = spasm_wtime();
+        prepare_uinv_(expected_rows);
+        HIPCHK(hipStreamSynchronize(stream));
+        ms_uinv = 1e3 * (spasm_wtime() - t0);
+    }
+    void prepare_w(i64 expected_rows, i64 own_entries)
+    {
+        const double t0 = spasm_wtime();
+        prepare_w_(expected_rows, own_entries);
+        HIPCHK(hipStreamSynchronize(stream));
+        ms_w = 1e3 * (spasm_wtime() - t0);
+    }
+
+    void prepare_uinv_(i64 expected_rows)
     {
         use_uinv = false;
         uinv_nnz = 0;
@@ -563,7 +581,7 @@ struct Round {
     // i.e. a scatter round over npiv rows without entries of their own whose "multiplier lists" are the rows of Uinv.  Costs about
     // uinv_nnz / npiv times the entries of U_PN: worth it when many more rows than pivots are reduced.
     // own_entries: upper bound of the entries of the rows that will be reduced along W (their non-pivot entries are copied behind W)
-    void prepare_w(i64 expected_rows, i64 own_entries)
+    void prepare_w_(i64 expected_rows, i64 own_entries)
     {
         use_w = false;
         wtotal = 0;
@@ -1190,6 +1208,8 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     }
     st.stream_fix = R.hctr.stream_fix;
     st.stream_redo = R.hctr.stream_redo;
+    st.ms_uinv = R.ms_uinv;
+    st.ms_w = R.ms_w;
 }
 
 struct HostU {
@@ -1372,8 +1392,9 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
 
 struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
 {
-    // every pivot is a leftmost entry, so rank, pivot columns and kernel do not depend on the tunables;
-    // enable_dense / sparsity_threshold (reference src/SpaSM.jl:329,337) decide when the dense tail takes over
+    // every pivot is a leftmost entry, so rank, pivot columns and kernel do not depend on the tunables; max_round,
+    // min_pivot_proportion, enable_dense and sparsity_threshold (reference src/SpaSM.jl:329-337) decide how far the sparse rounds
+    // go and what finishes
     struct echelonize_opts dflt;
     if (!opts) { spasm_echelonize_init_opts(&dflt); opts = &dflt; }
     require_device();
@@ -1399,6 +1420,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     if (const char *e = getenv("SPASM_AMD_ROUND_STATS")) R->force_lists = atoi(e) != 0;
     int round = 0;
     i64 cur_live = n;
+    bool gplu_finish = false; // the sparse rounds are over (max_round / min_pivot_proportion) and the dense finish is not an option
     while (cur->n > 0 && m > 0) {
         {
             const i64 cfree = (i64)m - (i64)U.pivcol.size();
@@ -1415,6 +1437,32 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         R->elect_local(*cur, 0);
         R->assign_pivots();
         if (R->npiv == 0) break; // no non-empty row left
+        if (!gplu_finish) {
+            // The reference's round loop (tunables src/SpaSM.jl:333-337): at most max_round sparse rounds, and none that finds
+            // fewer than min_pivot_proportion * min(rows, free columns) pivots ("not enough pivots found; stopping", README.md:32).
+            // What is left then goes to the dense finish when it fits the device and may be used, else to the GPLU-style
+            // finish: more rounds of the same kind until nothing is left (every pivot is a leftmost entry either way, so rank,
+            // pivot columns and kernel do not depend on where the loop stops).
+            const i64 cfree = (i64)m - (i64)U.pivcol.size();
+            const double need = opts->min_pivot_proportion * (double)std::min<i64>(cur_live, cfree);
+            const bool few = (double)R->npiv < need;
+            const bool spent = round >= opts->max_round;
+            if (few || spent) {
+                if (few) spasm_logf("[echelonize] not enough pivots found; stopping (%d < %.0f)\n", R->npiv, need);
+                const double cells = (double)cur_live * (double)cfree;
+                // dense when the remainder is dense enough (the reference's rule) or small enough for the cubic work not to matter
+                // (2^28 cells: a 16384 x 16384 remainder); a large sparse remainder is better served by more sparse rounds
+                const bool worth = (double)cur_nnz > opts->sparsity_threshold * cells || cells <= (double)((i64)1 << 28);
+                if (opts->enable_dense && cells > 0 && cells <= (double)dense_max_entries() && worth) {
+                    spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
+                               cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
+                    run_dense_tail(*cur, R->F, U, stream);
+                    break;
+                }
+                spasm_logf("[echelonize] finishing with GPLU-style rounds%s\n", opts->enable_GPLU ? "" : " (the dense finish does not fit the device)");
+                gplu_finish = true;
+            }
+        }
         R->mark_local(*cur, 0);
         R->build_U(*cur, R->pivrow.p);
         R->prepare_uinv(R->nnp);
@@ -2645,6 +2693,34 @@ SPASM_API void spasm_amd_shard_free(spasm_amd_shard *sh)
     if (!sh) return;
     delete sh->plan;
     delete sh;
+}
+
+// the device's field arithmetic on n test vectors (canonical residues a, b, c in; 8 results per vector out): see k_zp_probe
+SPASM_API int spasm_amd_zp_probe(i64 prime, int n, const int *a, const int *b, const int *c, int *out)
+{
+    spasm_clear_error();
+    try {
+        require_device();
+        if (prime <= 2 || prime > 0xfffffffbLL || n < 0) throw EngineError("bad arguments");
+        const ZpField F = zp_field_make(prime);
+        DevBuf<int> da, db, dc, dout;
+        da.alloc((size_t)n + 1); db.alloc((size_t)n + 1); dc.alloc((size_t)n + 1); dout.alloc((size_t)8 * n + 1);
+        hipStream_t s = nullptr;
+        if (n > 0) {
+            HIPCHK(hipMemcpyAsync(da.p, a, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(db.p, b, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(dc.p, c, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+            if (F.small) hipLaunchKernelGGL(k_zp_probe<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, F, n, da.p, db.p, dc.p, dout.p);
+            else hipLaunchKernelGGL(k_zp_probe<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, F, n, da.p, db.p, dc.p, dout.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)8 * n * sizeof(int), hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_zp_probe: %s", e.what());
+        return 1;
+    }
 }
 
 SPASM_API int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds)

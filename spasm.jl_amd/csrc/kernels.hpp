@@ -144,6 +144,30 @@ template <> __device__ __forceinline__ int team_incl_scan<64>(int x, int &total)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Field arithmetic as the kernels use it, one lane per test vector (tests/test_gpu_zp.py compares with Python integers;
+// reference src/SpaSM.jl:383-390).  out[8 * i ..] = mul, axpy, add, sub, neg, inverse, lazy product reduced
+// (mul_lazy + acc_reduce_short: the scatter kernels' path), sum of 64 lazy products reduced (acc_reduce: the hash tables' path).
+// ------------------------------------------------------------------------------------------------
+template <bool SMALL>
+__global__ void k_zp_probe(ZpField F, int n, const int *__restrict__ a, const int *__restrict__ b, const int *__restrict__ c, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = a[i], y = b[i], z = c[i];
+    int *o = out + (size_t)8 * i;
+    o[0] = zp_mul(F, x, y);
+    o[1] = zp_axpy(F, x, y, z);
+    o[2] = zp_add(F, x, y);
+    o[3] = zp_sub(F, x, y);
+    o[4] = zp_neg(F, x);
+    o[5] = x != 0 ? zp_inverse(F, x) : 0;
+    o[6] = acc_reduce_short<SMALL>(F, ZpAcc<SMALL>::mul_lazy(F, x, y));
+    typename ZpAcc<SMALL>::type acc = 0;
+    for (int k = 0; k < 64; k++) acc += ZpAcc<SMALL>::mul_lazy(F, x, y);
+    o[7] = acc_reduce<SMALL>(F, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // ingest: host-style CSR arrays (p,j,x) -> (start,len,ent)
 // ------------------------------------------------------------------------------------------------
 // values are brought to the canonical balanced residue here, once: the kernels downstream rely on it (the streaming scatter

@@ -46,6 +46,8 @@ def lib():
         h.orc_schur_round_range.restype = _P(CsrStruct)
         h.orc_schur_round_range.argtypes = [_P(CsrStruct), C.c_int, C.c_int, _P(C.c_int64), _P(C.c_double), _P(_P(CsrStruct)), _P(C.c_int)]
         h.orc_num_threads.restype = C.c_int
+        h.orc_set_threads.argtypes = [C.c_int]
+        h.orc_set_threads.restype = None
         _lib = h
     return _lib
 
@@ -128,6 +130,11 @@ def kernel(lu):
 
 def transpose(A):
     return OCSR(lib().orc_transpose(A.data))
+
+
+def set_threads(n):
+    """n > 0: that many OpenMP threads for the oracle's loops from now on; 0: all of them again."""
+    lib().orc_set_threads(int(n))
 
 
 def schur_round(A, want_U=False, row_lo=0, row_hi=None):

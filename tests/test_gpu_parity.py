@@ -598,3 +598,25 @@ def test_fuzz_schur_round_small_primes(S, O):
         assert (st["npiv"], st["applications"], st["nnz_reduced"], st["nnz_out"]) == \
                (info["npiv"], info["applications"], info["nnz_reduced"], info["nnz_out"]), (trial, p, n, m, k)
         assert Sc.rows() == So.rows(), (trial, p, n, m, k)
+
+
+@pytest.mark.gpu
+def test_round_loop_options_change_the_rounds_not_the_result(S, O):
+    """max_round and min_pivot_proportion (reference src/SpaSM.jl:333-335; the stop at README.md:32) decide how many sparse
+    rounds run before the finish takes over; every pivot stays a leftmost entry, so rank, pivot columns and kernel do not
+    move.  The round records (spasm_amd_last_rounds) must show the difference."""
+    A = S.synth_csr(1, 3000, 3000, row_nnz=6, prime=65521, seed=0x0917)
+    ref = S.echelonize(A, max_round=50, min_pivot_proportion=0.0, enable_dense=False)  # sparse rounds to the end
+    n_ref = len(S.last_rounds())
+    one = S.echelonize(A, max_round=1, min_pivot_proportion=0.0)
+    n_one = len(S.last_rounds())
+    none = S.echelonize(A, max_round=50, min_pivot_proportion=0.9)
+    n_none = len(S.last_rounds())
+    dflt = S.echelonize(A)
+    assert n_ref > 2 and n_one == 1 and n_none == 0, (n_ref, n_one, n_none)
+    olu = O.echelonize(A)
+    for f in (ref, one, none, dflt):
+        assert f.r == olu.r
+        assert np.asarray(f.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
+    Kref = S.kernel(ref).rows()
+    assert S.kernel(one).rows() == Kref and S.kernel(none).rows() == Kref and S.kernel(dflt).rows() == Kref == O.kernel(olu).rows()
