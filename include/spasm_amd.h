@@ -211,6 +211,10 @@ int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spasm_amd_roun
 /* Copy the Schur complement of the last run back to host CSR (n_shard_nonpivot x m). p_out (may be
  * NULL) receives, per output row, the index of the originating row of A. */
 struct spasm_csr *spasm_amd_schur_plan_fetch(spasm_amd_schur_plan *plan, int *p_out);
+/* The pivot rows of the plan's round as they enter U (scaled to a unit pivot, reference src/SpaSM.jl:712), in pivot-index order
+ * = ascending pivot column; pivcol_out / row_out (npiv ints each, may be NULL) receive the pivot column and the originating
+ * row of A of each.  What a row-sharded echelonization appends to U after every exchange, without rebuilding it on the host. */
+struct spasm_csr *spasm_amd_schur_plan_fetch_U(spasm_amd_schur_plan *plan, int *pivcol_out, int *row_out);
 void spasm_amd_schur_plan_free(spasm_amd_schur_plan *plan);
 
 /* ---- row-sharded round with an exchange of the pivot rows (one process per GPU; the collectives are the

@@ -165,6 +165,7 @@ SIGNATURES = {
     "spasm_amd_schur_plan_create_strided": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),
     "spasm_amd_schur_plan_run": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "spasm_amd_schur_plan_class_timing": (None, [C.c_void_p, C.c_int32]),
+    "spasm_amd_schur_plan_fetch_U": (_P(CsrStruct), [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),
     "spasm_amd_schur_plan_stats": (C.c_int32, [C.c_void_p, _P(RoundStats)]),
     "spasm_amd_schur_plan_fetch": (_P(CsrStruct), [C.c_void_p, _P(C.c_int32)]),
     "spasm_amd_schur_plan_free": (None, [C.c_void_p]),

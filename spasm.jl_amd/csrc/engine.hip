@@ -1271,44 +1271,19 @@ i64 dense_max_entries()
     return std::max<i64>((i64)1 << 31, (i64)(fr / 3) / 4);
 }
 
-int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
+// Leftmost-pivot elimination of a dense R x C matrix D (row-major, leading dimension ldc, residues mod p) whose column c is
+// column clist[c] of the matrix and whose row r comes from row row_orig[r] of the input; the pivot rows found are appended to U.
+int dense_eliminate(DevBuf<int> &D, int R, int C, i64 ldc, const int *clist, const int *row_orig, const ZpField &F, HostU &U, hipStream_t s)
 {
-    const int n = M.n, m = M.m;
     Scanner scan;
-    // live rows and live columns
-    DevBuf<int> rflag, rscan, rows, cflag, cscan, cmap, clist;
-    rflag.alloc((size_t)n + 1); rscan.alloc((size_t)n + 1); rows.alloc((size_t)n + 1);
-    cflag.alloc((size_t)m + 1); cscan.alloc((size_t)m + 1); cmap.alloc((size_t)m + 1); clist.alloc((size_t)m + 1);
-    hipLaunchKernelGGL(k_flag_live, dim3(cdiv((i64)n + 1, 256)), dim3(256), 0, s, n, M.len.p, rflag.p);
-    HIPCHK(hipGetLastError());
-    scan.exclusive(rflag.p, rscan.p, (size_t)n + 1, s);
-    hipLaunchKernelGGL(k_compact, dim3(cdiv(std::max(n, 1), 256)), dim3(256), 0, s, n, rflag.p, rscan.p, rows.p);
-    HIPCHK(hipGetLastError());
-    cflag.zero(s);
-    if (n > 0) {
-        hipLaunchKernelGGL(k_flag_cols, dim3(cdiv((i64)n * 64, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p, cflag.p);
-        HIPCHK(hipGetLastError());
-    }
-    scan.exclusive(cflag.p, cscan.p, (size_t)m + 1, s);
-    int R = 0, C = 0;
-    HIPCHK(hipMemcpyAsync(&R, rscan.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&C, cscan.p + m, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (R == 0 || C == 0) return 0;
-    hipLaunchKernelGGL(k_col_map, dim3(cdiv(m, 256)), dim3(256), 0, s, m, cflag.p, cscan.p, cmap.p, clist.p);
-    HIPCHK(hipGetLastError());
-    const i64 ldc = ((i64)C + 63) / 64 * 64;
-    DevBuf<int> D, is_piv, pivrow_of_col, prow, fcol;
+    DevBuf<int> is_piv, pivrow_of_col, prow, fcol;
     DevBuf<DenseState> st;
-    D.alloc((size_t)R * (size_t)ldc);
     is_piv.alloc((size_t)R + 1);
     pivrow_of_col.alloc((size_t)C + 1);
     prow.alloc((size_t)ldc);
     fcol.alloc((size_t)R + 1);
     st.alloc(1);
-    D.zero(s); is_piv.zero(s); st.zero(s);
-    hipLaunchKernelGGL(k_dense_fill, dim3(cdiv((i64)R * 64, 256)), dim3(256), 0, s, R, rows.p, M.start.p, M.len.p, M.ent.p, cmap.p, D.p, (i64d)ldc);
-    HIPCHK(hipGetLastError());
+    is_piv.zero(s); st.zero(s);
     const int rc = std::max(R, C);
     if (F.p <= ((i64)1 << 24)) {
         // blocked: panels of DPB columns, f64-MFMA trailing update (exact: 64 * (p/2)^2 < 2^53)
@@ -1370,7 +1345,7 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
     DevBuf<int2> Ufull;
     DevBuf<int> pivcol, porig;
     Ufull.alloc((size_t)tot + 1); pivcol.alloc((size_t)npd + 1); porig.alloc((size_t)npd + 1);
-    hipLaunchKernelGGL(k_dense_emit, dim3(C), dim3(64), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, uoff.p, clist.p, rows.p, M.orig.p,
+    hipLaunchKernelGGL(k_dense_emit, dim3(C), dim3(64), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, uoff.p, clist, row_orig,
                        Ufull.p, pivcol.p, porig.p);
     HIPCHK(hipGetLastError());
     std::vector<i64d> off((size_t)npd + 1);
@@ -1388,6 +1363,45 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
     append_entries(U, Ufull.p, (i64)tot, s);
     spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots\n", R, C, npd);
     return npd;
+}
+
+
+int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
+{
+    const int n = M.n, m = M.m;
+    Scanner scan;
+    // live rows and live columns
+    DevBuf<int> rflag, rscan, rows, cflag, cscan, cmap, clist;
+    rflag.alloc((size_t)n + 1); rscan.alloc((size_t)n + 1); rows.alloc((size_t)n + 1);
+    cflag.alloc((size_t)m + 1); cscan.alloc((size_t)m + 1); cmap.alloc((size_t)m + 1); clist.alloc((size_t)m + 1);
+    hipLaunchKernelGGL(k_flag_live, dim3(cdiv((i64)n + 1, 256)), dim3(256), 0, s, n, M.len.p, rflag.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(rflag.p, rscan.p, (size_t)n + 1, s);
+    hipLaunchKernelGGL(k_compact, dim3(cdiv(std::max(n, 1), 256)), dim3(256), 0, s, n, rflag.p, rscan.p, rows.p);
+    HIPCHK(hipGetLastError());
+    cflag.zero(s);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_flag_cols, dim3(cdiv((i64)n * 64, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p, cflag.p);
+        HIPCHK(hipGetLastError());
+    }
+    scan.exclusive(cflag.p, cscan.p, (size_t)m + 1, s);
+    int R = 0, C = 0;
+    HIPCHK(hipMemcpyAsync(&R, rscan.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&C, cscan.p + m, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (R == 0 || C == 0) return 0;
+    hipLaunchKernelGGL(k_col_map, dim3(cdiv(m, 256)), dim3(256), 0, s, m, cflag.p, cscan.p, cmap.p, clist.p);
+    HIPCHK(hipGetLastError());
+    const i64 ldc = ((i64)C + 63) / 64 * 64;
+    DevBuf<int> D, row_orig;
+    D.alloc((size_t)R * (size_t)ldc);
+    row_orig.alloc((size_t)R + 1);
+    D.zero(s);
+    hipLaunchKernelGGL(k_dense_fill, dim3(cdiv((i64)R * 64, 256)), dim3(256), 0, s, R, rows.p, M.start.p, M.len.p, M.ent.p, cmap.p, D.p, (i64d)ldc);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_gather_int, dim3(cdiv(R, 256)), dim3(256), 0, s, R, rows.p, M.orig.p, row_orig.p);
+    HIPCHK(hipGetLastError());
+    return dense_eliminate(D, R, C, ldc, clist.p, row_orig.p, F, U, s);
 }
 
 struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
@@ -2409,6 +2423,33 @@ void plan_run(spasm_amd_schur_plan *P, hipStream_t s)
     P->ran = true;
 }
 
+// the pivot rows of the plan's round as they enter U: scaled to a unit pivot, in pivot-index order (= ascending pivot column);
+// pivcol_out / row_out (npiv ints each, may be NULL): pivot column and originating row (global row number) of each
+struct spasm_csr *plan_fetch_U(spasm_amd_schur_plan *P, int *pivcol_out, int *row_out)
+{
+    Round &R = P->R;
+    hipStream_t s = R.stream;
+    const int np = R.npiv;
+    struct spasm_csr *Uc = spasm_csr_alloc(np, R.m, R.utotal, P->prime, true);
+    if (!Uc) throw EngineError("out of host memory for the round's U rows");
+    if (np > 0) HIPCHK(hipMemcpyAsync(Uc->p, R.uoff.p, ((size_t)np + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    else Uc->p[0] = 0;
+    if (R.utotal > 0) {
+        DevBuf<int> dj, dx;
+        dj.alloc((size_t)R.utotal);
+        dx.alloc((size_t)R.utotal);
+        hipLaunchKernelGGL(k_split_ent, dim3((unsigned)std::min<i64>((R.utotal + 255) / 256, 65536)), dim3(256), 0, s, (i64d)R.utotal, R.Ufull.p, dj.p, dx.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(Uc->j, dj.p, (size_t)R.utotal * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(Uc->x, dx.p, (size_t)R.utotal * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    if (np > 0 && pivcol_out) HIPCHK(hipMemcpyAsync(pivcol_out, R.pivcol.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (np > 0 && row_out) HIPCHK(hipMemcpyAsync(row_out, R.pivrow.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return Uc;
+}
+
 struct spasm_csr *plan_fetch(spasm_amd_schur_plan *P, int *p_out)
 {
     Round &R = P->R;
@@ -2606,6 +2647,18 @@ SPASM_API struct spasm_csr *spasm_amd_schur_plan_fetch(spasm_amd_schur_plan *pla
         return plan_fetch(plan, p_out);
     } catch (const std::exception &e) {
         spasm_set_error("spasm_amd_schur_plan_fetch: %s", e.what());
+        return nullptr;
+    }
+}
+
+SPASM_API struct spasm_csr *spasm_amd_schur_plan_fetch_U(spasm_amd_schur_plan *plan, int *pivcol_out, int *row_out)
+{
+    spasm_clear_error();
+    try {
+        if (!plan) throw EngineError("null plan");
+        return plan_fetch_U(plan, pivcol_out, row_out);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_schur_plan_fetch_U: %s", e.what());
         return nullptr;
     }
 }

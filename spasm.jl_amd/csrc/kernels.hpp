@@ -2094,7 +2094,7 @@ __global__ void k_dense_count(int C, const int *__restrict__ D, i64d ldc, const 
 }
 
 __global__ void k_dense_emit(int C, const int *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
-                             const i64d *__restrict__ uoff, const int *__restrict__ clist, const int *__restrict__ rows, const int *__restrict__ orig,
+                             const i64d *__restrict__ uoff, const int *__restrict__ clist, const int *__restrict__ row_orig,
                              int2 *__restrict__ Ufull, int *__restrict__ pivcol, int *__restrict__ piv_orig)
 {
     // one wave per pivot column keeps the entries of a U row in ascending column order
@@ -2111,7 +2111,14 @@ __global__ void k_dense_emit(int C, const int *__restrict__ D, i64d ldc, const i
         if (v != 0) Ufull[pos + __popcll(m & lanemask_lt())] = make_int2(clist[j], v);
         pos += __popcll(m);
     }
-    if (lane == 0) { pivcol[k] = clist[c]; piv_orig[k] = orig[rows[p]]; }
+    if (lane == 0) { pivcol[k] = clist[c]; piv_orig[k] = row_orig[p]; }
+}
+
+// out[i] = src[idx[i]]
+__global__ void k_gather_int(int n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
 }
 
 __global__ void k_flag_nonneg(int n, const int *__restrict__ v, int *__restrict__ flag)

@@ -33,6 +33,7 @@ class GpuShardEngine:
             raise RuntimeError("spasm_amd_shard_create failed: " + _abi.last_error())
         self.plan = None
         self.n_own = self.nnz_own = 0
+        self.npiv = 0
 
     def elect(self):
         keys = torch.empty(self.m, dtype=torch.int64, device=self.device)
@@ -48,6 +49,7 @@ class GpuShardEngine:
         if npiv < 0:
             raise RuntimeError("spasm_amd_shard_set_keys failed: " + _abi.last_error())
         self.n_own, self.nnz_own = int(n.value), int(nnz.value)
+        self.npiv = int(npiv)
         return int(npiv), self.n_own, self.nnz_own
 
     def export(self):
@@ -175,6 +177,26 @@ class GpuRoundEngine(GpuShardEngine):
         self._counts = (int(rows.value), int(nnz.value))
         return self._counts
 
+    def round_U(self):
+        """The pivot rows of the imported round as rows of U, from the device (spasm_amd_schur_plan_fetch_U):
+        (row lengths, columns, values, pivot columns, original rows), in pivot order."""
+        import numpy as np
+
+        from .api import CSR
+
+        npiv = int(self.npiv)
+        pc = np.empty(max(npiv, 1), dtype=np.int32)
+        ro = np.empty(max(npiv, 1), dtype=np.int32)
+        P = C.POINTER(C.c_int32)
+        ptr = self.lib.spasm_amd_schur_plan_fetch_U(self.plan, pc.ctypes.data_as(P), ro.ctypes.data_as(P))
+        if not ptr:
+            raise RuntimeError("spasm_amd_schur_plan_fetch_U failed: " + _abi.last_error())
+        Uc = CSR(ptr)
+        up = np.asarray(Uc.p)
+        nz = int(up[Uc.n])
+        return (np.diff(up).astype(np.int64), np.array(Uc.j[:nz], dtype=np.int64), np.array(Uc.x[:nz], dtype=np.int64),
+                pc[:npiv].astype(np.int64), ro[:npiv].astype(np.int64))
+
     def fetch_rows(self):
         import numpy as np
 
@@ -285,28 +307,12 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
             hdr_all = all_gather_var(hdr, counts[:, 0].tolist(), group)
             ent_all = all_gather_var(ent, counts[:, 1].tolist(), group)
             eng.import_(hdr_all, ent_all)
-            # the round's rows of U, as every rank's engine builds them: the elected rows scaled to a unit pivot
-            keys_h = keys.cpu().numpy()
-            h = hdr_all.cpu().numpy().astype(np.int64)
-            e = ent_all.cpu().numpy()
-            order = np.argsort(h[:, 0], kind="stable")           # ascending pivot index = ascending pivot column
-            starts = np.concatenate([[0], np.cumsum(h[:, 1])])
-            sel = _ranges(starts[:-1][order], h[order, 1])
-            cols_all, vals_all = e[sel, 0].astype(np.int64), e[sel, 1].astype(np.int64)
-            rs = np.concatenate([[0], np.cumsum(h[order, 1])]).astype(np.int64)
-            if len(order):
-                # position of the leftmost entry of every row: the smallest of (column, position) keys per segment
-                key = cols_all * (len(cols_all) + 1) + np.arange(len(cols_all), dtype=np.int64)
-                lead_pos = np.minimum.reduceat(key, rs[:-1]) % (len(cols_all) + 1)
-                invs = [pow(int(v) % prime, -1, prime) for v in vals_all[lead_pos]]
-                if prime < (1 << 31):  # residues and inverses below 2^31: the products fit int64
-                    prod = (vals_all % prime) * np.repeat(np.array(invs, dtype=np.int64), h[order, 1]) % prime
-                else:                  # exact python integers
-                    prod = (vals_all.astype(object) % prime) * np.repeat(np.array(invs, dtype=object), h[order, 1]) % prime
-                sv_all = np.where(prod > prime // 2, prod - prime, prod).astype(np.int64)
-                pcs = cols_all[lead_pos]
-                blocks.append((h[order, 1].astype(np.int64), cols_all, sv_all, pcs, (keys_h[pcs] & 0xffffffff).astype(np.int64)))
-                n_u += len(order)
+            # the round's rows of U come from the engine as it built them on the device (scaled to a unit pivot, in pivot order):
+            # nothing is recomputed on the host
+            blk = eng.round_U()
+            if len(blk[0]):
+                blocks.append(blk)
+                n_u += len(blk[0])
             eng.advance()  # the round runs; its Schur rows are the shard's matrix of the next round, still on the device
             rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv),
                            "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4)})

@@ -151,6 +151,18 @@ class NumpyRoundEngine(NumpyShardEngine):
     def counts(self):
         return sum(1 for r in self.rows if r), sum(len(r) for r in self.rows)
 
+    def round_U(self):
+        """the imported round's rows of U in pivot order: (lengths, columns, values (balanced), pivot columns, original rows)"""
+        p = self.p
+        lens, cols, vals = [], [], []
+        for pc in self.pivcols:
+            row = self.U[pc]
+            lens.append(len(row))
+            cols += [c for c, _ in row]
+            vals += [v - p if v > p // 2 else v for _, v in row]
+        return (np.array(lens, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(vals, dtype=np.int64),
+                np.array(self.pivcols, dtype=np.int64), np.array(self.pivrow, dtype=np.int64))
+
     def advance(self):
         """the round's Schur rows replace the shard's rows (pivot rows and eliminated rows become empty)"""
         self.lo = 0
