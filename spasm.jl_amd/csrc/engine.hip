@@ -1210,6 +1210,7 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     st.stream_redo = R.hctr.stream_redo;
     st.ms_uinv = R.ms_uinv;
     st.ms_w = R.ms_w;
+    (void)hipGetLastError(); // (an event that was never recorded makes hipEventElapsedTime fail: not an error of the engine)
 }
 
 struct HostU {
@@ -1404,6 +1405,71 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
     return dense_eliminate(D, R, C, ldc, clist.p, row_orig.p, F, U, s);
 }
 
+// The Schur complement of the round R has prepared (pivots elected, U built), computed straight into a dense matrix over the
+// columns that are left, and eliminated there: the finish of an echelonization whose remainder is dense.  The rows go through the
+// solve in batches (only their multiplier records have to fit, nothing sparse is written).
+void schur_dense_finish(Round &R, const DevMat &cur, int nnp, int chunk, double rec_per_row, i64 max_pool, HostU &U, hipStream_t s)
+{
+    const int m = cur.m;
+    Scanner scan;
+    // columns of the dense matrix: those that hold entries of the current matrix and carry no pivot of this round
+    DevBuf<int> cflag, cscan, cmap, clist;
+    cflag.alloc((size_t)m + 1); cscan.alloc((size_t)m + 1); cmap.alloc((size_t)m + 1); clist.alloc((size_t)m + 1);
+    cflag.zero(s);
+    if (cur.n > 0) {
+        hipLaunchKernelGGL(k_flag_cols, dim3(cdiv((i64)cur.n * 64, 256)), dim3(256), 0, s, cur.n, cur.start.p, cur.len.p, cur.ent.p, cflag.p);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_mask_pivot_cols, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, s, m, R.qinv_r.p, cflag.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(cflag.p, cscan.p, (size_t)m + 1, s);
+    int C = 0;
+    HIPCHK(hipMemcpyAsync(&C, cscan.p + m, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (C == 0 || nnp == 0) return;
+    hipLaunchKernelGGL(k_col_map, dim3(cdiv(m, 256)), dim3(256), 0, s, m, cflag.p, cscan.p, cmap.p, clist.p);
+    HIPCHK(hipGetLastError());
+    const i64 ldc = ((i64)C + 63) / 64 * 64;
+    DevBuf<int> D, row_orig;
+    D.alloc((size_t)nnp * (size_t)ldc);
+    row_orig.alloc((size_t)nnp + 1);
+    D.zero(s);
+    hipLaunchKernelGGL(k_gather_int, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, R.np_rows.p, cur.orig.p, row_orig.p);
+    HIPCHK(hipGetLastError());
+    int off = 0;
+    while (off < nnp) {
+        const int cnt = std::min(chunk, nnp - off);
+        const i64 tot = R.solve_phase(cur, R.np_rows.p + off, nullptr, cnt, std::max<i64>((i64)(rec_per_row * (double)cnt), 1 << 16), max_pool);
+        if (tot < 0) {
+            if (cnt <= 1) throw EngineError("the multiplier records of one row do not fit the device memory");
+            chunk = std::max(1, cnt / 2);
+            continue;
+        }
+        SchurDenseArgs a;
+        a.nrows = cnt;
+        a.roff = off;
+        a.rows = R.np_rows.p + off;
+        a.sflag = R.sflag.p;
+        a.start = cur.start.p;
+        a.len = cur.len.p;
+        a.ent = cur.ent.p;
+        a.qinv_r = R.qinv_r.p;
+        a.Lstart = R.Lstart.p;
+        a.Llen = R.Llen.p;
+        a.Lpool = R.Lpool.p;
+        a.UPN = R.UPN.p;
+        a.cmap = cmap.p;
+        a.D = D.p;
+        a.ldc = (i64d)ldc;
+        a.F = R.F;
+        hipLaunchKernelGGL(k_schur_dense, dim3(std::min(cdiv((i64)cnt * 64, 256), R.num_cu * 8)), dim3(256), 0, s, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        off += cnt;
+    }
+    dense_eliminate(D, nnp, C, ldc, clist.p, row_orig.p, R.F, U, s);
+}
+
 struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
 {
     // every pivot is a leftmost entry, so rank, pivot columns and kernel do not depend on the tunables; max_round,
@@ -1506,19 +1572,53 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         int off = 0, chunk = nnp, nbatch = 0;
         float ms_pivots = 0;
         DevBuf<i64d> app_scan;
-        // records and slots per row, measured on the first rows: a pool that turns out too small costs a whole solve
+        // ---- the density of the Schur complement, estimated before it is built (reference spasm_schur_estimate_density, prototype
+        // src/SpaSM.jl:763-764, log line README.md:25): the Schur rows of a sample of the non-pivot rows (every step-th, at most
+        // 2048; libspasm takes 100 at random) are computed for real.  The same sample sizes the record pool and the slots.
         double rec_per_row = 4.0 * (double)cur_nnz / (double)std::max(nnp, 1), slots_per_row = 0;
-        if (nnp > 16384) {
-            const int probe = 2048;
-            const i64 tp = R->solve_phase(*cur, R->np_rows.p, nullptr, probe, 1 << 20, max_pool);
+        double est_density = -1;
+        const int free_now = m - (int)U.pivcol.size() - R->npiv;
+        if (nnp > 0) {
+            const int probe = std::min(nnp, 2048);
+            const int step = nnp / probe;
+            DevBuf<int> probe_rows;
+            probe_rows.alloc((size_t)probe + 1);
+            hipLaunchKernelGGL(k_pick_stride, dim3(cdiv(probe, 256)), dim3(256), 0, stream, probe, step, R->np_rows.p, probe_rows.p);
+            HIPCHK(hipGetLastError());
+            const i64 tp = R->solve_phase(*cur, probe_rows.p, nullptr, probe, 1 << 20, max_pool);
+            // (the sample's Schur rows are only computed where the answer can matter: the dense finish allowed and within reach)
+            const bool dense_possible = opts->enable_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries();
             if (tp >= 0) {
                 rec_per_row = std::max(rec_per_row, 1.25 * (double)R->pool_used() / probe);
                 slots_per_row = 1.25 * (double)tp / probe;
-            } else {
+            }
+            if (tp >= 0 && tp <= max_slots && dense_possible) {
+                R->S.ent.ensure((size_t)tp + 1);
+                R->run_scatter(*cur, probe_rows.p, probe);
+                R->fetch_counters();
+                if (free_now > 0) est_density = (double)R->hctr.nnz_out / ((double)probe * (double)free_now);
+                spasm_logf("Schur complement is %d x %d, estimated density : %.2f (%d rows sampled)\n", nnp, free_now, est_density, probe);
+            } else if (tp < 0) {
                 rec_per_row = (double)max_pool / probe;
             }
-            const double fit = std::min((double)max_pool / std::max(rec_per_row, 1.0), slots_per_row > 0 ? (double)max_slots / slots_per_row : 1e18);
-            if (fit < (double)nnp) chunk = std::max(1, (int)(0.8 * fit));
+            if (nnp > 16384) {
+                const double fit = std::min((double)max_pool / std::max(rec_per_row, 1.0), slots_per_row > 0 ? (double)max_slots / slots_per_row : 1e18);
+                if (fit < (double)nnp) chunk = std::max(1, (int)(0.8 * fit));
+            }
+        }
+        // ---- dense already?  Then the Schur complement goes straight into the dense matrix of the finish (spasm_schur_dense,
+        // prototype src/SpaSM.jl:765-766) and is never materialised sparse.
+        if (opts->enable_dense && est_density > opts->sparsity_threshold && (double)nnp * (double)free_now <= (double)dense_max_entries()) {
+            spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found\n", round, R->npiv);
+            spasm_logf("[echelonize] finishing; density = %.3f (estimated); aspect ratio = %.1f; Schur complement straight to dense\n", est_density,
+                       free_now > 0 ? (double)nnp / (double)free_now : 0.0);
+            append_round_U(U, *R, *cur, stream);
+            schur_dense_finish(*R, *cur, nnp, chunk, rec_per_row, max_pool, U, stream);
+            spasm_amd_round_stats st;
+            fill_stats(st, *R, round, cur->n, cur_nnz);
+            st.nnz_out = -1; // (never counted: the rows went dense)
+            g_last_rounds.push_back(st);
+            break;
         }
         while (off < nnp || nnp == 0) {
             const int cnt = std::min(chunk, nnp - off);

@@ -2114,6 +2114,82 @@ __global__ void k_dense_emit(int C, const int *__restrict__ D, i64d ldc, const i
     if (lane == 0) { pivcol[k] = clist[c]; piv_orig[k] = row_orig[p]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Schur complement straight into a dense matrix (replaces libspasm's spasm_schur_dense, prototype reference src/SpaSM.jl:765-766):
+// when the density estimate says the Schur complement will be dense, its rows are never built sparse -- no hash table, no
+// 8-byte entries, no slots: D[row][cmap[col]] takes the row's own non-pivot entries and, run after run, minus the multiplier
+// times the run (a run = a pivot row's non-pivot part, or a chunk of a row of W).  One wave per row; the runs of a row are
+// applied one after the other (the columns of one run are distinct), waiting for the stores of a run before the next reads.
+// ------------------------------------------------------------------------------------------------
+struct SchurDenseArgs {
+    int nrows;                 // rows of this batch
+    int roff;                  // dense row of its first row
+    const int *rows;           // local row of each row slot
+    const int *sflag;          // 1: the row's own entries are among its records (plan along W)
+    const i64d *start;
+    const int *len;
+    const int2 *ent;
+    const int *qinv_r;
+    const i64d *Lstart;
+    const int *Llen;
+    const int4 *Lpool;
+    const int2 *UPN;
+    const int *cmap;           // column -> dense column (-1: not a column of D)
+    int *D;
+    i64d ldc;
+    ZpField F;
+};
+
+__global__ __launch_bounds__(256) void k_schur_dense(SchurDenseArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const ZpField F = a.F;
+    for (i64d t64 = ((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6; t64 < a.nrows; t64 += ((i64d)gridDim.x * blockDim.x) >> 6) {
+        const int t = (int)t64;
+        int *Drow = a.D + (i64d)(a.roff + t) * a.ldc;
+        if (!(a.sflag && a.sflag[t])) {
+            const int row = a.rows ? a.rows[t] : t;
+            const i64d st = a.start[row];
+            const int ln = a.len[row];
+            for (int k = lane; k < ln; k += 64) {
+                const int2 e = a.ent[st + k];
+                if (a.qinv_r[e.x] < 0) Drow[a.cmap[e.x]] = e.y; // (the columns of a row are distinct, D starts at zero)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const i64d ls = a.Lstart[t];
+        const int ll = a.Llen[t];
+        for (int i = 0; i < ll; i++) {
+            const int4 le = a.Lpool[ls + i];
+            if (le.y == 0) continue;
+            const int nm = zp_neg(F, le.y);
+            const int2 *up = a.UPN + (unsigned)le.z;
+            for (int k = lane; k < le.w; k += 64) {
+                const int2 u = up[k];
+                int *d = Drow + a.cmap[u.x];
+                const int cur = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (from L2: the run before wrote it)
+                *d = zp_axpy(F, nm, u.y, cur);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+// flag[j] = 1 for a column that holds entries (flag comes in from k_flag_cols) and carries no pivot of this round
+__global__ void k_mask_pivot_cols(int m, const int *__restrict__ qinv_r, int *__restrict__ flag)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m && qinv_r[j] >= 0) flag[j] = 0;
+    if (j == m) flag[j] = 0;
+}
+
+// every step-th element of a list
+__global__ void k_pick_stride(int n, int step, const int *__restrict__ src, int *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[(i64d)i * step];
+}
+
 // out[i] = src[idx[i]]
 __global__ void k_gather_int(int n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ out)
 {

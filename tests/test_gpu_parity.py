@@ -620,3 +620,23 @@ def test_round_loop_options_change_the_rounds_not_the_result(S, O):
         assert np.asarray(f.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
     Kref = S.kernel(ref).rows()
     assert S.kernel(one).rows() == Kref and S.kernel(none).rows() == Kref and S.kernel(dflt).rows() == Kref == O.kernel(olu).rows()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,m,kw,prime", [(2, 4000, 1600, dict(row_nnz=40), 127), (1, 1500, 1200, dict(row_nnz=30), 65521),
+                                              (0, 900, 700, dict(density=0.05), 2147483647)])
+def test_schur_complement_straight_to_dense(S, O, kind, n, m, kw, prime):
+    """When the density estimate (spasm_schur_estimate_density, prototype src/SpaSM.jl:763-764) says the Schur complement of a
+    round is dense, it is reduced straight into the dense matrix of the finish (spasm_schur_dense, :765-766) and never built
+    sparse.  The threshold sits between the density of the input (0.025 .. 0.05) and that of its first Schur complement; rank,
+    pivot columns and kernel must equal the oracle's, and the record of the last round must show that no sparse Schur
+    complement was counted."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xD35E, **kw)
+    fact = S.echelonize(A, sparsity_threshold=0.1)
+    rounds = S.last_rounds()
+    assert len(rounds) >= 1 and rounds[-1]["nnz_out"] == -1, rounds
+    olu = O.echelonize(A)
+    assert fact.r == olu.r
+    assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
+    assert S.kernel(fact).rows() == O.kernel(olu).rows()
+    assert S.factorization_verify(A, fact, 7)
