@@ -173,6 +173,8 @@ struct spasm_amd_round_stats {
      * W = -Uinv * U_PN (included in ms_pivots of an echelonize round; a plan builds them once, when it is created) */
     double ms_uinv;
     double ms_w;
+    i64 npiv_open;        /* of npiv: pivots the "Faugere-Lachartre on columns" search added to the leftmost-entry ones
+                           * (echelonize rounds with enable_greedy_pivot_search; 0 for plans, which keep to leftmost entries) */
 };
 
 typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;
@@ -212,7 +214,7 @@ int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spasm_amd_roun
  * NULL) receives, per output row, the index of the originating row of A. */
 struct spasm_csr *spasm_amd_schur_plan_fetch(spasm_amd_schur_plan *plan, int *p_out);
 /* The pivot rows of the plan's round as they enter U (scaled to a unit pivot, reference src/SpaSM.jl:712), in pivot-index order
- * = ascending pivot column; pivcol_out / row_out (npiv ints each, may be NULL) receive the pivot column and the originating
+ * (= ascending pivot column for a plan); pivcol_out / row_out (npiv ints each, may be NULL) receive the pivot column and the originating
  * row of A of each.  What a row-sharded echelonization appends to U after every exchange, without rebuilding it on the host. */
 struct spasm_csr *spasm_amd_schur_plan_fetch_U(spasm_amd_schur_plan *plan, int *pivcol_out, int *row_out);
 void spasm_amd_schur_plan_free(spasm_amd_schur_plan *plan);

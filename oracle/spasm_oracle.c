@@ -255,13 +255,46 @@ ORC_API int orc_sparse_triangular_solve(const struct spasm_csr *U, const struct 
 /* ------------------------------------------------------------------ Faugere-Lachartre pivots, proto src/SpaSM.jl:776-778
  * Candidate of a row = its leftmost entry; per column keep the sparsest candidate row (ties: lowest
  * row).  Pivot rows are copied into U scaled by pivot^-1 ("pivots in U are all equal to 1", :712).
- * rows[] lists the live rows of A (NULL = all).  Returns the number of new pivots; is_piv[i] set. */
+ * Returns the number of new pivots; is_piv[i] set.
+ *
+ * on_columns != 0 adds the second search libspasm's log names (README.md:22 "Faugere-Lachartre on columns"; the option is
+ * enable_greedy_pivot_search, src/SpaSM.jl:326).  libspasm's source is not in the reference tree, so its exact visiting order
+ * cannot be followed; this is the order-free rule the MI355X engine uses (kernels.hpp, k_close_cols ..), restated so that
+ * both take the SAME pivots and the parity tests stay bit-exact:
+ *   - a column is closed when a leftmost-pivot row holds it, open otherwise;
+ *   - a non-pivot row proposes its open column of smallest occupancy among the non-pivot rows (ties: leftmost);
+ *   - per column the sparsest proposing row wins (ties: lowest row);
+ *   - a winner is accepted when no other column of its row received a proposal.
+ * Accepted rows enter U BEFORE the leftmost-pivot rows of the round (they may hold leftmost-pivot columns, never the other
+ * way round), so U stays in topological order.  n_open, when given, receives the number of pivots this search added. */
 
-static int fl_pivots(const struct spasm_csr *A, struct spasm_csr *U, int *qinv, int *Urow_of, char *is_piv, int *Uorig, const int *orig)
+static void emit_pivot_row(const struct spasm_csr *A, int i, int j, struct spasm_csr *U, int *qinv, char *is_piv, int *Uorig, const int *orig)
+{
+    const struct spasm_field_struct *F = A->field;
+    i64 lo = A->p[i], hi = A->p[i + 1];
+    i64 unz = U->p[U->n];
+    if (unz + (hi - lo) > U->nzmax) csr_realloc(U, 2 * U->nzmax + (hi - lo));
+    spasm_ZZp piv = 0;
+    for (i64 k = lo; k < hi; k++) if (A->j[k] == j) piv = A->x[k];
+    assert(piv != 0);
+    spasm_ZZp inv = orc_zp_inverse(F, piv);
+    for (i64 k = lo; k < hi; k++) {
+        U->j[unz] = A->j[k];
+        U->x[unz] = orc_zp_mul(F, inv, A->x[k]);
+        unz++;
+    }
+    qinv[j] = U->n;
+    if (Uorig) Uorig[U->n] = orig ? orig[i] : i;
+    U->n++;
+    U->p[U->n] = unz;
+    is_piv[i] = 1;
+}
+
+static int fl_pivots_ex(const struct spasm_csr *A, struct spasm_csr *U, int *qinv, char *is_piv, int *Uorig, const int *orig,
+                        int on_columns, int *n_open)
 {
     int n = A->n, m = A->m;
-    const struct spasm_field_struct *F = A->field;
-    int *best = malloc(sizeof(int) * (size_t)m);
+    int *best = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
     for (int j = 0; j < m; j++) best[j] = -1;
     for (int i = 0; i < n; i++) {
         is_piv[i] = 0;
@@ -273,32 +306,66 @@ static int fl_pivots(const struct spasm_csr *A, struct spasm_csr *U, int *qinv, 
         int b = best[jmin];
         if (b < 0 || (hi - lo) < (A->p[b + 1] - A->p[b])) best[jmin] = i;
     }
-    int npiv = 0;
+    int npiv = 0, nopen = 0;
+    if (on_columns) {
+        char *left = calloc((size_t)(n > 0 ? n : 1), 1);   /* row is a leftmost pivot */
+        char *closed = calloc((size_t)(m > 0 ? m : 1), 1);
+        int *cnt = calloc((size_t)(m > 0 ? m : 1), sizeof(int));
+        int *best2 = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+        int *prop = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+        int any = 0;
+        for (int j = 0; j < m; j++) {
+            best2[j] = -1;
+            if (best[j] >= 0) { left[best[j]] = 1; any = 1; }
+        }
+        if (any) {
+            for (int i = 0; i < n; i++)
+                for (i64 k = A->p[i]; k < A->p[i + 1]; k++) {
+                    if (left[i]) closed[A->j[k]] = 1;
+                    else cnt[A->j[k]]++;
+                }
+            for (int i = 0; i < n; i++) {
+                prop[i] = -1;
+                if (left[i]) continue;
+                i64 lo = A->p[i], hi = A->p[i + 1];
+                int c = -1;
+                for (i64 k = lo; k < hi; k++) {
+                    int j = A->j[k];
+                    if (closed[j]) continue;
+                    if (c < 0 || cnt[j] < cnt[c] || (cnt[j] == cnt[c] && j < c)) c = j;
+                }
+                if (c < 0) continue;
+                prop[i] = c;
+                int b = best2[c];
+                if (b < 0 || (hi - lo) < (A->p[b + 1] - A->p[b])) best2[c] = i;
+            }
+            for (int j = 0; j < m; j++) {
+                int i = best2[j];
+                if (i < 0) continue;
+                int clash = 0;
+                for (i64 k = A->p[i]; k < A->p[i + 1]; k++) if (A->j[k] != j && best2[A->j[k]] >= 0) clash = 1;
+                if (clash) continue;
+                emit_pivot_row(A, i, j, U, qinv, is_piv, Uorig, orig);
+                nopen++;
+            }
+        }
+        free(left); free(closed); free(cnt); free(best2); free(prop);
+    }
     for (int j = 0; j < m; j++) {
         int i = best[j];
         if (i < 0) continue;
-        i64 lo = A->p[i], hi = A->p[i + 1];
-        i64 unz = U->p[U->n];
-        if (unz + (hi - lo) > U->nzmax) csr_realloc(U, 2 * U->nzmax + (hi - lo));
-        spasm_ZZp piv = 0;
-        for (i64 k = lo; k < hi; k++) if (A->j[k] == j) piv = A->x[k];
-        assert(piv != 0);
-        spasm_ZZp inv = orc_zp_inverse(F, piv);
-        for (i64 k = lo; k < hi; k++) {
-            U->j[unz] = A->j[k];
-            U->x[unz] = orc_zp_mul(F, inv, A->x[k]);
-            unz++;
-        }
-        qinv[j] = U->n;
-        if (Uorig) Uorig[U->n] = orig ? orig[i] : i;
-        U->n++;
-        U->p[U->n] = unz;
-        is_piv[i] = 1;
+        emit_pivot_row(A, i, j, U, qinv, is_piv, Uorig, orig);
         npiv++;
     }
-    (void)Urow_of;
     free(best);
-    return npiv;
+    if (n_open) *n_open = nopen;
+    return npiv + nopen;
+}
+
+static int fl_pivots(const struct spasm_csr *A, struct spasm_csr *U, int *qinv, int *Urow_of, char *is_piv, int *Uorig, const int *orig)
+{
+    (void)Urow_of;
+    return fl_pivots_ex(A, U, qinv, is_piv, Uorig, orig, 0, NULL);
 }
 
 /* ------------------------------------------------------------------ Schur complement, proto src/SpaSM.jl:761-762
@@ -485,7 +552,7 @@ ORC_API struct spasm_lu *orc_echelonize(const struct spasm_csr *A0, const struct
         if (orc_nnz(A) == 0 || U->n == maxr) break;
         char *is_piv = malloc((size_t)(A->n > 0 ? A->n : 1));
         int rank_before = U->n;
-        int npiv = fl_pivots(A, U, qinv, NULL, is_piv, Uorig, orig);
+        int npiv = fl_pivots_ex(A, U, qinv, is_piv, Uorig, orig, opts_in->enable_greedy_pivot_search, NULL);
         int avail = A->n < m - rank_before ? A->n : m - rank_before;
         int *p_out = malloc(sizeof(int) * (size_t)(A->n > 0 ? A->n : 1));
         struct spasm_csr *S = orc_schur(A, is_piv, U, qinv, p_out, stats, 0);

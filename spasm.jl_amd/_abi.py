@@ -93,6 +93,7 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
         ("stream_redo", C.c_int64),
         ("ms_uinv", C.c_double),
         ("ms_w", C.c_double),
+        ("npiv_open", C.c_int64),
     ]
 
     def as_dict(self):

@@ -420,7 +420,9 @@ extern "C" SPASM_API bool spasm_factorization_verify(const struct spasm_csr *A, 
     const uint64_t p = (uint64_t)A->field->p;
     if (U->m != m || fact->r != r || (uint64_t)U->field->p != p) return false;
     auto res = [p](int v) -> uint64_t { return v < 0 ? (uint64_t)((int64_t)v + (int64_t)p) : (uint64_t)v; };
-    // (a) echelon shape: qinv is a bijection pivot column -> row, every row starts at its pivot column with a 1
+    // (a) echelon shape: qinv is a bijection pivot column -> row, every row holds a 1 on its pivot column, and U is (permuted)
+    // upper triangular: the relation "row a has an entry on the pivot column of row b" has no cycle.  Pivots need not be the
+    // leftmost entries of their rows (the "FL on columns" search takes others).
     std::vector<int> pivcol((size_t)std::max(r, 1), -1);
     for (int j = 0; j < m; j++) {
         const int k = fact->qinv[j];
@@ -430,15 +432,27 @@ extern "C" SPASM_API bool spasm_factorization_verify(const struct spasm_csr *A, 
             pivcol[(size_t)k] = j;
         }
     }
+    std::vector<int> indeg((size_t)std::max(r, 1), 0), order;
+    order.reserve((size_t)r);
     for (int k = 0; k < r; k++) {
         if (pivcol[(size_t)k] < 0) return false;
         bool has_pivot = false;
         for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
-            if (U->j[q] < pivcol[(size_t)k] || U->j[q] >= m) return false;
+            if (U->j[q] < 0 || U->j[q] >= m) return false;
             if (U->j[q] == pivcol[(size_t)k]) { if (res(U->x[q]) != 1 || has_pivot) return false; has_pivot = true; }
+            else if (fact->qinv[U->j[q]] >= 0) indeg[(size_t)fact->qinv[U->j[q]]]++;
         }
         if (!has_pivot) return false;
     }
+    for (int k = 0; k < r; k++) if (indeg[(size_t)k] == 0) order.push_back(k);
+    for (size_t h = 0; h < order.size(); h++) {
+        const int k = order[h];
+        for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
+            const int b = fact->qinv[U->j[q]];
+            if (b >= 0 && b != k && --indeg[(size_t)b] == 0) order.push_back(b);
+        }
+    }
+    if ((int)order.size() != r) return false; // a cycle: not an echelon form under any permutation
     // (b) random combinations of the rows of A must reduce to zero
     const int trials = p < 65536 ? 8 : 2;
     std::vector<uint64_t> y((size_t)std::max(m, 1));
@@ -454,10 +468,11 @@ extern "C" SPASM_API bool spasm_factorization_verify(const struct spasm_csr *A, 
                 y[(size_t)c] = (y[(size_t)c] + xi * res(A->x ? A->x[q] : 1) % p) % p; // xi, residue < 2^32: the product fits 64 bits
             }
         }
-        // ascending pivot columns: row k touches only columns >= pivcol[k], so an eliminated column stays zero
-        for (int j = 0; j < m; j++) {
-            const int k = fact->qinv[j];
-            if (k < 0 || y[(size_t)j] == 0) continue;
+        // rows in topological order: row k touches, among pivot columns, only those of rows after it, so an eliminated column
+        // stays zero
+        for (int k : order) {
+            const int j = pivcol[(size_t)k];
+            if (y[(size_t)j] == 0) continue;
             const uint64_t c = y[(size_t)j];
             for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
                 const size_t col = (size_t)U->j[q];

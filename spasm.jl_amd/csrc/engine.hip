@@ -308,6 +308,51 @@ struct Round {
         }
     }
 
+    // ---- (1b') "FL on columns": after the leftmost election (best[] filled, pivots numbered), non-pivot rows take pivots on
+    // columns no pivot row touches (kernels.hpp, k_close_cols ..).  Renumbers the pivots: the new ones first.  Returns how many
+    // were added.  Single device only (the proposals would need a second all-reduce in a sharded round).
+    DevBuf<int> closed, colcnt, prop, newflag, newscan;
+    DevBuf<u64d> best2;
+    int n_leftmost = 0, n_open = 0;
+    int extend_pivots_on_open_columns(const DevMat &A)
+    {
+        n_leftmost = npiv;
+        n_open = 0;
+        if (npiv == 0 || A.n == 0) return 0;
+        closed.ensure((size_t)m + 1); colcnt.ensure((size_t)m + 1); newflag.ensure((size_t)m + 1); newscan.ensure((size_t)m + 1);
+        best2.ensure((size_t)m + 1);
+        prop.ensure((size_t)A.n + 1);
+        is_piv.ensure((size_t)A.n + 1);
+        HIPCHK(hipMemsetAsync(closed.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(colcnt.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(newflag.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(is_piv.p, 0, ((size_t)A.n + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best2.p);
+        hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, 0, 1, A.n, pivrow.p, is_piv.p);
+        constexpr int TEAM = 8;
+        hipLaunchKernelGGL((k_close_cols<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, stream, npiv, pivrow.p, A.start.p, A.len.p, A.ent.p, closed.p);
+        hipLaunchKernelGGL(k_col_histogram, dim3(cdiv((i64)A.n * 8, 256)), dim3(256), 0, stream, A.n, is_piv.p, A.start.p, A.len.p, A.ent.p, colcnt.p);
+        hipLaunchKernelGGL((k_propose_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, 0, 1, is_piv.p, A.start.p, A.len.p, A.ent.p,
+                           closed.p, colcnt.p, prop.p, best2.p);
+        hipLaunchKernelGGL((k_accept_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, 0, 1, A.start.p, A.len.p, A.ent.p, prop.p,
+                           best2.p, newflag.p);
+        HIPCHK(hipGetLastError());
+        scan.exclusive(newflag.p, newscan.p, (size_t)m + 1, stream);
+        int nnew = 0;
+        HIPCHK(hipMemcpyAsync(&nnew, newscan.p + m, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (nnew == 0) return 0;
+        // renumber: open-column pivots 0 .. nnew-1, leftmost pivots behind them (colscan still holds their ascending numbering)
+        pivrow.ensure((size_t)npiv + nnew + 1);
+        pivcol.ensure((size_t)npiv + nnew + 1);
+        hipLaunchKernelGGL(k_col_assign2, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, nnew, best.p, best2.p, newflag.p, newscan.p, colscan.p, qinv_r.p,
+                           pivrow.p, pivcol.p);
+        HIPCHK(hipGetLastError());
+        npiv += nnew;
+        n_open = nnew;
+        return nnew;
+    }
+
     // ---- (1c) local non-pivot, non-empty rows
     // row_stride: local row i is global row row_base + i * row_stride; (lo, hi, step): which LOCAL rows this plan reduces
     void mark_local(const DevMat &A, int row_base, int lo = 0, int hi = INT_MAX, int row_stride = 1, int step = 1)
@@ -1189,6 +1234,7 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     st.rows_in = rows_in;
     st.nnz_in = nnz_in;
     st.npiv = R.npiv;
+    st.npiv_open = R.n_open;
     st.rows_out = R.hctr.nonempty_out;
     st.nnz_out = (i64)R.hctr.nnz_out;
     st.nnz_reduced = (i64)R.hctr.nnz_reduced;
@@ -1472,9 +1518,10 @@ void schur_dense_finish(Round &R, const DevMat &cur, int nnp, int chunk, double 
 
 struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
 {
-    // every pivot is a leftmost entry, so rank, pivot columns and kernel do not depend on the tunables; max_round,
-    // min_pivot_proportion, enable_dense and sparsity_threshold (reference src/SpaSM.jl:329-337) decide how far the sparse rounds
-    // go and what finishes
+    // max_round, min_pivot_proportion, enable_dense and sparsity_threshold (reference src/SpaSM.jl:329-337) decide how far the
+    // sparse rounds go and what finishes.  With enable_greedy_pivot_search off every pivot is a leftmost entry, and rank, pivot
+    // columns and kernel do not depend on those tunables; with it on (the reference's default) the pivot columns depend on
+    // where the sparse rounds stop, the rank of course does not.
     struct echelonize_opts dflt;
     if (!opts) { spasm_echelonize_init_opts(&dflt); opts = &dflt; }
     require_device();
@@ -1517,12 +1564,17 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         R->elect_local(*cur, 0);
         R->assign_pivots();
         if (R->npiv == 0) break; // no non-empty row left
+        // enable_greedy_pivot_search (reference src/SpaSM.jl:326): off = leftmost-entry pivots only; on = also "FL on columns"
+        // in the max_round sparse rounds (libspasm's third search, the cycle-free greedy one, is not reproduced).  The rounds of the
+        // finish keep to leftmost entries, like the reference's GPLU and dense finishes.
+        R->n_leftmost = R->npiv;
+        R->n_open = 0;
+        if (opts->enable_greedy_pivot_search && !gplu_finish && round < opts->max_round) R->extend_pivots_on_open_columns(*cur);
         if (!gplu_finish) {
             // The reference's round loop (tunables src/SpaSM.jl:333-337): at most max_round sparse rounds, and none that finds
             // fewer than min_pivot_proportion * min(rows, free columns) pivots ("not enough pivots found; stopping", README.md:32).
             // What is left then goes to the dense finish when it fits the device and may be used, else to the GPLU-style
-            // finish: more rounds of the same kind until nothing is left (every pivot is a leftmost entry either way, so rank,
-            // pivot columns and kernel do not depend on where the loop stops).
+            // finish: more leftmost-pivot rounds until nothing is left.
             const i64 cfree = (i64)m - (i64)U.pivcol.size();
             const double need = opts->min_pivot_proportion * (double)std::min<i64>(cur_live, cfree);
             const bool few = (double)R->npiv < need;
@@ -1609,7 +1661,8 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         // ---- dense already?  Then the Schur complement goes straight into the dense matrix of the finish (spasm_schur_dense,
         // prototype src/SpaSM.jl:765-766) and is never materialised sparse.
         if (opts->enable_dense && est_density > opts->sparsity_threshold && (double)nnp * (double)free_now <= (double)dense_max_entries()) {
-            spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found\n", round, R->npiv);
+            spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found\n", round, R->n_leftmost);
+            if (R->n_open) spasm_logf("[pivots] ``Faugère-Lachartre on columns'': %d pivots found\n", R->n_open);
             spasm_logf("[echelonize] finishing; density = %.3f (estimated); aspect ratio = %.1f; Schur complement straight to dense\n", est_density,
                        free_now > 0 ? (double)nnp / (double)free_now : 0.0);
             append_round_U(U, *R, *cur, stream);
@@ -1711,7 +1764,8 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         st.ms_scatter = ms_scatter;
         st.ms_total = ms_pivots + ms_solve + ms_scatter;
         g_last_rounds.push_back(st);
-        spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found [%.1fs]\n", round, R->npiv, st.ms_pivots * 1e-3);
+        spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found [%.1fs]\n", round, R->n_leftmost, st.ms_pivots * 1e-3);
+        if (R->n_open) spasm_logf("[pivots] ``Faugère-Lachartre on columns'': %d pivots found\n", R->n_open);
         spasm_logf("Schur complement: %d * %d [%lld nz / density= %.3f], %.1fs%s\n", nnp, m - (int)U.pivcol.size(),
                    (long long)st.nnz_out, nnp > 0 && m > 0 ? (double)st.nnz_out / ((double)nnp * (double)m) : 0.0,
                    (st.ms_solve + st.ms_scatter) * 1e-3, nbatch > 1 ? " (in batches of rows)" : "");
@@ -1837,6 +1891,74 @@ struct spasm_csr *do_transpose(const struct spasm_csr *A)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pivot numbering for the consumers of a factorization (kernel, rref, triangular solve): a topological order of
+// "row a of U has an entry on the pivot column of row b  =>  a before b", which makes U_PP strictly upper triangular in
+// pivot-index space -- what the solve kernels assume.  U produced by this engine is stored in such an order already
+// (rounds in sequence; inside a round the open-column pivots, then the leftmost ones by ascending column), so the check
+// is one pass; any other (permuted) triangular U gets a depth-first numbering.  Pivots need not be leftmost entries
+// (reference src/SpaSM.jl:712 only promises unit pivots).  Returns perm (perm[t] = row of U with pivot index t) and fills
+// pc (pivot column of each row).
+// ------------------------------------------------------------------------------------------------
+static std::vector<int> pivot_topological_order(const struct spasm_csr *U, const int *qinv, const char *who, std::vector<int> &pc)
+{
+    const int r = U->n, m = U->m;
+    const std::string w(who);
+    pc.assign((size_t)std::max(r, 1), -1);
+    int named = 0;
+    for (int j = 0; j < m; j++) {
+        const int a = qinv[j];
+        if (a >= r) throw EngineError(w + ": qinv points outside U");
+        if (a >= 0) { if (pc[(size_t)a] < 0) named++; pc[(size_t)a] = j; }
+    }
+    if (named != r) throw EngineError(w + ": qinv does not name one pivot column per row of U");
+    for (int a = 0; a < r; a++) {
+        bool unit = false;
+        for (i64 k = U->p[a]; k < U->p[a + 1]; k++) if (U->j[k] == pc[(size_t)a] && U->x[k] == 1) unit = true;
+        if (!unit) throw EngineError(w + ": pivots of U must be 1");
+    }
+    std::vector<int> perm((size_t)std::max(r, 1));
+    bool ordered = true;
+    for (int a = 0; a < r && ordered; a++)
+        for (i64 k = U->p[a]; k < U->p[a + 1]; k++) {
+            const int b = qinv[U->j[k]];
+            if (b >= 0 && b < a) { ordered = false; break; }
+        }
+    if (ordered) {
+        for (int a = 0; a < r; a++) perm[(size_t)a] = a;
+        return perm;
+    }
+    std::vector<char> state((size_t)r, 0);
+    std::vector<int> stack, post;
+    std::vector<i64> pos((size_t)r, 0);
+    post.reserve((size_t)r);
+    for (int root = 0; root < r; root++) {
+        if (state[(size_t)root]) continue;
+        stack.push_back(root);
+        state[(size_t)root] = 1;
+        pos[(size_t)root] = U->p[root];
+        while (!stack.empty()) {
+            const int a = stack.back();
+            bool pushed = false;
+            while (pos[(size_t)a] < U->p[a + 1]) {
+                const int b = qinv[U->j[pos[(size_t)a]++]];
+                if (b < 0 || b == a) continue;
+                if (state[(size_t)b] == 1) throw EngineError(w + ": U is not (permuted) triangular");
+                if (state[(size_t)b] == 0) {
+                    state[(size_t)b] = 1;
+                    pos[(size_t)b] = U->p[b];
+                    stack.push_back(b);
+                    pushed = true;
+                    break;
+                }
+            }
+            if (!pushed) { state[(size_t)a] = 2; post.push_back(a); stack.pop_back(); }
+        }
+    }
+    for (int t = 0; t < r; t++) perm[(size_t)t] = post[(size_t)(r - 1 - t)];
+    return perm;
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel basis from an echelonized U (reference call site src/SpaSM.jl:879).
 // The reduced row echelon form R of U is computed with the SAME solve + scatter kernels as a Schur
 // round (each row of U is reduced by all the others); the kernel vector of free column j is then
@@ -1845,9 +1967,8 @@ struct spasm_csr *do_transpose(const struct spasm_csr *A)
 // ------------------------------------------------------------------------------------------------
 // spasm_rref (reference src/SpaSM.jl:871): the reduced row echelon form of U.  Row k of R is row k of U minus the
 // combination of the OTHER rows that clears its entries on their pivot columns -- one Schur "round" in which every row
-// of U is a pivot row and, at the same time, a row to reduce with its own pivot excluded (self_idx).  Requires pivots
-// that are the leftmost entries of their rows (true for this engine's and the oracle's LUs): numbering the pivots by
-// ascending column then makes U_PP strictly upper triangular, which is what the solve kernels assume.
+// of U is a pivot row and, at the same time, a row to reduce with its own pivot excluded (self_idx).  The pivots are
+// numbered in a topological order (pivot_topological_order), so they need not be leftmost entries.
 // ------------------------------------------------------------------------------------------------
 struct spasm_csr *do_rref(const struct spasm_lu *fact, int *Rqinv)
 {
@@ -1858,26 +1979,16 @@ struct spasm_csr *do_rref(const struct spasm_lu *fact, int *Rqinv)
     const int r = U->n, m = U->m;
     const int *qinv = fact->qinv;
     const i64 prime = U->field->p;
-    // pivots numbered by ascending column: idx -> (column, row of U)
-    std::vector<int> h_qinv_r((size_t)std::max(m, 1), -1), h_pivcol, h_pivrow, h_self((size_t)std::max(r, 1), -1);
-    for (int j = 0; j < m; j++) {
-        const int k = qinv[j];
-        if (k >= r) throw EngineError("spasm_rref: qinv points outside U");
-        if (k < 0) continue;
-        h_qinv_r[(size_t)j] = (int)h_pivcol.size();
-        h_self[(size_t)k] = (int)h_pivcol.size();
-        h_pivcol.push_back(j);
-        h_pivrow.push_back(k);
-    }
-    if ((int)h_pivcol.size() != r) throw EngineError("spasm_rref: qinv does not name one pivot column per row of U");
-    for (int k = 0; k < r; k++) {
-        const int pc = h_pivcol[(size_t)h_self[(size_t)k]];
-        bool unit = false;
-        for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
-            if (U->j[q] < pc) throw EngineError("spasm_rref: the pivot of a row of U must be its leftmost entry");
-            if (U->j[q] == pc && U->x[q] == 1) unit = true;
-        }
-        if (!unit) throw EngineError("spasm_rref: pivots of U must be 1");
+    // pivots numbered in topological order: idx -> (column, row of U)
+    std::vector<int> pc;
+    const std::vector<int> perm = pivot_topological_order(U, qinv, "spasm_rref", pc);
+    std::vector<int> h_qinv_r((size_t)std::max(m, 1), -1), h_pivcol((size_t)r), h_pivrow((size_t)r), h_self((size_t)std::max(r, 1), -1);
+    for (int t = 0; t < r; t++) {
+        const int k = perm[(size_t)t];
+        h_qinv_r[(size_t)pc[(size_t)k]] = t;
+        h_self[(size_t)k] = t;
+        h_pivcol[(size_t)t] = pc[(size_t)k];
+        h_pivrow[(size_t)t] = k;
     }
     struct spasm_csr *Rm = nullptr;
     std::vector<i64> sp((size_t)r + 1, 0);
@@ -1959,7 +2070,7 @@ struct spasm_csr *do_rref(const struct spasm_lu *fact, int *Rqinv)
 // X * U = B for every row of B at once (the reference loops spasm_sparse_triangular_solve over the rows of B,
 // src/SpaSM.jl:733-755): with x_b on the pivot columns and x_a on the others, x_b * U + x_a == B[k] (:694-713).  One Schur
 // "round" with U as the pivot rows and B as the rows to reduce: the multipliers ARE x_b, the Schur row IS x_a.
-// Returns X (rows of B x rows of U); ok[k] = 1 when x_a is empty, i.e. row k has a solution.  Same requirement on U as rref.
+// Returns X (rows of B x rows of U); ok[k] = 1 when x_a is empty, i.e. row k has a solution.  Same pivot numbering as rref.
 // ------------------------------------------------------------------------------------------------
 struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok)
 {
@@ -1970,25 +2081,14 @@ struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const 
     const int r = U->n, m = U->m, nb = B->n;
     const i64 prime = U->field->p;
     if (B->m != m || B->field->p != prime) throw EngineError("spasm_amd_triangular_solve: B and U differ in columns or field");
-    std::vector<int> h_qinv_r((size_t)std::max(m, 1), -1), h_pivcol, h_pivrow, h_idx_of_row((size_t)std::max(r, 1), -1);
-    for (int j = 0; j < m; j++) {
-        const int k = qinv[j];
-        if (k >= r) throw EngineError("spasm_amd_triangular_solve: qinv points outside U");
-        if (k < 0) continue;
-        h_qinv_r[(size_t)j] = (int)h_pivcol.size();
-        h_idx_of_row[(size_t)k] = (int)h_pivcol.size();
-        h_pivcol.push_back(j);
-        h_pivrow.push_back(k);
-    }
-    if ((int)h_pivcol.size() != r) throw EngineError("spasm_amd_triangular_solve: qinv does not name one pivot column per row of U");
-    for (int k = 0; k < r; k++) {
-        const int pc = h_pivcol[(size_t)h_idx_of_row[(size_t)k]];
-        bool unit = false;
-        for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
-            if (U->j[q] < pc) throw EngineError("spasm_amd_triangular_solve: the pivot of a row of U must be its leftmost entry");
-            if (U->j[q] == pc && U->x[q] == 1) unit = true;
-        }
-        if (!unit) throw EngineError("spasm_amd_triangular_solve: pivots of U must be 1");
+    std::vector<int> pc;
+    const std::vector<int> perm = pivot_topological_order(U, qinv, "spasm_amd_triangular_solve", pc);
+    std::vector<int> h_qinv_r((size_t)std::max(m, 1), -1), h_pivcol((size_t)r), h_pivrow((size_t)r);
+    for (int t = 0; t < r; t++) {
+        const int k = perm[(size_t)t];
+        h_qinv_r[(size_t)pc[(size_t)k]] = t;
+        h_pivcol[(size_t)t] = pc[(size_t)k];
+        h_pivrow[(size_t)t] = k;
     }
     std::vector<i64> xp((size_t)nb + 1, 0);
     std::vector<int> slen((size_t)std::max(nb, 1), 0);
@@ -2068,60 +2168,10 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
     const double t0 = spasm_wtime();
     spasm_logf("[kernel] start. U is %d x %d (%lld nnz). Transposing U\n", r, m, (long long)spasm_nnz(U));
 
-    // pivot column of each row; check the unit pivots the solve relies on (reference src/SpaSM.jl:712)
-    std::vector<int> pc((size_t)std::max(r, 1), -1);
-    for (int j = 0; j < m; j++) {
-        const int a = qinv[j];
-        if (a >= r) throw EngineError("spasm_kernel: qinv points outside U");
-        if (a >= 0) pc[(size_t)a] = j;
-    }
-    for (int a = 0; a < r; a++) {
-        if (pc[(size_t)a] < 0) throw EngineError("spasm_kernel: a row of U has no pivot column in qinv");
-        bool unit = false;
-        for (i64 k = U->p[a]; k < U->p[a + 1]; k++) if (U->j[k] == pc[(size_t)a] && U->x[k] == 1) unit = true;
-        if (!unit) throw EngineError("spasm_kernel: pivots of U must be 1");
-    }
-    // pivot numbering: a topological order of "row a has an entry on the pivot column of row b => a before b".
-    // U produced by this engine is already ordered (identity); otherwise a depth-first numbering is used.
-    std::vector<int> perm((size_t)std::max(r, 1)), idx_of((size_t)std::max(r, 1));
-    bool ordered = true;
-    for (int a = 0; a < r && ordered; a++)
-        for (i64 k = U->p[a]; k < U->p[a + 1]; k++) {
-            const int b = qinv[U->j[k]];
-            if (b >= 0 && b < a) { ordered = false; break; }
-        }
-    if (ordered) {
-        for (int a = 0; a < r; a++) perm[(size_t)a] = a;
-    } else {
-        std::vector<char> state((size_t)r, 0);
-        std::vector<int> stack, post;
-        std::vector<i64> pos((size_t)r, 0);
-        post.reserve((size_t)r);
-        for (int root = 0; root < r; root++) {
-            if (state[(size_t)root]) continue;
-            stack.push_back(root);
-            state[(size_t)root] = 1;
-            pos[(size_t)root] = U->p[root];
-            while (!stack.empty()) {
-                const int a = stack.back();
-                bool pushed = false;
-                while (pos[(size_t)a] < U->p[a + 1]) {
-                    const int b = qinv[U->j[pos[(size_t)a]++]];
-                    if (b < 0 || b == a) continue;
-                    if (state[(size_t)b] == 1) throw EngineError("spasm_kernel: U is not (permuted) triangular");
-                    if (state[(size_t)b] == 0) {
-                        state[(size_t)b] = 1;
-                        pos[(size_t)b] = U->p[b];
-                        stack.push_back(b);
-                        pushed = true;
-                        break;
-                    }
-                }
-                if (!pushed) { state[(size_t)a] = 2; post.push_back(a); stack.pop_back(); }
-            }
-        }
-        for (int t = 0; t < r; t++) perm[(size_t)t] = post[(size_t)(r - 1 - t)];
-    }
+    // pivot column of each row, unit pivots checked (reference src/SpaSM.jl:712), topological numbering
+    std::vector<int> pc;
+    const std::vector<int> perm = pivot_topological_order(U, qinv, "spasm_kernel", pc);
+    std::vector<int> idx_of((size_t)std::max(r, 1));
     for (int t = 0; t < r; t++) idx_of[(size_t)perm[(size_t)t]] = t;
 
     // Transposed triangular system (what libspasm solves per free column, README.md:39 "Transposing U"):

@@ -144,30 +144,6 @@ template <> __device__ __forceinline__ int team_incl_scan<64>(int x, int &total)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Field arithmetic as the kernels use it, one lane per test vector (tests/test_gpu_zp.py compares with Python integers;
-// reference src/SpaSM.jl:383-390).  out[8 * i ..] = mul, axpy, add, sub, neg, inverse, lazy product reduced
-// (mul_lazy + acc_reduce_short: the scatter kernels' path), sum of 64 lazy products reduced (acc_reduce: the hash tables' path).
-// ------------------------------------------------------------------------------------------------
-template <bool SMALL>
-__global__ void k_zp_probe(ZpField F, int n, const int *__restrict__ a, const int *__restrict__ b, const int *__restrict__ c, int *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = a[i], y = b[i], z = c[i];
-    int *o = out + (size_t)8 * i;
-    o[0] = zp_mul(F, x, y);
-    o[1] = zp_axpy(F, x, y, z);
-    o[2] = zp_add(F, x, y);
-    o[3] = zp_sub(F, x, y);
-    o[4] = zp_neg(F, x);
-    o[5] = x != 0 ? zp_inverse(F, x) : 0;
-    o[6] = acc_reduce_short<SMALL>(F, ZpAcc<SMALL>::mul_lazy(F, x, y));
-    typename ZpAcc<SMALL>::type acc = 0;
-    for (int k = 0; k < 64; k++) acc += ZpAcc<SMALL>::mul_lazy(F, x, y);
-    o[7] = acc_reduce<SMALL>(F, acc);
-}
-
-// ------------------------------------------------------------------------------------------------
 // ingest: host-style CSR arrays (p,j,x) -> (start,len,ent)
 // ------------------------------------------------------------------------------------------------
 // values are brought to the canonical balanced residue here, once: the kernels downstream rely on it (the streaming scatter
@@ -247,6 +223,135 @@ __global__ void k_col_assign(int m, const u64d *__restrict__ best, const int *__
         pivcol[idx] = j;
     } else {
         qinv_r[j] = -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// "FL on columns" (reference README.md:22, the second of the three searches spasm_pivots_extract_structural names, prototype
+// src/SpaSM.jl:776-778): beyond the leftmost-entry pivots, a non-pivot row may take a pivot on a column that NO pivot row
+// touches -- such a column is "open" -- because no elimination by the pivots found so far can reach that entry.
+// libspasm walks the rows one after the other and closes the columns of each row it accepts; here all rows propose at once:
+//   1. closed[c] = 1 for every column of every leftmost-pivot row;
+//   2. occupancy histogram cnt[c] = rows (pivot rows excluded) holding column c, with a wave-level reduction: the lanes of a
+//      wave that hold the same column are counted with one atomic (BASELINE north_star: "column-occupancy histograms via
+//      wave-level reductions");
+//   3. a non-pivot row proposes its open column of smallest occupancy (ties: leftmost) -- the pivot that will cause the least
+//      fill-in; per column the sparsest proposing row wins (ties: lowest row), as in the leftmost election;
+//   4. a winner is accepted when none of its OTHER columns was won by anybody: accepted rows then do not contain each other's
+//      pivot columns, leftmost-pivot rows do not contain them either (they are open), so U stays triangular when the new
+//      pivots are numbered before the leftmost ones.
+// Deterministic and order-free, so the CPU oracle can take the same pivots (oracle/spasm_oracle.c: fl_on_columns).
+// ------------------------------------------------------------------------------------------------
+template <int TEAM>
+__global__ void k_close_cols(int npiv, const int *__restrict__ rowsrc, const i64d *__restrict__ start, const int *__restrict__ len,
+                             const int2 *__restrict__ ent, int *__restrict__ closed)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int idx = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (idx >= npiv) return;
+    const int row = rowsrc[idx];
+    const i64d st = start[row];
+    const int ln = len[row];
+    for (int k = tl; k < ln; k += TEAM) closed[ent[st + k].x] = 1;
+}
+
+// cnt[c] += number of (non-pivot) rows holding column c; one wave = 64 consecutive entries of the flattened row list, lanes with
+// equal columns are merged before the atomic (readfirstlane "waterfall" over the distinct columns of the wave)
+__global__ void k_col_histogram(int n, const int *__restrict__ is_piv, const i64d *__restrict__ start, const int *__restrict__ len,
+                                const int2 *__restrict__ ent, int *__restrict__ cnt)
+{
+    constexpr int TEAM = 8; // lanes per row: rows of ~20 entries take three steps
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    const bool live = i < n && !is_piv[i];
+    const i64d st = live ? start[i] : 0;
+    const int ln = live ? len[i] : 0;
+    int steps = (ln + TEAM - 1) / TEAM;
+    for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o)); // (the wave walks together: ballots below)
+    for (int s = 0; s < steps; s++) {
+        const int k = s * TEAM + tl;
+        const bool have = k < ln;
+        const int c = have ? ent[st + k].x : -1;
+        u64d todo = __ballot(have);
+        while (todo) {
+            const int c0 = __builtin_amdgcn_readlane(c, __ffsll((long long)todo) - 1);
+            const u64d same = __ballot(have && c == c0);
+            if ((threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(&cnt[c0], __popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+
+// a non-pivot row proposes its open column of smallest occupancy (ties: leftmost): best2[c] = min (len << 32 | row)
+template <int TEAM>
+__global__ void k_propose_open(int n, int row_base, int row_stride, const int *__restrict__ is_piv, const i64d *__restrict__ start,
+                               const int *__restrict__ len, const int2 *__restrict__ ent, const int *__restrict__ closed, const int *__restrict__ cnt,
+                               int *__restrict__ prop, u64d *__restrict__ best2)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i >= n) return;
+    int choice = -1;
+    if (!is_piv[i] && len[i] > 0) {
+        const i64d st = start[i];
+        const int ln = len[i];
+        u64d key = ~0ull; // (occupancy << 32 | column)
+        for (int k = tl; k < ln; k += TEAM) {
+            const int c = ent[st + k].x;
+            if (!closed[c]) key = min(key, ((u64d)(unsigned)cnt[c] << 32) | (u64d)(unsigned)c);
+        }
+        for (int o = TEAM / 2; o > 0; o >>= 1) key = min(key, (u64d)__shfl_xor((long long)key, o, TEAM));
+        if (key != ~0ull) {
+            choice = (int)(unsigned)(key & 0xffffffffull);
+            if (tl == 0) atomicMin(&best2[choice], ((u64d)(unsigned)ln << 32) | (u64d)(unsigned)(row_base + i * row_stride));
+        }
+    }
+    if (tl == 0) prop[i] = choice;
+}
+
+// the winner of column c is accepted (best[c] takes it over) when no other column of its row was won by anybody
+template <int TEAM>
+__global__ void k_accept_open(int n, int row_base, int row_stride, const i64d *__restrict__ start, const int *__restrict__ len,
+                              const int2 *__restrict__ ent, const int *__restrict__ prop, const u64d *__restrict__ best2, int *__restrict__ newflag)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i >= n) return;
+    const int c = prop[i];
+    if (c < 0) return;
+    if ((int)(unsigned)(best2[c] & 0xffffffffull) != row_base + i * row_stride) return; // another row won the column
+    const i64d st = start[i];
+    const int ln = len[i];
+    bool clash = false;
+    for (int k = tl; k < ln; k += TEAM) {
+        const int c2 = ent[st + k].x;
+        clash |= c2 != c && best2[c2] != NO_BEST;
+    }
+    if (team_ballot<TEAM>(clash) == 0 && tl == 0) newflag[c] = 1;
+}
+
+// numbering with the open-column pivots first (ascending column), then the leftmost pivots (ascending column)
+__global__ void k_col_flags2(int m, const u64d *__restrict__ best, const int *__restrict__ newflag, int *__restrict__ flflag)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) flflag[j] = best[j] != NO_BEST;
+    if (j == m) flflag[j] = 0;
+    (void)newflag;
+}
+__global__ void k_col_assign2(int m, int nnew, const u64d *__restrict__ best, const u64d *__restrict__ best2, const int *__restrict__ newflag,
+                              const int *__restrict__ newscan, const int *__restrict__ flscan, int *__restrict__ qinv_r, int *__restrict__ pivrow,
+                              int *__restrict__ pivcol)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    int idx = -1;
+    u64d b = NO_BEST;
+    if (newflag[j]) { idx = newscan[j]; b = best2[j]; }
+    else if (best[j] != NO_BEST) { idx = nnew + flscan[j]; b = best[j]; }
+    qinv_r[j] = idx;
+    if (idx >= 0) {
+        pivrow[idx] = (int)(unsigned)(b & 0xffffffffull);
+        pivcol[idx] = j;
     }
 }
 
@@ -2506,3 +2611,28 @@ __global__ __launch_bounds__(256) void k_dense_gemm(int c1, int R, int C, ZpFiel
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Field arithmetic as the kernels use it, one lane per test vector (tests/test_gpu_zp.py compares with Python integers;
+// reference src/SpaSM.jl:383-390).  out[8 * i ..] = mul, axpy, add, sub, neg, inverse, lazy product reduced
+// (mul_lazy + acc_reduce_short: the scatter kernels' path), sum of 64 lazy products reduced (acc_reduce: the hash tables' path).
+// ------------------------------------------------------------------------------------------------
+template <bool SMALL>
+__global__ void k_zp_probe(ZpField F, int n, const int *__restrict__ a, const int *__restrict__ b, const int *__restrict__ c, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = a[i], y = b[i], z = c[i];
+    int *o = out + (size_t)8 * i;
+    o[0] = zp_mul(F, x, y);
+    o[1] = zp_axpy(F, x, y, z);
+    o[2] = zp_add(F, x, y);
+    o[3] = zp_sub(F, x, y);
+    o[4] = zp_neg(F, x);
+    o[5] = x != 0 ? zp_inverse(F, x) : 0;
+    o[6] = acc_reduce_short<SMALL>(F, ZpAcc<SMALL>::mul_lazy(F, x, y));
+    typename ZpAcc<SMALL>::type acc = 0;
+    for (int k = 0; k < 64; k++) acc += ZpAcc<SMALL>::mul_lazy(F, x, y);
+    o[7] = acc_reduce<SMALL>(F, acc);
+}
+

@@ -55,3 +55,45 @@ def test_verify_rejects_mismatched_matrix(S, O):
     lu = _copy_lu(S, O.echelonize(A), 200)
     assert S.factorization_verify(A, lu, 3)
     assert not S.factorization_verify(B, lu, 3)
+
+
+@pytest.mark.parametrize("kind,n,m,kw,p,seed", [(1, 600, 640, dict(row_nnz=3), 65521, 1), (1, 500, 400, dict(row_nnz=5), 127, 2),
+                                                (1, 700, 900, dict(row_nnz=8), 0xFFFFFFFB, 3), (0, 300, 500, dict(density=0.01), 2147483647, 4)])
+def test_oracle_fl_on_columns_pivots(S, O, kind, n, m, kw, p, seed):
+    """The oracle's restatement of the "Faugere-Lachartre on columns" search (enable_greedy_pivot_search, reference
+    src/SpaSM.jl:326; oracle fl_pivots_ex): pivots that are not leftmost entries, yet U stays (permuted) triangular in the order
+    it is stored, spans the rows of A (factorization_verify accepts it for several seeds), has the rank of the leftmost-only
+    run, and yields a kernel basis that annihilates A.  A cycle among the pivots must be rejected by the verifier."""
+    A = S.synth_csr(kind, n, m, prime=p, seed=seed, **kw)
+    g = O.echelonize(A, enable_greedy_pivot_search=True)
+    l = O.echelonize(A, enable_greedy_pivot_search=False)
+    assert g.r == l.r
+    rows = g.U.rows()
+    q = np.asarray(g.qinv)
+    pc = {int(q[j]): j for j in range(m) if q[j] >= 0}
+    assert sorted(pc) == list(range(g.r))
+    assert any(min(c for c, _ in row) != pc[a] for a, row in enumerate(rows)), "no pivot off the leftmost entry: the search did nothing"
+    for a, row in enumerate(rows):  # stored in topological order: a row only touches pivot columns of later rows
+        assert all(q[c] < 0 or q[c] >= a for c, _ in row)
+    lu = _copy_lu(S, g, n)
+    for sd in (0, 1, 2):
+        assert S.factorization_verify(A, lu, sd)
+    # K * A^T == 0 with exact integers
+    K = O.kernel(g)
+    assert K.n == m - g.r
+    Arows = A.rows()
+    for krow in K.rows():
+        kv = dict(krow)
+        for arow in Arows:
+            assert sum(v * kv.get(c, 0) for c, v in arow) % p == 0
+    # two rows that hold each other's pivot column: no order eliminates with them, the verifier must say no
+    if g.r >= 2:
+        cyc = [list(r) for r in rows]
+        a, b = 0, 1
+        if not any(c == pc[b] for c, _ in cyc[a]):
+            cyc[a].append((pc[b], 1))
+        if not any(c == pc[a] for c, _ in cyc[b]):
+            cyc[b].append((pc[a], 1))
+        Uc = S.CSR.from_rows(cyc, m, p)
+        bad = S.LU.from_parts(Uc, np.array(q, dtype=np.int32), np.full(max(n, m, 1), -1, dtype=np.int32))
+        assert not S.factorization_verify(A, bad, 1)

@@ -640,3 +640,99 @@ def test_schur_complement_straight_to_dense(S, O, kind, n, m, kw, prime):
     assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
     assert S.kernel(fact).rows() == O.kernel(olu).rows()
     assert S.factorization_verify(A, fact, 7)
+
+
+# ---- "Faugère-Lachartre on columns" (enable_greedy_pivot_search, reference src/SpaSM.jl:326; log line README.md:22) -------------
+
+GREEDY_CASES = [
+    ("fixed_nnz", 1, 3000, 3000, dict(row_nnz=6), 65521),
+    ("three_per_row", 1, 8000, 8000, dict(row_nnz=3), 65521),
+    ("macaulay_like", 2, 4000, 1600, dict(row_nnz=40), 127),
+    ("bernoulli", 0, 900, 1300, dict(density=0.01), 2147483647),
+    ("wide_big_prime", 1, 2500, 4000, dict(row_nnz=8), 0xFFFFFFFB),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,n,m,kw,prime", GREEDY_CASES, ids=[c[0] for c in GREEDY_CASES])
+def test_fl_on_columns_takes_the_oracles_pivots(S, O, name, kind, n, m, kw, prime):
+    """With enable_greedy_pivot_search the sparse rounds also take pivots that are not leftmost entries: on columns no pivot row
+    touches, chosen by column occupancy (kernels.hpp k_close_cols ..; oracle fl_pivots_ex).  The rule is order-free, so engine
+    and oracle must elect the same pivots round by round: with the dense finish off both go through the same max_round rounds
+    and finish on leftmost entries, which makes rank, pivot columns, the rows of U from the sparse rounds and the kernel basis
+    comparable entry for entry."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xF1C0, **kw)
+    fact = S.echelonize(A, enable_greedy_pivot_search=True, enable_dense=False)
+    rounds = S.last_rounds()
+    olu = O.echelonize(A, enable_greedy_pivot_search=True)
+    plain = S.echelonize(A, enable_greedy_pivot_search=False, enable_dense=False)
+    assert fact.r == olu.r == plain.r
+    assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
+    sparse_rounds = [r for r in rounds if r["round"] < 3]
+    assert sum(r["npiv_open"] for r in sparse_rounds) > 0, rounds            # the search found something
+    assert all(r["npiv_open"] == 0 for r in rounds if r["round"] >= 3)       # the finish keeps to leftmost entries
+    k = sum(r["npiv"] for r in sparse_rounds)
+    assert fact.U.rows()[:k] == olu.U.rows()[:k]                             # same pivot rows, same order, same values
+    assert S.kernel(fact).rows() == O.kernel(olu).rows()
+    assert S.factorization_verify(A, fact, 11)
+    # some pivot is NOT the leftmost entry of its row
+    q = np.asarray(fact.qinv)
+    pc = {int(q[j]): j for j in range(m) if q[j] >= 0}
+    assert any(min(c for c, _ in row) != pc[a] for a, row in enumerate(fact.U.rows()[:k]))
+
+
+@pytest.mark.gpu
+def test_fl_on_columns_finds_more_pivots_per_round(S, O):
+    """What the search is for: more structural pivots per round, fewer rounds.  On the 3-per-row matrix
+    the first round must elect visibly more pivots than the leftmost-entry election alone, and the whole run must not take
+    more rounds; the rank is that of the oracle."""
+    A = S.synth_csr(1, 100000, 100000, row_nnz=3, prime=65521, seed=0xF1C1)
+    g = S.echelonize(A, enable_greedy_pivot_search=True)
+    rg = S.last_rounds()
+    l = S.echelonize(A, enable_greedy_pivot_search=False)
+    rl = S.last_rounds()
+    assert g.r == l.r
+    assert rg[0]["npiv"] - rg[0]["npiv_open"] == rl[0]["npiv"]               # the leftmost election is the same
+    assert rg[0]["npiv_open"] > 0.05 * rl[0]["npiv"], (rg[0], rl[0])
+    assert len(rg) <= len(rl)
+    assert S.factorization_verify(A, g, 3) and S.factorization_verify(A, l, 3)
+    Kg = S.kernel(g)
+    assert Kg.n == A.m - g.r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,p,density,seed", [(60, 80, 65521, 0.08, 1), (120, 90, 127, 0.05, 2), (90, 140, 2147483647, 0.06, 3)])
+def test_consumers_accept_pivots_that_are_not_leftmost(S, O, n, m, p, density, seed):
+    """rref, the triangular solve and the kernel number the pivots in a topological order of U (engine.hip
+    pivot_topological_order), so a factorization from the "FL on columns" search -- or the oracle's -- works like any other:
+    R has the unit vectors on the pivot columns and the same row space; X * U == B; K spans the right kernel."""
+    rng = np.random.default_rng(seed)
+    D = ((rng.random((n, m)) < density) * rng.integers(1, min(p, 1 << 31), size=(n, m))).astype(np.int64)
+    D[n - 1] = (3 * D[0] + 5 * D[1]) % p
+    A = S.CSR(D.T.copy(), prime=p)
+    fact = S.echelonize(A, enable_greedy_pivot_search=True, enable_dense=False)
+    olu = O.echelonize(A, enable_greedy_pivot_search=True)
+    assert fact.r == olu.r and np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
+    q = np.asarray(fact.qinv)
+    piv = [j for j in range(m) if q[j] >= 0]
+    R, rq = S.rref(fact)
+    Rd = np.zeros((R.n, m), dtype=object)
+    for k, row in enumerate(R.rows()):
+        for c, v in row:
+            Rd[k, c] = v % p
+    for j in piv:                                                            # identity on the pivot columns
+        col = Rd[:, j]
+        assert col[int(rq[j])] == 1 and sum(1 for v in col if v) == 1
+    _, pr = O.dense_rref(np.vstack([D % p, np.array(Rd.tolist(), dtype=np.int64)]), p)
+    assert len(pr) == fact.r == R.n                                           # same row space
+    # the same through the oracle's factorization (a foreign LU, rows in the oracle's order)
+    foreign = S.LU.from_parts(S.CSR.from_rows(olu.U.rows(), m, p), np.asarray(olu.qinv, dtype=np.int32), np.full(max(n, m), -1, dtype=np.int32))
+    R2, rq2 = S.rref(foreign)
+    assert sorted(map(tuple, (tuple(r) for r in R2.rows()))) == sorted(map(tuple, (tuple(r) for r in R.rows())))
+    assert S.kernel(foreign).rows() == S.kernel(fact).rows() == O.kernel(olu).rows()
+    # X * U == B for the rows of A
+    X = S.sparse_triangular_solve(fact, A)
+    assert X is not None
+    Ud = np.array(fact.U.todense().tolist(), dtype=object) % p
+    Xd = np.array(X.todense().tolist(), dtype=object) % p
+    assert ((Xd.dot(Ud) - (D % p)) % p == 0).all()
