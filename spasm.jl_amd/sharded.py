@@ -260,7 +260,9 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     engine_cls = engine_cls or GpuRoundEngine
-    finish = finish or (lambda M: api.echelonize(M))
+    # the sharded rounds elect leftmost-entry pivots only (one all-reduce per round); the finish keeps to them as well, so that the
+    # pivot columns and the kernel basis do not depend on the number of ranks
+    finish = finish or (lambda M: api.echelonize(M, enable_greedy_pivot_search=False))
     sparsity_threshold = float(api.EchelonizeOpts().struct.sparsity_threshold)
     n, m, prime = A.n, A.m, int(A.prime)
     eng = engine_cls(A, rank, n, stride=world)  # the rank's rows stay on its device from here on

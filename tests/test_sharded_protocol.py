@@ -193,7 +193,7 @@ def _echelonize_worker(rank, world, port, n, m, k, p, seed, finish_nnz, q):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         A = S.synth_csr(1, n, m, row_nnz=k, prime=p, seed=seed)
-        fact, info = sharded.echelonize_sharded(A, engine_cls=NumpyRoundEngine, finish=O.echelonize, finish_nnz=finish_nnz)
+        fact, info = sharded.echelonize_sharded(A, engine_cls=NumpyRoundEngine, finish=lambda M: O.echelonize(M, enable_greedy_pivot_search=False), finish_nnz=finish_nnz)
         K = O.kernel(fact)
         q.put((rank, fact.r, np.asarray(fact.qinv).tolist(), K.rows(), [(r["finish"], r["npiv"]) for r in info["rounds"]]))
     except Exception as exc:
