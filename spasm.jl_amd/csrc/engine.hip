@@ -1451,69 +1451,186 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
     return dense_eliminate(D, R, C, ldc, clist.p, row_orig.p, F, U, s);
 }
 
-// The Schur complement of the round R has prepared (pivots elected, U built), computed straight into a dense matrix over the
-// columns that are left, and eliminated there: the finish of an echelonization whose remainder is dense.  The rows go through the
-// solve in batches (only their multiplier records have to fit, nothing sparse is written).
-void schur_dense_finish(Round &R, const DevMat &cur, int nnp, int chunk, double rec_per_row, i64 max_pool, HostU &U, hipStream_t s)
-{
-    const int m = cur.m;
+// ------------------------------------------------------------------------------------------------
+// The Schur complement of a round straight into a dense matrix (spasm_schur_dense, prototype reference src/SpaSM.jl:765-766),
+// through a dense image of W = -(I + U_PP)^-1 U_PN (kernels.hpp, k_wd_level ..): no multiplier solve, so the cost does not
+// depend on how many pivots a row reaches.
+// ------------------------------------------------------------------------------------------------
+struct DenseW {
+    Round &R;
+    const DevMat &cur;
+    hipStream_t s;
     Scanner scan;
+    DevBuf<int> cflag, cscan, cmap, clist, cmap_s, order;
+    DevBuf<int> Wd;
+    std::vector<int> lvl_off; // rows order[lvl_off[l-1] .. lvl_off[l]) make level l >= 1 (level 0 needs no combination)
+    int C = 0, depth = 0;
+    bool have_levels = false;
+
+    DenseW(Round &R_, const DevMat &cur_, hipStream_t s_) : R(R_), cur(cur_), s(s_) {}
+
     // columns of the dense matrix: those that hold entries of the current matrix and carry no pivot of this round
-    DevBuf<int> cflag, cscan, cmap, clist;
-    cflag.alloc((size_t)m + 1); cscan.alloc((size_t)m + 1); cmap.alloc((size_t)m + 1); clist.alloc((size_t)m + 1);
-    cflag.zero(s);
-    if (cur.n > 0) {
-        hipLaunchKernelGGL(k_flag_cols, dim3(cdiv((i64)cur.n * 64, 256)), dim3(256), 0, s, cur.n, cur.start.p, cur.len.p, cur.ent.p, cflag.p);
+    int map_columns()
+    {
+        const int m = cur.m;
+        cflag.alloc((size_t)m + 1); cscan.alloc((size_t)m + 1); cmap.alloc((size_t)m + 1); clist.alloc((size_t)m + 1); cmap_s.alloc((size_t)m + 1);
+        cflag.zero(s);
+        if (cur.n > 0) {
+            hipLaunchKernelGGL(k_flag_cols, dim3(cdiv((i64)cur.n * 64, 256)), dim3(256), 0, s, cur.n, cur.start.p, cur.len.p, cur.ent.p, cflag.p);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_mask_pivot_cols, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, s, m, R.qinv_r.p, cflag.p);
+        HIPCHK(hipGetLastError());
+        scan.exclusive(cflag.p, cscan.p, (size_t)m + 1, s);
+        HIPCHK(hipMemcpyAsync(&C, cscan.p + m, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (C > 0) {
+            hipLaunchKernelGGL(k_col_map, dim3(cdiv(m, 256)), dim3(256), 0, s, m, cflag.p, cscan.p, cmap.p, clist.p);
+            HIPCHK(hipGetLastError());
+        }
+        return C;
+    }
+
+    // levels of the pivot graph (pivot indices are a topological order: row q of U_PP only holds indices > q)
+    void levels()
+    {
+        if (have_levels) return;
+        have_levels = true;
+        const int npiv = R.npiv;
+        std::vector<UHdr> hdr((size_t)std::max(npiv, 1));
+        std::vector<int2> upp((size_t)std::max<i64>(R.utotal, 1));
+        HIPCHK(hipMemcpyAsync(hdr.data(), R.uhdr.p, (size_t)npiv * sizeof(UHdr), hipMemcpyDeviceToHost, s));
+        if (R.utotal > 0) HIPCHK(hipMemcpyAsync(upp.data(), R.UPP.p, (size_t)R.utotal * sizeof(int2), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int> lev((size_t)std::max(npiv, 1), 0);
+        depth = 0;
+        for (int q = npiv - 1; q >= 0; q--) {
+            const UHdr &h = hdr[(size_t)q];
+            int l = 0;
+            for (int k = 0; k < h.npp; k++) l = std::max(l, lev[(size_t)upp[(size_t)h.off + (size_t)k].x] + 1);
+            lev[(size_t)q] = l;
+            depth = std::max(depth, l);
+        }
+        lvl_off.assign((size_t)depth + 1, 0);
+        for (int q = 0; q < npiv; q++) if (lev[(size_t)q] > 0) lvl_off[(size_t)lev[(size_t)q]]++;
+        // lvl_off[l] = end of level l after the prefix sum; level l starts at lvl_off[l - 1]
+        for (int l = 1; l <= depth; l++) lvl_off[(size_t)l] += lvl_off[(size_t)l - 1];
+        std::vector<int> h_order((size_t)std::max(lvl_off[(size_t)depth], 1)), cursor(lvl_off.begin(), lvl_off.end());
+        for (int q = 0; q < npiv; q++) {
+            const int l = lev[(size_t)q];
+            if (l > 0) h_order[(size_t)cursor[(size_t)l - 1]++] = q;
+        }
+        order.alloc(h_order.size());
+        HIPCHK(hipMemcpyAsync(order.p, h_order.data(), h_order.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+
+    static int threads_for(int Cs) { return Cs >= 1024 ? 256 : std::max(16, Cs / 4); }
+
+    // W on the columns cmap_s maps to 0 .. Cs-1 (Cs a multiple of 64)
+    void build_w(int Cs)
+    {
+        levels();
+        const int npiv = R.npiv;
+        const i64 ldw = Cs;
+        Wd.ensure((size_t)std::max(npiv, 1) * (size_t)ldw);
+        HIPCHK(hipMemsetAsync(Wd.p, 0, (size_t)npiv * (size_t)ldw * sizeof(int), s));
+        constexpr int TEAM = 16;
+        hipLaunchKernelGGL((k_wd_seed<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, s, npiv, R.F, R.uhdr.p, R.UPN.p, cmap_s.p, Wd.p, (i64d)ldw);
+        HIPCHK(hipGetLastError());
+        const int bt = threads_for(Cs);
+        const unsigned gy = (unsigned)cdiv(Cs, 4 * bt);
+        for (int l = 1; l <= depth; l++) {
+            const int lo = lvl_off[(size_t)l - 1], cnt = lvl_off[(size_t)l] - lo;
+            if (cnt == 0) continue;
+            if (R.F.small) hipLaunchKernelGGL((k_wd_level<true>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, Wd.p, (i64d)ldw, Cs);
+            else hipLaunchKernelGGL((k_wd_level<false>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, Wd.p, (i64d)ldw, Cs);
+            if ((l & 1023) == 0) HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_mask_pivot_cols, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, s, m, R.qinv_r.p, cflag.p);
-    HIPCHK(hipGetLastError());
-    scan.exclusive(cflag.p, cscan.p, (size_t)m + 1, s);
-    int C = 0;
-    HIPCHK(hipMemcpyAsync(&C, cscan.p + m, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+
+    // the Schur rows of `rows` (local rows, device list) on the slab's columns: Dp[t][dcol0 + j]
+    void rows_into(const int *rows, int nrows, int Cs, int *Dp, i64 ldc, int dcol0)
+    {
+        if (nrows == 0) return;
+        const int bt = threads_for(Cs);
+        const unsigned gy = (unsigned)cdiv(Cs, 4 * bt);
+        if (R.F.small) hipLaunchKernelGGL((k_wd_rows<true>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, rows, R.F, cur.start.p, cur.len.p, cur.ent.p,
+                                          R.qinv_r.p, cmap_s.p, Wd.p, (i64d)Cs, Cs, Dp, (i64d)ldc, dcol0);
+        else hipLaunchKernelGGL((k_wd_rows<false>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, rows, R.F, cur.start.p, cur.len.p, cur.ent.p,
+                                R.qinv_r.p, cmap_s.p, Wd.p, (i64d)Cs, Cs, Dp, (i64d)ldc, dcol0);
+        HIPCHK(hipGetLastError());
+    }
+
+    void slab(int s0, int Cs, int stride)
+    {
+        hipLaunchKernelGGL(k_slab_cmap, dim3(cdiv(cur.m, 256)), dim3(256), 0, s, cur.m, cmap.p, s0, Cs, stride, cmap_s.p);
+        HIPCHK(hipGetLastError());
+    }
+
+    // spasm_schur_estimate_density (prototype reference src/SpaSM.jl:763-764) without solving a single row: the Schur complement
+    // restricted to 64 of its columns, evenly spread, for ALL the non-pivot rows; density relative to `free_cols` columns
+    double estimate_density(const int *rows, int nrows, int free_cols)
+    {
+        if (C == 0 || nrows == 0 || free_cols <= 0) return 0.0;
+        const int Cs = 64, stride = std::max(1, C / Cs);
+        const int sampled = std::min(Cs, (C + stride - 1) / stride);
+        slab(0, Cs, stride > 1 ? stride : 0); // (stride 1: the first 64 columns, as a slab)
+        build_w(Cs);
+        DevBuf<int> Dsm;
+        DevBuf<u64d> cnt;
+        Dsm.alloc((size_t)nrows * Cs);
+        cnt.alloc(1);
+        cnt.zero(s);
+        rows_into(rows, nrows, Cs, Dsm.p, Cs, 0);
+        hipLaunchKernelGGL(k_count_nonzero, dim3(std::min(cdiv((i64)nrows * Cs, 256), R.num_cu * 16)), dim3(256), 0, s, (i64d)nrows * Cs, Dsm.p, cnt.p);
+        HIPCHK(hipGetLastError());
+        u64d nz = 0;
+        HIPCHK(hipMemcpyAsync(&nz, cnt.p, sizeof nz, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        // nz / (rows * sampled) is the density over the C live columns; the other free columns are empty
+        return (double)nz / ((double)nrows * (double)sampled) * ((double)C / (double)free_cols);
+    }
+};
+
+// The finish of an echelonization whose remainder is dense: the Schur complement of the round R has prepared (pivots elected, U
+// built) goes straight into a dense matrix over the columns that are left, and is eliminated there.
+void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStream_t s, DenseW *prepared = nullptr)
+{
+    std::unique_ptr<DenseW> own;
+    if (!prepared) {
+        own.reset(new DenseW(R, cur, s));
+        own->map_columns();
+        prepared = own.get();
+    }
+    DenseW &W = *prepared;
+    const int C = W.C;
     if (C == 0 || nnp == 0) return;
-    hipLaunchKernelGGL(k_col_map, dim3(cdiv(m, 256)), dim3(256), 0, s, m, cflag.p, cscan.p, cmap.p, clist.p);
-    HIPCHK(hipGetLastError());
     const i64 ldc = ((i64)C + 63) / 64 * 64;
     DevBuf<int> D, row_orig;
     D.alloc((size_t)nnp * (size_t)ldc);
     row_orig.alloc((size_t)nnp + 1);
-    D.zero(s);
     hipLaunchKernelGGL(k_gather_int, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, R.np_rows.p, cur.orig.p, row_orig.p);
     HIPCHK(hipGetLastError());
-    int off = 0;
-    while (off < nnp) {
-        const int cnt = std::min(chunk, nnp - off);
-        const i64 tot = R.solve_phase(cur, R.np_rows.p + off, nullptr, cnt, std::max<i64>((i64)(rec_per_row * (double)cnt), 1 << 16), max_pool);
-        if (tot < 0) {
-            if (cnt <= 1) throw EngineError("the multiplier records of one row do not fit the device memory");
-            chunk = std::max(1, cnt / 2);
-            continue;
-        }
-        SchurDenseArgs a;
-        a.nrows = cnt;
-        a.roff = off;
-        a.rows = R.np_rows.p + off;
-        a.sflag = R.sflag.p;
-        a.start = cur.start.p;
-        a.len = cur.len.p;
-        a.ent = cur.ent.p;
-        a.qinv_r = R.qinv_r.p;
-        a.Lstart = R.Lstart.p;
-        a.Llen = R.Llen.p;
-        a.Lpool = R.Lpool.p;
-        a.UPN = R.UPN.p;
-        a.cmap = cmap.p;
-        a.D = D.p;
-        a.ldc = (i64d)ldc;
-        a.F = R.F;
-        hipLaunchKernelGGL(k_schur_dense, dim3(std::min(cdiv((i64)cnt * 64, 256), R.num_cu * 8)), dim3(256), 0, s, a);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
-        off += cnt;
+    // W for as many columns at a time as a third of the free memory holds
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    i64 budget = (i64)(fr / 3) + (i64)(W.Wd.n * sizeof(int));
+    if (const char *mb = getenv("SPASM_AMD_MEM_BUDGET_MB")) budget = std::max<i64>(atoll(mb), 1) << 18; // tests: several slabs
+    i64 Cs = std::min<i64>(ldc, std::max<i64>(64, budget / ((i64)std::max(R.npiv, 1) * 4) / 64 * 64));
+    int nslab = 0;
+    for (i64 s0 = 0; s0 < ldc; s0 += Cs, nslab++) {
+        const int w = (int)std::min<i64>(Cs, ldc - s0);
+        W.slab((int)s0, w, 0);
+        W.build_w(w);
+        W.rows_into(R.np_rows.p, nnp, w, D.p, ldc, (int)s0);
     }
-    dense_eliminate(D, nnp, C, ldc, clist.p, row_orig.p, R.F, U, s);
+    HIPCHK(hipStreamSynchronize(s));
+    spasm_logf("[echelonize/dense] Schur complement %d x %d through a dense W (%d pivots, %d levels, %d slab%s of columns)\n", nnp, C, R.npiv, W.depth,
+               nslab, nslab == 1 ? "" : "s");
+    W.Wd.release();
+    dense_eliminate(D, nnp, C, ldc, W.clist.p, row_orig.p, R.F, U, s);
 }
 
 struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
@@ -1630,7 +1747,19 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         double rec_per_row = 4.0 * (double)cur_nnz / (double)std::max(nnp, 1), slots_per_row = 0;
         double est_density = -1;
         const int free_now = m - (int)U.pivcol.size() - R->npiv;
-        if (nnp > 0) {
+        const bool dense_possible = opts->enable_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries();
+        std::unique_ptr<DenseW> dw;
+        if (nnp > 0 && dense_possible && !R->use_uinv) {
+            // No Uinv: the rows of this round reach many pivots (or there are few rows), and the row sample below would walk those
+            // reaches one dependent step at a time (1.7 s for 2048 rows of the 200k x 80k Macaulay-like case).  Sample COLUMNS
+            // instead: the Schur complement on 64 of its columns, all rows, through a dense W.
+            dw.reset(new DenseW(*R, *cur, stream));
+            dw->map_columns();
+            est_density = dw->estimate_density(R->np_rows.p, nnp, free_now);
+            spasm_logf("Schur complement is %d x %d, estimated density : %.2f (64 columns sampled, %d levels)\n", nnp, free_now, est_density, dw->depth);
+        }
+        const bool go_dense = dense_possible && est_density > opts->sparsity_threshold;
+        if (nnp > 0 && !go_dense) {
             const int probe = std::min(nnp, 2048);
             const int step = nnp / probe;
             DevBuf<int> probe_rows;
@@ -1638,13 +1767,12 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
             hipLaunchKernelGGL(k_pick_stride, dim3(cdiv(probe, 256)), dim3(256), 0, stream, probe, step, R->np_rows.p, probe_rows.p);
             HIPCHK(hipGetLastError());
             const i64 tp = R->solve_phase(*cur, probe_rows.p, nullptr, probe, 1 << 20, max_pool);
-            // (the sample's Schur rows are only computed where the answer can matter: the dense finish allowed and within reach)
-            const bool dense_possible = opts->enable_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries();
             if (tp >= 0) {
                 rec_per_row = std::max(rec_per_row, 1.25 * (double)R->pool_used() / probe);
                 slots_per_row = 1.25 * (double)tp / probe;
             }
-            if (tp >= 0 && tp <= max_slots && dense_possible) {
+            // (the sample's Schur rows are only computed where the answer can matter: the dense finish allowed and within reach)
+            if (tp >= 0 && tp <= max_slots && dense_possible && est_density < 0) {
                 R->S.ent.ensure((size_t)tp + 1);
                 R->run_scatter(*cur, probe_rows.p, probe);
                 R->fetch_counters();
@@ -1660,19 +1788,20 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         }
         // ---- dense already?  Then the Schur complement goes straight into the dense matrix of the finish (spasm_schur_dense,
         // prototype src/SpaSM.jl:765-766) and is never materialised sparse.
-        if (opts->enable_dense && est_density > opts->sparsity_threshold && (double)nnp * (double)free_now <= (double)dense_max_entries()) {
+        if (dense_possible && est_density > opts->sparsity_threshold) {
             spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found\n", round, R->n_leftmost);
             if (R->n_open) spasm_logf("[pivots] ``Faugère-Lachartre on columns'': %d pivots found\n", R->n_open);
             spasm_logf("[echelonize] finishing; density = %.3f (estimated); aspect ratio = %.1f; Schur complement straight to dense\n", est_density,
                        free_now > 0 ? (double)nnp / (double)free_now : 0.0);
             append_round_U(U, *R, *cur, stream);
-            schur_dense_finish(*R, *cur, nnp, chunk, rec_per_row, max_pool, U, stream);
+            schur_dense_finish(*R, *cur, nnp, U, stream, dw.get());
             spasm_amd_round_stats st;
             fill_stats(st, *R, round, cur->n, cur_nnz);
             st.nnz_out = -1; // (never counted: the rows went dense)
             g_last_rounds.push_back(st);
             break;
         }
+        dw.reset();
         while (off < nnp || nnp == 0) {
             const int cnt = std::min(chunk, nnp - off);
             HIPCHK(hipEventRecord(R->ev[1], stream));

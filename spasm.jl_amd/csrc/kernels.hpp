@@ -2220,64 +2220,130 @@ __global__ void k_dense_emit(int C, const int *__restrict__ D, i64d ldc, const i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Schur complement straight into a dense matrix (replaces libspasm's spasm_schur_dense, prototype reference src/SpaSM.jl:765-766):
-// when the density estimate says the Schur complement will be dense, its rows are never built sparse -- no hash table, no
-// 8-byte entries, no slots: D[row][cmap[col]] takes the row's own non-pivot entries and, run after run, minus the multiplier
-// times the run (a run = a pivot row's non-pivot part, or a chunk of a row of W).  One wave per row; the runs of a row are
-// applied one after the other (the columns of one run are distinct), waiting for the stores of a run before the next reads.
+// Schur complement through a DENSE W (spasm_schur_dense, prototype reference src/SpaSM.jl:765-766, for rounds whose rows reach
+// thousands of pivots -- Macaulay-like matrices).  The multiplier solve walks the reach of every row, one dependent round trip
+// per pivot (k_solve / k_solve_big: 8.7 of 11.5 s of kernel time on the 200k x 80k case); a dense image of
+//     W = -(I + U_PP)^-1 U_PN          (one row per pivot, one column per column of the dense matrix D)
+// costs the same whatever the reach: row q of W is  -U_PN[q] - sum over the entries (c, v) of U_PP[q] of v * W[c], c > q, so the
+// rows are computed level by level of the pivot graph (levels from the host, one launch each), and then
+//     D[row] = row_N + sum over the row's entries (col, a) on pivot columns of a * W[q(col)].
+// Every step is a combination of dense rows with a handful of coefficients: HBM-bound streaming, 16 bytes per lane.  The columns
+// are independent, so W is built for a slab of columns at a time when it does not fit whole, and a sample of 64 columns gives
+// the density estimate (spasm_schur_estimate_density) without any row solve.
+// cmap_s: column of the matrix -> column of the slab, -1 outside.
 // ------------------------------------------------------------------------------------------------
-struct SchurDenseArgs {
-    int nrows;                 // rows of this batch
-    int roff;                  // dense row of its first row
-    const int *rows;           // local row of each row slot
-    const int *sflag;          // 1: the row's own entries are among its records (plan along W)
-    const i64d *start;
-    const int *len;
-    const int2 *ent;
-    const int *qinv_r;
-    const i64d *Lstart;
-    const int *Llen;
-    const int4 *Lpool;
-    const int2 *UPN;
-    const int *cmap;           // column -> dense column (-1: not a column of D)
-    int *D;
-    i64d ldc;
-    ZpField F;
+__global__ void k_slab_cmap(int m, const int *__restrict__ cmap, int s0, int Cs, int stride, int *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int idx = cmap[j];
+    int o = -1;
+    if (idx >= 0) {
+        if (stride <= 1) { if (idx >= s0 && idx - s0 < Cs) o = idx - s0; }
+        else if (idx % stride == 0 && idx / stride < Cs) o = idx / stride;
+    }
+    out[j] = o;
+}
+
+template <int TEAM>
+__global__ void k_wd_seed(int npiv, ZpField F, const UHdr *__restrict__ uhdr, const int2 *__restrict__ UPN, const int *__restrict__ cmap_s,
+                          int *__restrict__ Wd, i64d ldw)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int q = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (q >= npiv) return;
+    const UHdr h = uhdr[q];
+    for (int k = tl; k < h.npn; k += TEAM) {
+        const int2 e = UPN[(i64d)h.off + k];
+        const int j = cmap_s[e.x];
+        if (j >= 0) Wd[(i64d)q * ldw + j] = zp_neg(F, e.y);
+    }
+}
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+template <bool SMALL> struct DenseAcc;
+template <> struct DenseAcc<true> { // p < 2^16: |a * w| < 2^30, an i64 takes 2^33 terms
+    long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    __device__ __forceinline__ void fma(const ZpField &, int c, v4i32 w)
+    {
+        a0 += (long long)c * w.x; a1 += (long long)c * w.y; a2 += (long long)c * w.z; a3 += (long long)c * w.w;
+    }
+    __device__ __forceinline__ v4i32 finish(const ZpField &F, v4i32 base) const
+    {
+        return (v4i32){zp_reduce(F, a0 + base.x), zp_reduce(F, a1 + base.y), zp_reduce(F, a2 + base.z), zp_reduce(F, a3 + base.w)};
+    }
+};
+template <> struct DenseAcc<false> { // lazy products |r| < 2^31.1 (ZpAcc<false>), an i64 takes 2^31 of them
+    long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    __device__ __forceinline__ void fma(const ZpField &F, int c, v4i32 w)
+    {
+        a0 += ZpAcc<false>::mul_lazy(F, c, w.x); a1 += ZpAcc<false>::mul_lazy(F, c, w.y);
+        a2 += ZpAcc<false>::mul_lazy(F, c, w.z); a3 += ZpAcc<false>::mul_lazy(F, c, w.w);
+    }
+    __device__ __forceinline__ v4i32 finish(const ZpField &F, v4i32 base) const
+    {
+        return (v4i32){zp_reduce(F, a0 + base.x), zp_reduce(F, a1 + base.y), zp_reduce(F, a2 + base.z), zp_reduce(F, a3 + base.w)};
+    }
 };
 
-__global__ __launch_bounds__(256) void k_schur_dense(SchurDenseArgs a)
+// rows order[0 .. nrows) of W (one level of the pivot graph): W[q] -= sum v * W[c].  blockIdx.x = row, blockIdx.y = chunk of
+// 4 * blockDim.x columns; ldw and the slab width are multiples of 4
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_wd_level(int nrows, const int *__restrict__ order, ZpField F, const UHdr *__restrict__ uhdr,
+                                                  const int2 *__restrict__ UPP, int *__restrict__ Wd, i64d ldw, int Cs)
 {
-    const int lane = threadIdx.x & 63;
-    const ZpField F = a.F;
-    for (i64d t64 = ((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6; t64 < a.nrows; t64 += ((i64d)gridDim.x * blockDim.x) >> 6) {
-        const int t = (int)t64;
-        int *Drow = a.D + (i64d)(a.roff + t) * a.ldc;
-        if (!(a.sflag && a.sflag[t])) {
-            const int row = a.rows ? a.rows[t] : t;
-            const i64d st = a.start[row];
-            const int ln = a.len[row];
-            for (int k = lane; k < ln; k += 64) {
-                const int2 e = a.ent[st + k];
-                if (a.qinv_r[e.x] < 0) Drow[a.cmap[e.x]] = e.y; // (the columns of a row are distinct, D starts at zero)
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const i64d ls = a.Lstart[t];
-        const int ll = a.Llen[t];
-        for (int i = 0; i < ll; i++) {
-            const int4 le = a.Lpool[ls + i];
-            if (le.y == 0) continue;
-            const int nm = zp_neg(F, le.y);
-            const int2 *up = a.UPN + (unsigned)le.z;
-            for (int k = lane; k < le.w; k += 64) {
-                const int2 u = up[k];
-                int *d = Drow + a.cmap[u.x];
-                const int cur = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (from L2: the run before wrote it)
-                *d = zp_axpy(F, nm, u.y, cur);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int q = order[blockIdx.x];
+    const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if (j >= Cs) return;
+    const UHdr h = uhdr[q];
+    DenseAcc<SMALL> acc;
+    const int2 *up = UPP + (i64d)h.off;
+    for (int k = 0; k < h.npp; k++) {
+        const int2 e = up[k]; // (uniform over the workgroup)
+        const v4i32 w = *(const v4i32 *)(Wd + (i64d)e.x * ldw + j);
+        acc.fma(F, zp_neg(F, e.y), w);
+    }
+    v4i32 *dst = (v4i32 *)(Wd + (i64d)q * ldw + j);
+    *dst = acc.finish(F, *dst);
+    (void)nrows;
+}
+
+// dense Schur rows: D[t][dcol0 + j] = own entry on that column + sum a * W[q(col)][j].  blockIdx.x = row slot t (rows[t] = local row)
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_wd_rows(int nrows, const int *__restrict__ rows, ZpField F, const i64d *__restrict__ start,
+                                                 const int *__restrict__ len, const int2 *__restrict__ ent, const int *__restrict__ qinv_r,
+                                                 const int *__restrict__ cmap_s, const int *__restrict__ Wd, i64d ldw, int Cs, int *__restrict__ D, i64d ldc,
+                                                 int dcol0)
+{
+    const int t = blockIdx.x;
+    const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if (j >= Cs) return;
+    const int row = rows ? rows[t] : t;
+    const i64d st = start[row];
+    const int ln = len[row];
+    DenseAcc<SMALL> acc;
+    v4i32 own = (v4i32){0, 0, 0, 0};
+    for (int k = 0; k < ln; k++) {
+        const int2 e = ent[st + k]; // (uniform over the workgroup)
+        const int q = qinv_r[e.x];
+        if (q >= 0) {
+            acc.fma(F, e.y, *(const v4i32 *)(Wd + (i64d)q * ldw + j));
+        } else {
+            const int jj = cmap_s[e.x] - j;
+            if (jj == 0) own.x = e.y; else if (jj == 1) own.y = e.y; else if (jj == 2) own.z = e.y; else if (jj == 3) own.w = e.y;
         }
     }
+    *(v4i32 *)(D + (i64d)t * ldc + dcol0 + j) = acc.finish(F, own);
+    (void)nrows;
+}
+
+__global__ void k_count_nonzero(i64d n, const int *__restrict__ v, u64d *__restrict__ out)
+{
+    u64d c = 0;
+    for (i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64d)gridDim.x * blockDim.x) c += v[i] != 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor((long long)c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
 // flag[j] = 1 for a column that holds entries (flag comes in from k_flag_cols) and carries no pivot of this round
