@@ -1,0 +1,431 @@
+// Dense finish for primes below 2^16 (BASELINE configs 2, 3, 5: p = 65521 and p = 127) -- device code.
+//
+// Replaces, for those primes, the f64 panels of kernels.hpp (libspasm's spasm_ffpack_rref / spasm_ffpack_LU finish over the
+// datatype spasm_datatype_choose picks, prototypes reference src/SpaSM.jl:805-812, enum :373).  Same elimination -- columns left
+// to right, the pivot of a column is the FIRST row, not yet a pivot, that holds a non-zero in it -- organised in two levels:
+//
+//   panel (64 columns)   copied transposed into P[64][rows]; ONE persistent cooperative kernel eliminates it column by column
+//                        with the rows of every workgroup resident in LDS and one grid barrier per column (k_panel_lu): the
+//                        election is an atomicMin per workgroup, the elected row travels through a 256-byte global record.
+//                        The multipliers stay in P where they were read, as in an in-place LU.
+//   block (KB columns)   the panels of a block update only the columns of the block (K = 64); the columns right of the block
+//                        are updated once per block with K = KB.
+//   updates              rows that became pivots: triangular solve among the 64 of a panel (k_trsm_i8); everybody else: an int8
+//                        MFMA GEMM (k_gemm_i8, v_mfma_i32_32x32x32_i8, operands staged in LDS).  Residues are split in signed
+//                        base-256 digits -- one for p < 2^8, two for p < 2^16 (three accumulators: d0*d0, d0*d1 + d1*d0, d1*d1)
+//                        -- and recombined in 64 bits, so the result is exact.
+// The multipliers F[row][slot] and the normalised pivot rows Ut[column][slot] are kept as digit planes with the K index
+// contiguous, the layout both MFMA operands want (16 consecutive k per lane).
+#pragma once
+
+#include "kernels.hpp"
+
+#define DP_W 64            // columns of a panel
+#define DP_NONE 0x7fffffff
+
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+struct PanelInfo {          // one per panel of the current block; written by k_panel_lu
+    int npp;                // pivots found in the panel
+    int gbase;              // pivots found before it (sequence number of its first pivot)
+    int pad0, pad1;
+    int row[DP_W];          // pivot rows in election order, -1 beyond npp
+    int col[DP_W];          // their columns inside the panel
+    int inv[DP_W];          // inverse of the pivot value
+    int mtri[DP_W * DP_W];  // mtri[t * 64 + s] = multiplier of pivot row t at pivot s < t (0 elsewhere)
+};
+
+struct PanelSync {          // reset by k_panel_load before every k_panel_lu launch
+    unsigned arrive;        // grid-barrier counter
+    unsigned timeout;       // set when a bounded spin gave up (the launch is then reported as failed)
+    unsigned pad[2];
+    int cand[DP_W];         // per column: lowest candidate row (atomicMin), DP_NONE when there is none
+};
+
+// ---- P[j][i] = D[i][c0 + j] (j < w; 0 beyond), i < R; rows R .. Rp-1 are zero
+__global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w, const int *__restrict__ D, i64d ldc, int *__restrict__ P, PanelSync *sy)
+{
+    __shared__ int tile[DP_W][DP_W + 1];
+    const int i0 = blockIdx.x * 64;
+    if (blockIdx.x == 0) { // the words the panel kernel polls, reset in stream order before it
+        if (threadIdx.x < DP_W) sy->cand[threadIdx.x] = DP_NONE;
+        if (threadIdx.x == 0) { sy->arrive = 0; sy->timeout = 0; }
+    }
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, j = idx & 63;
+        const int i = i0 + r;
+        tile[j][r] = (i < R && j < w) ? D[(i64d)i * ldc + c0 + j] : 0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int j = idx >> 6, r = idx & 63;
+        if (i0 + r < Rp) P[(i64d)j * Rp + i0 + r] = tile[j][r];
+    }
+}
+
+// grid barrier number `epoch` (1, 2, ...) of a launch whose `nblocks` workgroups are all resident (cooperative launch).  No fences:
+// everything one workgroup hands to another in k_panel_lu is written with agent-scope atomic stores (write-through) and read with
+// agent-scope atomic loads (guide, guideline 16, forms R1 / R2); every storing wave drains its stores before the workgroup's barrier,
+// one lane then arrives and polls.  A fence pair (release: L2 write-back, acquire: invalidate) cost ~30 us per column instead.
+__device__ __forceinline__ bool panel_grid_barrier(PanelSync *sy, unsigned epoch, unsigned nblocks)
+{
+    __shared__ int s_ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&sy->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * nblocks;
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(&sy->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24) || __hip_atomic_load(&sy->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // (~ seconds)
+                __hip_atomic_store(&sy->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// a^-1 mod p for p < 2^16 in 32-bit arithmetic (the f64 / i64 Euclid of zp_inverse costs ~10 us on one lane, once per column of a
+// panel, on the critical path of every workgroup); a is a non-zero balanced residue
+__device__ __forceinline__ int zp_inverse_small(int p, int a)
+{
+    unsigned r0 = (unsigned)p, r1 = (unsigned)(a < 0 ? a + p : a);
+    int s0 = 0, s1 = 1;
+    while (r1 != 0) {
+        const unsigned q = r0 / r1;
+        const unsigned t = r0 - q * r1; r0 = r1; r1 = t;
+        const int u = s0 - (int)q * s1; s0 = s1; s1 = u; // |s| <= p throughout
+    }
+    int r = s0 % p;
+    if (r < 0) r += p;
+    return r > p / 2 ? r - p : r;
+}
+
+// x + a * b for balanced residues of a prime < 2^16, result balanced: one lazy reduction and a correction either way
+__device__ __forceinline__ int zp_axpy_small(const ZpField &F, int a, int b, int x)
+{
+    int r = zp_small_lazy(__mul24(a, b) + x, -F.finvp, (int)F.p);
+    if (r > (int)F.halfp) r -= (int)F.p;
+    else if (r < (int)F.mhalfp) r += (int)F.p;
+    return r;
+}
+
+// ---- the panel, one cooperative launch of NT-thread workgroups.  Workgroup b owns rows [b * chunk, (b + 1) * chunk) of P; with
+// INLDS they live in LDS as X[j * chunk + r] for the whole launch (chunk * 256 bytes), otherwise the kernel works on P in place
+// (L2 / MALL resident; only the owner of a row ever reads or writes it).  seq[i] = sequence number of the pivot row i became,
+// -1 while it is none.  candrow: 2 x gridDim.x records of 64 + 1 ints (the candidate row, then the inverse of its entry in
+// the current column).
+#define DP_REC 80
+template <bool INLDS, int NT>
+__global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c0, ZpField F, int *__restrict__ P, int *__restrict__ seq,
+                                                 int *__restrict__ pivrow_of_col, PanelInfo *__restrict__ info, PanelSync *sy, int *candrow,
+                                                 DenseState *st)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_x[]; // INLDS: chunk * 64 ints
+    __shared__ int s_prow[DP_W];
+    __shared__ int s_cand;
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * chunk;
+    const i64d xs = INLDS ? (i64d)chunk : (i64d)Rp; // stride between the columns of the row storage
+    int *X = INLDS ? s_x : P + base;
+    if (INLDS) {
+        for (int j = 0; j < DP_W; j++)
+            for (int r = tid; r < chunk; r += NT) s_x[j * chunk + r] = P[(i64d)j * Rp + base + r];
+    }
+    // the status of the rows this thread owns (r = tid + NT k): bit k set = not a pivot (yet)
+    unsigned long long live = 0;
+    const int nmine = tid < chunk ? (chunk - tid + NT - 1) / NT : 0;
+    for (int k = 0; k < nmine; k++)
+        if (seq[base + tid + NT * k] < 0) live |= 1ull << k;
+    const int gbase = st->npiv;
+    int npp = 0;
+    __syncthreads();
+    bool alive = true;
+    for (int c = 0; c < w && alive; c++) {
+        // ---- election: my first live row with a non-zero in column c
+        if (tid == 0) s_cand = DP_NONE;
+        __syncthreads();
+        int mine = DP_NONE;
+        {
+            unsigned long long m = live;
+            while (m) {
+                const int k = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (X[(i64d)c * xs + tid + NT * k] != 0) { mine = base + tid + NT * k; break; }
+            }
+        }
+        mine = wave_min_i32(mine);
+        if ((tid & 63) == 0 && mine != DP_NONE) atomicMin(&s_cand, mine);
+        __syncthreads();
+        const int wg_cand = s_cand;
+        int *rec = candrow + (size_t)((c & 1) * gridDim.x + blockIdx.x) * DP_REC;
+        if (wg_cand != DP_NONE) {
+            // the candidate's row (unscaled) and the inverse of its leading entry where every workgroup can read them, then the bid
+            // (two sets of records, by column parity: a workgroup may bid for column c + 1 while another still reads column c's)
+            if (tid < DP_W) __hip_atomic_store(&rec[tid], X[(i64d)tid * xs + (wg_cand - base)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == DP_W) __hip_atomic_store(&rec[DP_W], zp_inverse_small((int)F.p, X[(i64d)c * xs + (wg_cand - base)]), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 2 * DP_W) __hip_atomic_fetch_min(&sy->cand[c], wg_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        alive = panel_grid_barrier(sy, (unsigned)c + 1, gridDim.x);
+        const int p = __hip_atomic_load(&sy->cand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == DP_NONE || !alive) continue; // no pivot in this column
+        const int owner = p / chunk;
+        int *orec = candrow + (size_t)((c & 1) * gridDim.x + owner) * DP_REC;
+        const int inv = __hip_atomic_load(&orec[DP_W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < DP_W) {
+            const int raw = __hip_atomic_load(&orec[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prow[tid] = tid > c && tid < w ? zp_axpy_small(F, inv, raw, 0) : 0;
+        }
+        __syncthreads();
+        // ---- elimination of my live rows; the multiplier stays in column c
+        {
+            unsigned long long m = live;
+            while (m) {
+                const int k = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int r = tid + NT * k;
+                if (base + r == p) { live &= ~(1ull << k); continue; } // the new pivot row: frozen from here on
+                const int f = X[(i64d)c * xs + r];
+                if (f == 0) continue;
+                const int nf = -f;
+                for (int j = c + 1; j < w; j++) {
+                    int *x = &X[(i64d)j * xs + r];
+                    *x = zp_axpy_small(F, nf, s_prow[j], *x);
+                }
+            }
+        }
+        if (blockIdx.x == owner && tid == 0) {
+            seq[p] = gbase + npp;
+            pivrow_of_col[c0 + c] = p;
+            info->row[npp] = p;
+            info->col[npp] = c;
+            info->inv[npp] = inv;
+        }
+        npp++;
+        __syncthreads(); // s_prow is rewritten by the next column
+    }
+    if (INLDS) {
+        __syncthreads();
+        for (int j = 0; j < DP_W; j++)
+            for (int r = tid; r < chunk; r += NT) P[(i64d)j * Rp + base + r] = s_x[j * chunk + r];
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        info->npp = npp;
+        info->gbase = gbase;
+        for (int t = npp; t < DP_W; t++) { info->row[t] = -1; info->col[t] = -1; info->inv[t] = 0; }
+        st->npp = npp;
+        st->npiv = gbase + npp;
+        if (!alive) st->pad = 1; // a grid barrier timed out: the host reports the elimination as failed
+    }
+}
+
+// signed base-256 digits of the residue v of a prime < 2^16: a representative of v's class in [-32896, 32639]
+__device__ __forceinline__ void zp_digits(const ZpField &F, int v, int &d0, int &d1)
+{
+    if (v > 32639) v -= (int)F.p;
+    d0 = ((v + 128) & 255) - 128;
+    d1 = (v - d0) >> 8;
+}
+
+// ---- after k_panel_lu: the panel's columns of D (non-pivot rows: zero; the panel's pivot rows: normalised), the multipliers as
+// digit planes F[d][i][slot0 + s] (0 where row i was a pivot already when pivot s was elected), and mtri.
+template <int ND>
+__global__ __launch_bounds__(256) void k_panel_store(int R, int Rp, int c0, int w, ZpField F, const int *__restrict__ P, const int *__restrict__ seq,
+                                                    int *__restrict__ D, i64d ldc, PanelInfo *__restrict__ info, signed char *__restrict__ Fd, i64d fplane,
+                                                    int KB, int slot0)
+{
+    __shared__ int tile[DP_W][DP_W + 1];
+    __shared__ int s_col[DP_W], s_inv[DP_W], s_row[DP_W];
+    const int i0 = blockIdx.x * 64;
+    const int npp = info->npp, gbase = info->gbase;
+    if (threadIdx.x < DP_W) { s_col[threadIdx.x] = info->col[threadIdx.x]; s_inv[threadIdx.x] = info->inv[threadIdx.x]; s_row[threadIdx.x] = info->row[threadIdx.x]; }
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int j = idx >> 6, r = idx & 63;
+        tile[j][r] = i0 + r < Rp ? P[(i64d)j * Rp + i0 + r] : 0;
+    }
+    __syncthreads();
+    // multipliers: thread r (< 64) of each group of 64 writes the 64 slots of its row, 16 at a time
+    for (int idx = threadIdx.x; idx < 64 * 4; idx += 256) {
+        const int r = idx >> 2, part = idx & 3;
+        const int i = i0 + r;
+        if (i >= Rp) continue;
+        const int sq = i < R ? seq[i] : 0; // padding rows count as pivots of old: all zero
+        int w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0};
+        for (int b = 0; b < 16; b++) {
+            const int s = part * 16 + b;
+            int v = 0;
+            if (s < npp && (sq < 0 || sq > gbase + s)) v = tile[s_col[s]][r];
+            int d0, d1;
+            zp_digits(F, v, d0, d1);
+            w0[b >> 2] |= (d0 & 255) << (8 * (b & 3));
+            w1[b >> 2] |= (d1 & 255) << (8 * (b & 3));
+        }
+        *(int4 *)(Fd + (i64d)i * KB + slot0 + part * 16) = make_int4(w0[0], w0[1], w0[2], w0[3]);
+        if (ND == 2) *(int4 *)(Fd + fplane + (i64d)i * KB + slot0 + part * 16) = make_int4(w1[0], w1[1], w1[2], w1[3]);
+    }
+    // mtri (one workgroup does it: its rows are anywhere, so it reads P, not the tile)
+    if (blockIdx.x == 0)
+        for (int idx = threadIdx.x; idx < DP_W * DP_W; idx += 256) {
+            const int t = idx >> 6, s = idx & 63;
+            info->mtri[idx] = (s < t && t < npp) ? P[(i64d)s_col[s] * Rp + s_row[t]] : 0;
+        }
+    __syncthreads();
+    // D: rows that are no pivots get zeros; the panel's own pivot rows their normalised entries; older pivot rows stay as they are
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, j = idx & 63;
+        const int i = i0 + r;
+        if (i >= R || j >= w) continue;
+        const int sq = seq[i];
+        if (sq >= 0 && sq < gbase) continue;
+        int v = 0;
+        if (sq >= gbase) {
+            const int t = sq - gbase, ct = s_col[t];
+            if (j == ct) v = 1;
+            else if (j > ct) v = zp_mul(F, s_inv[t], tile[j][r]);
+        }
+        D[(i64d)i * ldc + c0 + j] = v;
+    }
+}
+
+// ---- the pivot rows of one panel on the columns [ja, jb): u_t = inv_t (D[p_t][j] - sum_{s<t} mtri[t][s] u_s); D[p_t][j] = u_t and
+// the digit planes Ut[d][j][slot0 + t].  One thread per column.
+template <int ND>
+__global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, int *__restrict__ D, i64d ldc, const PanelInfo *__restrict__ info,
+                                                signed char *__restrict__ Ut, i64d uplane, int KB, int slot0)
+{
+    __shared__ int s_m[DP_W * DP_W];
+    __shared__ int s_row[DP_W], s_inv[DP_W];
+    const int npp = info->npp;
+    for (int e = threadIdx.x; e < DP_W * DP_W; e += 64) s_m[e] = info->mtri[e];
+    s_row[threadIdx.x] = info->row[threadIdx.x];
+    s_inv[threadIdx.x] = info->inv[threadIdx.x];
+    __syncthreads();
+    const int j = ja + blockIdx.x * 64 + threadIdx.x;
+    if (j >= jb) return;
+    int u[DP_W];
+    int w0[16], w1[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) { w0[b] = 0; w1[b] = 0; }
+#pragma unroll
+    for (int t = 0; t < DP_W; t++) {
+        u[t] = 0;
+        if (t < npp) { // uniform
+            long long acc = (long long)D[(i64d)s_row[t] * ldc + j];
+#pragma unroll
+            for (int s = 0; s < t; s++) acc -= (long long)s_m[t * DP_W + s] * (long long)u[s]; // |term| < 2^30, 64 terms
+            const int v = zp_mul(F, s_inv[t], zp_reduce(F, acc));
+            u[t] = v;
+            D[(i64d)s_row[t] * ldc + j] = v;
+            int d0, d1;
+            zp_digits(F, v, d0, d1);
+            w0[t >> 2] |= (d0 & 255) << (8 * (t & 3));
+            w1[t >> 2] |= (d1 & 255) << (8 * (t & 3));
+        }
+    }
+    int4 *o0 = (int4 *)(Ut + (i64d)j * KB + slot0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) o0[q] = make_int4(w0[4 * q], w0[4 * q + 1], w0[4 * q + 2], w0[4 * q + 3]);
+    if (ND == 2) {
+        int4 *o1 = (int4 *)(Ut + uplane + (i64d)j * KB + slot0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) o1[q] = make_int4(w1[4 * q], w1[4 * q + 1], w1[4 * q + 2], w1[4 * q + 3]);
+    }
+}
+
+// ---- D[i][j] -= sum_{k < K} F[i][k0 + k] * Ut[j][k0 + k]  (mod p), j in [ja, jb).
+// rows == NULL: all rows i < R that are no pivots (seq[i] < 0); otherwise the rows rows[0 .. nrows) (entries < 0 skipped).
+// Workgroup tile 128 rows x 64 columns, 4 waves of 32 x 64 (two 32x32x32 MFMA tiles side by side); K in stages of 64 bytes
+// staged through LDS (rows of 64 bytes padded to 80: conflict-free 16-byte reads).  v_mfma_i32_32x32x32_i8: lane l holds
+// A[row l & 31][k = 16 (l >> 5) + 0..15] and B[same k][column l & 31] (both operands take the same k, so any permutation of k
+// inside the instruction cancels); C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+#define GI_LDS_STRIDE 80
+template <int ND>
+__global__ __launch_bounds__(256) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ seq,
+                                                 const int *__restrict__ rows, int nrows, const signed char *__restrict__ Fd, i64d fplane,
+                                                 const signed char *__restrict__ Ut, i64d uplane, int KB)
+{
+    __shared__ __attribute__((aligned(16))) signed char s_a[ND][128 * GI_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) signed char s_b[ND][64 * GI_LDS_STRIDE];
+    __shared__ int s_gi[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 128, j0 = ja + blockIdx.y * 64;
+    if (tid < 128) {
+        const int mi = m0 + tid;
+        int gi = -1;
+        if (rows) { if (mi < nrows) gi = rows[mi]; }
+        else if (mi < R && seq[mi] < 0) gi = mi;
+        s_gi[tid] = gi;
+    }
+    __syncthreads();
+    constexpr int NACC = ND == 1 ? 1 : 3, A1 = ND == 1 ? 0 : 1, A2 = ND == 1 ? 0 : 2, D1 = ND - 1;
+    v16i32 acc[NACC][2];
+#pragma unroll
+    for (int a = 0; a < NACC; a++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][n][r] = 0;
+    // staging assignments: A 128 rows x 4 segments of 16 bytes = 512 pieces, two per thread; B 64 x 4 = 256, one per thread
+    const int ar0 = tid >> 2, aseg = tid & 3; // rows ar0 and ar0 + 64
+    const int gia = s_gi[ar0], gib = s_gi[ar0 + 64];
+    const int bj = j0 + (tid >> 2); // (Ut is padded to a multiple of 64 columns: always in range)
+    for (int ks = 0; ks < K; ks += 64) {
+        int4 ra[ND][2], rb[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            const signed char *fp = Fd + (i64d)d * fplane + k0 + ks + aseg * 16;
+            ra[d][0] = gia >= 0 ? *(const int4 *)(fp + (i64d)gia * KB) : make_int4(0, 0, 0, 0);
+            ra[d][1] = gib >= 0 ? *(const int4 *)(fp + (i64d)gib * KB) : make_int4(0, 0, 0, 0);
+            rb[d] = *(const int4 *)(Ut + (i64d)d * uplane + (i64d)bj * KB + k0 + ks + aseg * 16);
+        }
+        __syncthreads(); // the previous stage has been consumed
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            *(int4 *)(&s_a[d][ar0 * GI_LDS_STRIDE + aseg * 16]) = ra[d][0];
+            *(int4 *)(&s_a[d][(ar0 + 64) * GI_LDS_STRIDE + aseg * 16]) = ra[d][1];
+            *(int4 *)(&s_b[d][(tid >> 2) * GI_LDS_STRIDE + aseg * 16]) = rb[d];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int ko = kk * 32 + 16 * (lane >> 5);
+            v4i32 fa[ND], fb[ND][2];
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                fa[d] = *(const v4i32 *)(&s_a[d][(wave * 32 + (lane & 31)) * GI_LDS_STRIDE + ko]);
+                fb[d][0] = *(const v4i32 *)(&s_b[d][(lane & 31) * GI_LDS_STRIDE + ko]);
+                fb[d][1] = *(const v4i32 *)(&s_b[d][(32 + (lane & 31)) * GI_LDS_STRIDE + ko]);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                acc[0][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[0][n], acc[0][n], 0, 0, 0);
+                if (ND == 2) {
+                    acc[A1][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[D1][n], acc[A1][n], 0, 0, 0);
+                    acc[A1][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[D1], fb[0][n], acc[A1][n], 0, 0, 0);
+                    acc[A2][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[D1], fb[D1][n], acc[A2][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const int col = j0 + n * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int gi = s_gi[mrow];
+            if (gi < 0 || col >= jb) continue;
+            long long v = (long long)acc[0][n][r];
+            if (ND == 2) v += (long long)acc[A1][n][r] * 256 + (long long)acc[A2][n][r] * 65536;
+            int *d = D + (i64d)gi * ldc + col;
+            *d = zp_reduce(F, (long long)*d - v);
+        }
+    }
+}

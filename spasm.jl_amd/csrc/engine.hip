@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "stream.hpp"
+#include "dense.hpp"
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 #include <vector>
@@ -1318,6 +1319,105 @@ i64 dense_max_entries()
     return std::max<i64>((i64)1 << 31, (i64)(fr / 3) / 4);
 }
 
+// The elimination proper for primes below 2^16 (dense.hpp): panels in a persistent cooperative kernel, int8 MFMA updates in two
+// levels.  Fills pivrow_of_col; returns false when the shape is outside what the panel kernel takes (the caller then uses the
+// f64 panels).
+bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F, DevBuf<int> &pivrow_of_col, hipStream_t s)
+{
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        HIPCHK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int ND = F.p <= 255 ? 1 : 2;
+    int KB = 1024;
+    if (const char *e = getenv("SPASM_AMD_DENSE_KB")) KB = std::max(64, atoi(e) / 64 * 64); // tests: several blocks on small matrices
+    // rows per workgroup of the panel kernel: a multiple of 64; resident in LDS when they fit (576 rows = 144 KB)
+    int G = num_cu;
+    int chunk = (int)((((i64)R + G - 1) / G + 63) / 64 * 64);
+    if (chunk > 65536) return false; // (64 rows per thread at most)
+    G = (int)(((i64)R + chunk - 1) / chunk);
+    const int Rp = G * chunk;
+    const bool inlds = chunk <= 576;
+    const int Cp = (int)ldc; // a multiple of 64
+    DevBuf<int> P, seq, candrow;
+    DevBuf<signed char> Fd, Ut;
+    DevBuf<PanelInfo> info;
+    DevBuf<PanelSync> sync;
+    DevBuf<DenseState> st;
+    const int npanel = KB / DP_W;
+    const i64 fplane = (i64)Rp * KB, uplane = (i64)Cp * KB;
+    P.alloc((size_t)DP_W * (size_t)Rp);
+    seq.alloc((size_t)Rp);
+    candrow.alloc((size_t)2 * G * DP_REC);
+    Fd.alloc((size_t)ND * (size_t)fplane);
+    Ut.alloc((size_t)ND * (size_t)uplane);
+    info.alloc((size_t)npanel);
+    sync.alloc(1);
+    st.alloc(1);
+    st.zero(s);
+    HIPCHK(hipMemsetAsync(seq.p, 0xff, (size_t)Rp * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(pivrow_of_col.p, 0xff, ((size_t)C + 1) * sizeof(int), s));
+    const size_t lds = inlds ? (size_t)chunk * DP_W * sizeof(int) : 0;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 576 * DP_W * (int)sizeof(int)));
+        attr_done = true;
+    }
+    auto gemm = [&](int ja, int jb, int k0, int K, const int *rows, int nrows) {
+        if (jb <= ja || K <= 0) return;
+        const dim3 grid((unsigned)cdiv(rows ? nrows : R, 128), (unsigned)cdiv(jb - ja, 64));
+        if (ND == 1) hipLaunchKernelGGL((k_gemm_i8<1>), grid, dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows, Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB);
+        else hipLaunchKernelGGL((k_gemm_i8<2>), grid, dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows, Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB);
+    };
+    auto trsm = [&](int q, int ja, int jb) {
+        if (jb <= ja) return;
+        if (ND == 1) hipLaunchKernelGGL((k_trsm_i8<1>), dim3(cdiv(jb - ja, 64)), dim3(64), 0, s, ja, jb, F, D.p, (i64d)ldc, info.p + q, Ut.p, (i64d)uplane, KB, q * DP_W);
+        else hipLaunchKernelGGL((k_trsm_i8<2>), dim3(cdiv(jb - ja, 64)), dim3(64), 0, s, ja, jb, F, D.p, (i64d)ldc, info.p + q, Ut.p, (i64d)uplane, KB, q * DP_W);
+    };
+    for (int b0 = 0; b0 < C; b0 += KB) {
+        const int b1 = std::min(b0 + KB, C);
+        HIPCHK(hipMemsetAsync(Fd.p, 0, (size_t)ND * (size_t)fplane, s));
+        HIPCHK(hipMemsetAsync(Ut.p, 0, (size_t)ND * (size_t)uplane, s));
+        int q = 0;
+        for (int c0 = b0; c0 < b1; c0 += DP_W, q++) {
+            const int c1 = std::min(c0 + DP_W, b1), w = c1 - c0;
+            hipLaunchKernelGGL(k_panel_load, dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, D.p, (i64d)ldc, P.p, sync.p);
+            {
+                int a_Rp = Rp, a_chunk = chunk, a_w = w, a_c0 = c0;
+                ZpField a_F = F;
+                int *a_P = P.p, *a_seq = seq.p, *a_pc = pivrow_of_col.p, *a_cand = candrow.p;
+                PanelInfo *a_info = info.p + q;
+                PanelSync *a_sy = sync.p;
+                DenseState *a_st = st.p;
+                void *args[] = {&a_Rp, &a_chunk, &a_w, &a_c0, &a_F, &a_P, &a_seq, &a_pc, &a_info, &a_sy, &a_cand, &a_st};
+                HIPCHK(hipLaunchCooperativeKernel(inlds ? (const void *)k_panel_lu<true, 1024> : (const void *)k_panel_lu<false, 1024>, dim3(G), dim3(1024),
+                                                  args, (unsigned)lds, s));
+            }
+            if (ND == 1) hipLaunchKernelGGL((k_panel_store<1>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
+            else hipLaunchKernelGGL((k_panel_store<2>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
+            // inside the block: the panel's pivot rows, then everybody else, K = 64
+            trsm(q, c1, b1);
+            gemm(c1, b1, q * DP_W, DP_W, nullptr, 0);
+            HIPCHK(hipGetLastError());
+        }
+        // right of the block: the pivot rows panel by panel (those of earlier panels first applied through the GEMM), then all others
+        const int npan = q;
+        for (int t = 0; t < npan; t++) {
+            if (t > 0) gemm(b1, C, 0, t * DP_W, (const int *)((const char *)(info.p + t) + offsetof(PanelInfo, row)), DP_W);
+            trsm(t, b1, C);
+        }
+        gemm(b1, C, 0, npan * DP_W, nullptr, 0);
+        HIPCHK(hipGetLastError());
+    }
+    DenseState hst;
+    HIPCHK(hipMemcpyAsync(&hst, st.p, sizeof hst, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hst.pad) throw EngineError("dense finish: a grid barrier of the panel kernel timed out (the device is shared with another process?)");
+    return true;
+}
+
 // Leftmost-pivot elimination of a dense R x C matrix D (row-major, leading dimension ldc, residues mod p) whose column c is
 // column clist[c] of the matrix and whose row r comes from row row_orig[r] of the input; the pivot rows found are appended to U.
 int dense_eliminate(DevBuf<int> &D, int R, int C, i64 ldc, const int *clist, const int *row_orig, const ZpField &F, HostU &U, hipStream_t s)
@@ -1332,7 +1432,10 @@ int dense_eliminate(DevBuf<int> &D, int R, int C, i64 ldc, const int *clist, con
     st.alloc(1);
     is_piv.zero(s); st.zero(s);
     const int rc = std::max(R, C);
-    if (F.p <= ((i64)1 << 24)) {
+    const char *force64 = getenv("SPASM_AMD_DENSE_F64"); // diagnostics: the f64 panels for every prime
+    if (F.small && !(force64 && atoi(force64)) && dense_eliminate_i8(D, R, C, ldc, F, pivrow_of_col, s)) {
+        // (done: pivrow_of_col is filled, D holds the echelon form)
+    } else if (F.p <= ((i64)1 << 24)) {
         // blocked: panels of DPB columns, f64-MFMA trailing update (exact: 64 * (p/2)^2 < 2^53)
         const i64 R64 = ((i64)R + 63) / 64 * 64, ldu = ldc;
         DevBuf<double> Lm, Upan;
@@ -1550,16 +1653,44 @@ struct DenseW {
         HIPCHK(hipGetLastError());
     }
 
-    // the Schur rows of `rows` (local rows, device list) on the slab's columns: Dp[t][dcol0 + j]
+    // the entries of the rows on pivot columns as (pivot index, value) lists
+    DevBuf<i64d> pcnt, poff;
+    DevBuf<int2> plist;
+    const int *prows = nullptr;
+    int pn = -1;
+    void row_lists(const int *rows, int nrows)
+    {
+        if (prows == rows && pn == nrows) return;
+        prows = rows; pn = nrows;
+        constexpr int TEAM = 16;
+        pcnt.alloc((size_t)nrows + 1); poff.alloc((size_t)nrows + 1);
+        hipLaunchKernelGGL((k_wd_pcount<TEAM>), dim3(cdiv(((i64)nrows + 1) * TEAM, 256)), dim3(256), 0, s, nrows, rows, cur.start.p, cur.len.p, cur.ent.p,
+                           R.qinv_r.p, pcnt.p);
+        HIPCHK(hipGetLastError());
+        scan.exclusive(pcnt.p, poff.p, (size_t)nrows + 1, s);
+        i64d tot = 0;
+        HIPCHK(hipMemcpyAsync(&tot, poff.p + nrows, sizeof tot, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        plist.alloc((size_t)tot + 1);
+        hipLaunchKernelGGL((k_wd_pfill<TEAM>), dim3(cdiv((i64)nrows * TEAM, 256)), dim3(256), 0, s, nrows, rows, cur.start.p, cur.len.p, cur.ent.p,
+                           R.qinv_r.p, poff.p, plist.p);
+        HIPCHK(hipGetLastError());
+    }
+
+    // the Schur rows of `rows` (local rows, device list) on the slab's columns: Dp[t][dcol0 + j]; Dp is zero there on entry
     void rows_into(const int *rows, int nrows, int Cs, int *Dp, i64 ldc, int dcol0)
     {
         if (nrows == 0) return;
+        row_lists(rows, nrows);
+        constexpr int TEAM = 16;
+        hipLaunchKernelGGL((k_wd_own<TEAM>), dim3(cdiv((i64)nrows * TEAM, 256)), dim3(256), 0, s, nrows, rows, cur.start.p, cur.len.p, cur.ent.p, R.qinv_r.p,
+                           cmap_s.p, Dp, (i64d)ldc, dcol0);
         const int bt = threads_for(Cs);
         const unsigned gy = (unsigned)cdiv(Cs, 4 * bt);
-        if (R.F.small) hipLaunchKernelGGL((k_wd_rows<true>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, rows, R.F, cur.start.p, cur.len.p, cur.ent.p,
-                                          R.qinv_r.p, cmap_s.p, Wd.p, (i64d)Cs, Cs, Dp, (i64d)ldc, dcol0);
-        else hipLaunchKernelGGL((k_wd_rows<false>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, rows, R.F, cur.start.p, cur.len.p, cur.ent.p,
-                                R.qinv_r.p, cmap_s.p, Wd.p, (i64d)Cs, Cs, Dp, (i64d)ldc, dcol0);
+        if (R.F.small) hipLaunchKernelGGL((k_wd_rows<true>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, Wd.p, (i64d)Cs, Cs, Dp,
+                                          (i64d)ldc, dcol0);
+        else hipLaunchKernelGGL((k_wd_rows<false>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, Wd.p, (i64d)Cs, Cs, Dp, (i64d)ldc,
+                                dcol0);
         HIPCHK(hipGetLastError());
     }
 
@@ -1581,6 +1712,7 @@ struct DenseW {
         DevBuf<int> Dsm;
         DevBuf<u64d> cnt;
         Dsm.alloc((size_t)nrows * Cs);
+        Dsm.zero(s);
         cnt.alloc(1);
         cnt.zero(s);
         rows_into(rows, nrows, Cs, Dsm.p, Cs, 0);
@@ -1610,6 +1742,7 @@ void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStrea
     const i64 ldc = ((i64)C + 63) / 64 * 64;
     DevBuf<int> D, row_orig;
     D.alloc((size_t)nnp * (size_t)ldc);
+    D.zero(s);
     row_orig.alloc((size_t)nnp + 1);
     hipLaunchKernelGGL(k_gather_int, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, R.np_rows.p, cur.orig.p, row_orig.p);
     HIPCHK(hipGetLastError());

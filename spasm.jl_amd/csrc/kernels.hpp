@@ -2309,32 +2309,86 @@ __global__ __launch_bounds__(256) void k_wd_level(int nrows, const int *__restri
     (void)nrows;
 }
 
-// dense Schur rows: D[t][dcol0 + j] = own entry on that column + sum a * W[q(col)][j].  blockIdx.x = row slot t (rows[t] = local row)
+// The entries of the non-pivot rows on pivot columns, as (pivot index, value) lists (once per round: every slab of columns and the
+// density estimate go along them), and the scatter of the other entries into the dense rows.
+template <int TEAM>
+__global__ void k_wd_pcount(int nrows, const int *__restrict__ rows, const i64d *__restrict__ start, const int *__restrict__ len,
+                            const int2 *__restrict__ ent, const int *__restrict__ qinv_r, i64d *__restrict__ cnt)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int t = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (t > nrows) return;
+    int c = 0;
+    if (t < nrows) {
+        const int row = rows ? rows[t] : t;
+        const i64d st = start[row];
+        const int ln = len[row];
+        for (int k = tl; k < ln; k += TEAM) c += qinv_r[ent[st + k].x] >= 0;
+        for (int o = TEAM / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, TEAM);
+    }
+    if (tl == 0) cnt[t] = c;
+}
+
+template <int TEAM>
+__global__ void k_wd_pfill(int nrows, const int *__restrict__ rows, const i64d *__restrict__ start, const int *__restrict__ len,
+                           const int2 *__restrict__ ent, const int *__restrict__ qinv_r, const i64d *__restrict__ off, int2 *__restrict__ plist)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int t = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (t >= nrows) return;
+    const int row = rows ? rows[t] : t;
+    const i64d st = start[row];
+    const int ln = len[row];
+    i64d pos = off[t];
+    const u64d below = (1ull << tl) - 1ull;
+    for (int k0 = 0; k0 < ln; k0 += TEAM) {
+        const int k = k0 + tl;
+        int2 e = make_int2(0, 0);
+        int q = -1;
+        if (k < ln) { e = ent[st + k]; q = qinv_r[e.x]; }
+        const u64d m = team_ballot<TEAM>(q >= 0);
+        if (q >= 0) plist[pos + __popcll(m & below)] = make_int2(q, e.y);
+        pos += __popcll(m);
+    }
+}
+
+// D[t][dcol0 + cmap_s[col]] = value for the entries on columns of the slab (D zero before; the columns of a row are distinct)
+template <int TEAM>
+__global__ void k_wd_own(int nrows, const int *__restrict__ rows, const i64d *__restrict__ start, const int *__restrict__ len,
+                         const int2 *__restrict__ ent, const int *__restrict__ qinv_r, const int *__restrict__ cmap_s, int *__restrict__ D, i64d ldc,
+                         int dcol0)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int t = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (t >= nrows) return;
+    const int row = rows ? rows[t] : t;
+    const i64d st = start[row];
+    const int ln = len[row];
+    for (int k = tl; k < ln; k += TEAM) {
+        const int2 e = ent[st + k];
+        if (qinv_r[e.x] >= 0) continue;
+        const int j = cmap_s[e.x];
+        if (j >= 0) D[(i64d)t * ldc + dcol0 + j] = e.y;
+    }
+}
+
+// dense Schur rows: D[t][dcol0 + j] += sum a * W[q][j] over the row's list (q, a).  blockIdx.x = row slot t
 template <bool SMALL>
-__global__ __launch_bounds__(256) void k_wd_rows(int nrows, const int *__restrict__ rows, ZpField F, const i64d *__restrict__ start,
-                                                 const int *__restrict__ len, const int2 *__restrict__ ent, const int *__restrict__ qinv_r,
-                                                 const int *__restrict__ cmap_s, const int *__restrict__ Wd, i64d ldw, int Cs, int *__restrict__ D, i64d ldc,
-                                                 int dcol0)
+__global__ __launch_bounds__(256) void k_wd_rows(int nrows, ZpField F, const i64d *__restrict__ poff, const int2 *__restrict__ plist,
+                                                 const int *__restrict__ Wd, i64d ldw, int Cs, int *__restrict__ D, i64d ldc, int dcol0)
 {
     const int t = blockIdx.x;
     const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
     if (j >= Cs) return;
-    const int row = rows ? rows[t] : t;
-    const i64d st = start[row];
-    const int ln = len[row];
+    const i64d lo = poff[t], hi = poff[t + 1];
+    if (lo == hi) return; // (the own entries are there already)
     DenseAcc<SMALL> acc;
-    v4i32 own = (v4i32){0, 0, 0, 0};
-    for (int k = 0; k < ln; k++) {
-        const int2 e = ent[st + k]; // (uniform over the workgroup)
-        const int q = qinv_r[e.x];
-        if (q >= 0) {
-            acc.fma(F, e.y, *(const v4i32 *)(Wd + (i64d)q * ldw + j));
-        } else {
-            const int jj = cmap_s[e.x] - j;
-            if (jj == 0) own.x = e.y; else if (jj == 1) own.y = e.y; else if (jj == 2) own.z = e.y; else if (jj == 3) own.w = e.y;
-        }
+    for (i64d k = lo; k < hi; k++) {
+        const int2 e = plist[k]; // (uniform over the workgroup)
+        acc.fma(F, e.y, *(const v4i32 *)(Wd + (i64d)e.x * ldw + j));
     }
-    *(v4i32 *)(D + (i64d)t * ldc + dcol0 + j) = acc.finish(F, own);
+    v4i32 *dst = (v4i32 *)(D + (i64d)t * ldc + dcol0 + j);
+    *dst = acc.finish(F, *dst);
     (void)nrows;
 }
 
