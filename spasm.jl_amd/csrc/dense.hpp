@@ -21,6 +21,7 @@
 #include "kernels.hpp"
 
 #define DP_W 64            // columns of a panel
+#define DP_REC 80          // ints of a candidate record: the row (64), the inverse of its leading entry, the bid (row index)
 #define DP_NONE 0x7fffffff
 
 typedef int v16i32 __attribute__((ext_vector_type(16)));
@@ -35,11 +36,11 @@ struct PanelInfo {          // one per panel of the current block; written by k_
     int mtri[DP_W * DP_W];  // mtri[t * 64 + s] = multiplier of pivot row t at pivot s < t (0 elsewhere)
 };
 
+#define DP_NCTR 64           // arrival counters of the grid barrier (workgroup b adds to counter b % 64), 128 bytes apart
 struct PanelSync {          // reset by k_panel_load before every k_panel_lu launch
-    unsigned arrive;        // grid-barrier counter
+    unsigned arrive[DP_NCTR * 32];
     unsigned timeout;       // set when a bounded spin gave up (the launch is then reported as failed)
-    unsigned pad[2];
-    int cand[DP_W];         // per column: lowest candidate row (atomicMin), DP_NONE when there is none
+    unsigned pad[3];
 };
 
 // ---- P[j][i] = D[i][c0 + j] (j < w; 0 beyond), i < R; rows R .. Rp-1 are zero
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w
     __shared__ int tile[DP_W][DP_W + 1];
     const int i0 = blockIdx.x * 64;
     if (blockIdx.x == 0) { // the words the panel kernel polls, reset in stream order before it
-        if (threadIdx.x < DP_W) sy->cand[threadIdx.x] = DP_NONE;
-        if (threadIdx.x == 0) { sy->arrive = 0; sy->timeout = 0; }
+        if (threadIdx.x < DP_NCTR) sy->arrive[threadIdx.x * 32] = 0;
+        if (threadIdx.x == 0) sy->timeout = 0;
     }
     for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, j = idx & 63;
@@ -67,29 +68,51 @@ __global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w
 // everything one workgroup hands to another in k_panel_lu is written with agent-scope atomic stores (write-through) and read with
 // agent-scope atomic loads (guide, guideline 16, forms R1 / R2); every storing wave drains its stores before the workgroup's barrier,
 // one lane then arrives and polls.  A fence pair (release: L2 write-back, acquire: invalidate) cost ~30 us per column instead.
-__device__ __forceinline__ bool panel_grid_barrier(PanelSync *sy, unsigned epoch, unsigned nblocks)
+// Every workgroup's arrival used to be an atomic add on ONE word, and its bid an atomicMin on another: 2 x 256 read-modify-writes
+// on two addresses serialise at the memory side, 7-9 us per column.  Now: 64 arrival counters (at most 4 adds each), polled by
+// the 64 lanes of wave 0 with one load per poll; the bids are plain write-through stores next to the candidate rows
+// (record word DP_W + 1), read once after the barrier, four per lane, and reduced in the wave.
+// Returns the winning bid (DP_NONE: no pivot in the column), or -1 when a spin timed out.  The bids are read AFTER the full
+// counts have been seen (dependent, later loads): a workgroup's record is complete before its arrival (vmcnt(0), barrier, then
+// the add), so they are final then.  (Loading bids and counters in one poll is WRONG: the loads can be served out of order,
+// workgroups then disagree on the winner.)
+__device__ __forceinline__ int panel_grid_barrier(PanelSync *sy, unsigned epoch, unsigned nblocks, const int *recs)
 {
-    __shared__ int s_ok;
+    __shared__ int s_win;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&sy->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = epoch * nblocks;
-        int ok = 1;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_fetch_add(&sy->arrive[(blockIdx.x % DP_NCTR) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // counter `lane` takes the workgroups lane, lane + 64, ...
+        const unsigned mine = lane < (int)nblocks ? (nblocks - lane + DP_NCTR - 1) / DP_NCTR : 0;
+        const unsigned target = epoch * mine;
+        int win = -1;
         unsigned spins = 0;
-        while (__hip_atomic_load(&sy->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
+        for (;;) {
+            const unsigned a = mine ? __hip_atomic_load(&sy->arrive[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__all(a >= target)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int best = DP_NONE;
+                for (unsigned b = lane; b < nblocks; b += 64)
+                    best = min(best, __hip_atomic_load(&recs[(size_t)b * DP_REC + DP_W + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                win = wave_min_i32(best);
+                break;
+            }
             if (++spins > (1u << 24) || __hip_atomic_load(&sy->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // (~ seconds)
                 __hip_atomic_store(&sy->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
                 break;
             }
         }
-        s_ok = ok;
+        if (lane == 0) s_win = win;
     }
     __syncthreads();
-    return s_ok != 0;
+    return s_win;
 }
+
+// inverses of all residues of a prime < 2^16 (one table per dense elimination): invtab[a], 0 < a < p
+__device__ __forceinline__ int zp_inverse_small(int p, int a);
+__global__ void k_inv_table(int p, int *__restrict__ invtab);
 
 // a^-1 mod p for p < 2^16 in 32-bit arithmetic (the f64 / i64 Euclid of zp_inverse costs ~10 us on one lane, once per column of a
 // panel, on the critical path of every workgroup); a is a non-zero balanced residue
@@ -107,6 +130,12 @@ __device__ __forceinline__ int zp_inverse_small(int p, int a)
     return r > p / 2 ? r - p : r;
 }
 
+__global__ void k_inv_table(int p, int *__restrict__ invtab)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < p) invtab[a] = a ? zp_inverse_small(p, a) : 0;
+}
+
 // x + a * b for balanced residues of a prime < 2^16, result balanced: one lazy reduction and a correction either way
 __device__ __forceinline__ int zp_axpy_small(const ZpField &F, int a, int b, int x)
 {
@@ -119,15 +148,15 @@ __device__ __forceinline__ int zp_axpy_small(const ZpField &F, int a, int b, int
 // ---- the panel, one cooperative launch of NT-thread workgroups.  Workgroup b owns rows [b * chunk, (b + 1) * chunk) of P; with
 // INLDS they live in LDS as X[j * chunk + r] for the whole launch (chunk * 256 bytes), otherwise the kernel works on P in place
 // (L2 / MALL resident; only the owner of a row ever reads or writes it).  seq[i] = sequence number of the pivot row i became,
-// -1 while it is none.  candrow: 2 x gridDim.x records of 64 + 1 ints (the candidate row, then the inverse of its entry in
-// the current column).
-#define DP_REC 80
+// -1 while it is none.  candrow: 2 x gridDim.x records of DP_REC ints (the candidate row, the inverse of its entry in the current
+// column, the bid).
 template <bool INLDS, int NT>
 __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c0, ZpField F, int *__restrict__ P, int *__restrict__ seq,
                                                  int *__restrict__ pivrow_of_col, PanelInfo *__restrict__ info, PanelSync *sy, int *candrow,
-                                                 DenseState *st)
+                                                 DenseState *st, const int *__restrict__ invtab, unsigned long long *stamps)
 {
     extern __shared__ __attribute__((aligned(16))) int s_x[]; // INLDS: chunk * 64 ints
+#define PSTAMP(k) do { if (stamps && blockIdx.x == 0 && tid == 0) stamps[c * 8 + (k)] = wall_clock64(); } while (0)
     __shared__ int s_prow[DP_W];
     __shared__ int s_cand;
     const int tid = threadIdx.x;
@@ -149,6 +178,7 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
     bool alive = true;
     for (int c = 0; c < w && alive; c++) {
         // ---- election: my first live row with a non-zero in column c
+        PSTAMP(0);
         if (tid == 0) s_cand = DP_NONE;
         __syncthreads();
         int mine = DP_NONE;
@@ -164,18 +194,23 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
         if ((tid & 63) == 0 && mine != DP_NONE) atomicMin(&s_cand, mine);
         __syncthreads();
         const int wg_cand = s_cand;
+        PSTAMP(1);
         int *rec = candrow + (size_t)((c & 1) * gridDim.x + blockIdx.x) * DP_REC;
+        if (tid == 2 * DP_W) __hip_atomic_store(&rec[DP_W + 1], wg_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the bid, always
         if (wg_cand != DP_NONE) {
             // the candidate's row (unscaled) and the inverse of its leading entry where every workgroup can read them, then the bid
             // (two sets of records, by column parity: a workgroup may bid for column c + 1 while another still reads column c's)
             if (tid < DP_W) __hip_atomic_store(&rec[tid], X[(i64d)tid * xs + (wg_cand - base)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == DP_W) __hip_atomic_store(&rec[DP_W], zp_inverse_small((int)F.p, X[(i64d)c * xs + (wg_cand - base)]), __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 2 * DP_W) __hip_atomic_fetch_min(&sy->cand[c], wg_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == DP_W) {
+                const int lead = X[(i64d)c * xs + (wg_cand - base)];
+                __hip_atomic_store(&rec[DP_W], invtab[lead < 0 ? lead + (int)F.p : lead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        alive = panel_grid_barrier(sy, (unsigned)c + 1, gridDim.x);
-        const int p = __hip_atomic_load(&sy->cand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p == DP_NONE || !alive) continue; // no pivot in this column
+        PSTAMP(2);
+        const int p = panel_grid_barrier(sy, (unsigned)c + 1, gridDim.x, candrow + (size_t)((c & 1) * gridDim.x) * DP_REC);
+        PSTAMP(3);
+        if (p < 0) { alive = false; continue; }
+        if (p == DP_NONE) continue; // no pivot in this column
         const int owner = p / chunk;
         int *orec = candrow + (size_t)((c & 1) * gridDim.x + owner) * DP_REC;
         const int inv = __hip_atomic_load(&orec[DP_W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -184,6 +219,7 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
             s_prow[tid] = tid > c && tid < w ? zp_axpy_small(F, inv, raw, 0) : 0;
         }
         __syncthreads();
+        PSTAMP(4);
         // ---- elimination of my live rows; the multiplier stays in column c
         {
             unsigned long long m = live;
@@ -210,6 +246,7 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
         }
         npp++;
         __syncthreads(); // s_prow is rewritten by the next column
+        PSTAMP(5);
     }
     if (INLDS) {
         __syncthreads();
@@ -347,7 +384,7 @@ __global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, int *
 // inside the instruction cancels); C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 #define GI_LDS_STRIDE 80
 template <int ND>
-__global__ __launch_bounds__(256) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ seq,
+__global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ seq,
                                                  const int *__restrict__ rows, int nrows, const signed char *__restrict__ Fd, i64d fplane,
                                                  const signed char *__restrict__ Ut, i64d uplane, int KB)
 {

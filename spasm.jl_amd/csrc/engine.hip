@@ -1341,7 +1341,7 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
     const int Rp = G * chunk;
     const bool inlds = chunk <= 576;
     const int Cp = (int)ldc; // a multiple of 64
-    DevBuf<int> P, seq, candrow;
+    DevBuf<int> P, seq, candrow, invtab;
     DevBuf<signed char> Fd, Ut;
     DevBuf<PanelInfo> info;
     DevBuf<PanelSync> sync;
@@ -1357,6 +1357,11 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
     sync.alloc(1);
     st.alloc(1);
     st.zero(s);
+    DevBuf<unsigned long long> stamps; // diagnostics: phase times of the panel kernel's columns (workgroup 0), 100 MHz ticks
+    if (const char *e = getenv("SPASM_AMD_PANEL_STAMPS")) if (atoi(e)) { stamps.alloc(DP_W * 8); stamps.zero(s); }
+    invtab.alloc((size_t)F.p);
+    hipLaunchKernelGGL(k_inv_table, dim3(cdiv(F.p, 256)), dim3(256), 0, s, (int)F.p, invtab.p);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(seq.p, 0xff, (size_t)Rp * sizeof(int), s));
     HIPCHK(hipMemsetAsync(pivrow_of_col.p, 0xff, ((size_t)C + 1) * sizeof(int), s));
     const size_t lds = inlds ? (size_t)chunk * DP_W * sizeof(int) : 0;
@@ -1391,7 +1396,9 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
                 PanelInfo *a_info = info.p + q;
                 PanelSync *a_sy = sync.p;
                 DenseState *a_st = st.p;
-                void *args[] = {&a_Rp, &a_chunk, &a_w, &a_c0, &a_F, &a_P, &a_seq, &a_pc, &a_info, &a_sy, &a_cand, &a_st};
+                const int *a_inv = invtab.p;
+                unsigned long long *a_stamps = stamps.p;
+                void *args[] = {&a_Rp, &a_chunk, &a_w, &a_c0, &a_F, &a_P, &a_seq, &a_pc, &a_info, &a_sy, &a_cand, &a_st, &a_inv, &a_stamps};
                 HIPCHK(hipLaunchCooperativeKernel(inlds ? (const void *)k_panel_lu<true, 1024> : (const void *)k_panel_lu<false, 1024>, dim3(G), dim3(1024),
                                                   args, (unsigned)lds, s));
             }
@@ -1415,6 +1422,20 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
     HIPCHK(hipMemcpyAsync(&hst, st.p, sizeof hst, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hst.pad) throw EngineError("dense finish: a grid barrier of the panel kernel timed out (the device is shared with another process?)");
+    if (stamps.p) {
+        std::vector<unsigned long long> h(DP_W * 8);
+        HIPCHK(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        int n = 0;
+        for (int c = 0; c + 1 < DP_W; c++) {
+            if (!h[(size_t)c * 8 + 5] || !h[(size_t)(c + 1) * 8]) continue;
+            for (int k = 0; k < 5; k++) acc[k] += (double)(h[(size_t)c * 8 + k + 1] - h[(size_t)c * 8 + k]);
+            acc[5] += (double)(h[(size_t)(c + 1) * 8] - h[(size_t)c * 8 + 5]);
+            n++;
+        }
+        if (n) fprintf(stderr, "[panel stamps] last panel, %d columns, us per column: scan %.2f  record %.2f  barrier %.2f  pivot row %.2f  eliminate %.2f  loop %.2f\n", n,
+                       acc[0] / n / 100, acc[1] / n / 100, acc[2] / n / 100, acc[3] / n / 100, acc[4] / n / 100, acc[5] / n / 100);
+    }
     return true;
 }
 
