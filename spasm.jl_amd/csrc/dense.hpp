@@ -150,22 +150,25 @@ __device__ __forceinline__ int zp_axpy_small(const ZpField &F, int a, int b, int
 // (L2 / MALL resident; only the owner of a row ever reads or writes it).  seq[i] = sequence number of the pivot row i became,
 // -1 while it is none.  candrow: 2 x gridDim.x records of DP_REC ints (the candidate row, the inverse of its entry in the current
 // column, the bid).
-template <bool INLDS, int NT>
+// XT: how a residue is kept in LDS -- signed char for p < 2^8, short for p < 2^16 (balanced residues fit), so that 2304 / 1152 rows
+// per workgroup stay resident instead of 576; int for the in-place (global memory) variant.
+template <bool INLDS, int NT, typename XT>
 __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c0, ZpField F, int *__restrict__ P, int *__restrict__ seq,
                                                  int *__restrict__ pivrow_of_col, PanelInfo *__restrict__ info, PanelSync *sy, int *candrow,
                                                  DenseState *st, const int *__restrict__ invtab, unsigned long long *stamps)
 {
-    extern __shared__ __attribute__((aligned(16))) int s_x[]; // INLDS: chunk * 64 ints
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dynx[]; // INLDS: chunk * 64 residues
+    XT *s_x = (XT *)s_dynx;
 #define PSTAMP(k) do { if (stamps && blockIdx.x == 0 && tid == 0) stamps[c * 8 + (k)] = wall_clock64(); } while (0)
     __shared__ int s_prow[DP_W];
     __shared__ int s_cand;
     const int tid = threadIdx.x;
     const int base = blockIdx.x * chunk;
     const i64d xs = INLDS ? (i64d)chunk : (i64d)Rp; // stride between the columns of the row storage
-    int *X = INLDS ? s_x : P + base;
+    XT *X = INLDS ? s_x : (XT *)(P + base); // (XT = int when !INLDS)
     if (INLDS) {
         for (int j = 0; j < DP_W; j++)
-            for (int r = tid; r < chunk; r += NT) s_x[j * chunk + r] = P[(i64d)j * Rp + base + r];
+            for (int r = tid; r < chunk; r += NT) s_x[j * chunk + r] = (XT)P[(i64d)j * Rp + base + r];
     }
     // the status of the rows this thread owns (r = tid + NT k): bit k set = not a pivot (yet)
     unsigned long long live = 0;
@@ -200,9 +203,9 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
         if (wg_cand != DP_NONE) {
             // the candidate's row (unscaled) and the inverse of its leading entry where every workgroup can read them, then the bid
             // (two sets of records, by column parity: a workgroup may bid for column c + 1 while another still reads column c's)
-            if (tid < DP_W) __hip_atomic_store(&rec[tid], X[(i64d)tid * xs + (wg_cand - base)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < DP_W) __hip_atomic_store(&rec[tid], (int)X[(i64d)tid * xs + (wg_cand - base)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid == DP_W) {
-                const int lead = X[(i64d)c * xs + (wg_cand - base)];
+                const int lead = (int)X[(i64d)c * xs + (wg_cand - base)];
                 __hip_atomic_store(&rec[DP_W], invtab[lead < 0 ? lead + (int)F.p : lead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -228,12 +231,12 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
                 m &= m - 1;
                 const int r = tid + NT * k;
                 if (base + r == p) { live &= ~(1ull << k); continue; } // the new pivot row: frozen from here on
-                const int f = X[(i64d)c * xs + r];
+                const int f = (int)X[(i64d)c * xs + r];
                 if (f == 0) continue;
                 const int nf = -f;
                 for (int j = c + 1; j < w; j++) {
-                    int *x = &X[(i64d)j * xs + r];
-                    *x = zp_axpy_small(F, nf, s_prow[j], *x);
+                    XT *x = &X[(i64d)j * xs + r];
+                    *x = (XT)zp_axpy_small(F, nf, s_prow[j], (int)*x);
                 }
             }
         }
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
     if (INLDS) {
         __syncthreads();
         for (int j = 0; j < DP_W; j++)
-            for (int r = tid; r < chunk; r += NT) P[(i64d)j * Rp + base + r] = s_x[j * chunk + r];
+            for (int r = tid; r < chunk; r += NT) P[(i64d)j * Rp + base + r] = (int)s_x[j * chunk + r];
     }
     if (blockIdx.x == 0 && tid == 0) {
         info->npp = npp;
@@ -378,22 +381,43 @@ __global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, int *
 
 // ---- D[i][j] -= sum_{k < K} F[i][k0 + k] * Ut[j][k0 + k]  (mod p), j in [ja, jb).
 // rows == NULL: all rows i < R that are no pivots (seq[i] < 0); otherwise the rows rows[0 .. nrows) (entries < 0 skipped).
-// Workgroup tile 128 rows x 64 columns, 4 waves of 32 x 64 (two 32x32x32 MFMA tiles side by side); K in stages of 64 bytes
-// staged through LDS (rows of 64 bytes padded to 80: conflict-free 16-byte reads).  v_mfma_i32_32x32x32_i8: lane l holds
-// A[row l & 31][k = 16 (l >> 5) + 0..15] and B[same k][column l & 31] (both operands take the same k, so any permutation of k
-// inside the instruction cancels); C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+// Four waves as WM x WN, each with TM x TN tiles of 32 x 32 (v_mfma_i32_32x32x32_i8): the workgroup covers BM = 32 WM TM rows
+// and BN = 32 WN TN columns.  One digit: 2 x 2 waves of 2 x 2 tiles, 128 x 128 (a fragment read from LDS feeds two MFMAs);
+// two digits (three accumulators per tile): 4 x 1 waves of 1 x 2 tiles, 128 x 64.  K in stages of 64 bytes staged through LDS
+// (rows of 64 bytes padded to 80: conflict-free 16-byte reads).  Lane l holds A[row l & 31][k = 16 (l >> 5) + 0..15] and
+// B[same k][column l & 31] (both operands take the same k, so any permutation of k inside the instruction cancels);
+// C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 #define GI_LDS_STRIDE 80
-template <int ND>
+#define GI_BAND 32
+template <int ND, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ seq,
-                                                 const int *__restrict__ rows, int nrows, const signed char *__restrict__ Fd, i64d fplane,
-                                                 const signed char *__restrict__ Ut, i64d uplane, int KB)
+                                                    const int *__restrict__ rows, int nrows, const signed char *__restrict__ Fd, i64d fplane,
+                                                    const signed char *__restrict__ Ut, i64d uplane, int KB, int ntm, int ntn)
 {
-    __shared__ __attribute__((aligned(16))) signed char s_a[ND][128 * GI_LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) signed char s_b[ND][64 * GI_LDS_STRIDE];
-    __shared__ int s_gi[128];
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int APT = BM * 4 / 256, BPT = BN * 4 / 256; // 16-byte pieces per thread and stage
+    static_assert(APT >= 1 && BPT >= 1 && BM * 4 % 256 == 0 && BN * 4 % 256 == 0, "tile vs staging");
+    __shared__ __attribute__((aligned(16))) signed char s_a[ND][BM * GI_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) signed char s_b[ND][BN * GI_LDS_STRIDE];
+    __shared__ int s_gi[BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 128, j0 = ja + blockIdx.y * 64;
-    if (tid < 128) {
+    const int wm = wave / WN, wn = wave % WN;
+    // Tile order (1-D grid of ntm x ntn tiles): bands of GI_BAND row tiles; inside a band the column tiles one after the other, each
+    // with the band's row tiles.  The workgroups in flight then share the band's rows of F (4096 x K bytes: L2 / MALL) and a few
+    // column tiles of Ut; row tiles fastest over the whole grid re-read all of F from HBM once per column tile (85 GB per update
+    // of the 333k x 32k tail of config 5 at 1/10).
+    int tm, tn;
+    {
+        const int per_band = GI_BAND * ntn;
+        const int band = blockIdx.x / per_band, within = blockIdx.x % per_band;
+        const int rows_in_band = min(GI_BAND, ntm - band * GI_BAND);
+        tn = within / rows_in_band;
+        tm = band * GI_BAND + within % rows_in_band;
+        if (tn >= ntn) return; // (cannot happen for full bands; the last band is launched with its own count)
+    }
+    const int m0 = tm * BM, j0 = ja + tn * BN;
+    if (tid < BM) {
         const int mi = m0 + tid;
         int gi = -1;
         if (rows) { if (mi < nrows) gi = rows[mi]; }
@@ -402,67 +426,90 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k
     }
     __syncthreads();
     constexpr int NACC = ND == 1 ? 1 : 3, A1 = ND == 1 ? 0 : 1, A2 = ND == 1 ? 0 : 2, D1 = ND - 1;
-    v16i32 acc[NACC][2];
+    v16i32 acc[NACC][TM][TN];
 #pragma unroll
     for (int a = 0; a < NACC; a++)
 #pragma unroll
-        for (int n = 0; n < 2; n++)
+        for (int m = 0; m < TM; m++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][n][r] = 0;
-    // staging assignments: A 128 rows x 4 segments of 16 bytes = 512 pieces, two per thread; B 64 x 4 = 256, one per thread
-    const int ar0 = tid >> 2, aseg = tid & 3; // rows ar0 and ar0 + 64
-    const int gia = s_gi[ar0], gib = s_gi[ar0 + 64];
-    const int bj = j0 + (tid >> 2); // (Ut is padded to a multiple of 64 columns: always in range)
-    for (int ks = 0; ks < K; ks += 64) {
-        int4 ra[ND][2], rb[ND];
+            for (int n = 0; n < TN; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][m][n][r] = 0;
+    // staging: piece x (0 .. BM * 4) = row x / 4, 16-byte segment x % 4; thread tid takes pieces tid, tid + 256, ...
+    const int seg = tid & 3, prow = tid >> 2;
+    int gia[APT];
+#pragma unroll
+    for (int u = 0; u < APT; u++) gia[u] = s_gi[prow + 64 * u];
+    // software pipeline: the global loads of stage s + 1 are in flight while stage s is multiplied out of LDS
+    int4 ra[ND][APT], rb[ND][BPT];
+    auto fetch = [&](int ks) {
 #pragma unroll
         for (int d = 0; d < ND; d++) {
-            const signed char *fp = Fd + (i64d)d * fplane + k0 + ks + aseg * 16;
-            ra[d][0] = gia >= 0 ? *(const int4 *)(fp + (i64d)gia * KB) : make_int4(0, 0, 0, 0);
-            ra[d][1] = gib >= 0 ? *(const int4 *)(fp + (i64d)gib * KB) : make_int4(0, 0, 0, 0);
-            rb[d] = *(const int4 *)(Ut + (i64d)d * uplane + (i64d)bj * KB + k0 + ks + aseg * 16);
+            const signed char *fp = Fd + (i64d)d * fplane + k0 + ks + seg * 16;
+#pragma unroll
+            for (int u = 0; u < APT; u++) ra[d][u] = gia[u] >= 0 ? *(const int4 *)(fp + (i64d)gia[u] * KB) : make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < BPT; u++) // (Ut is padded by 128 columns: always in range)
+                rb[d][u] = *(const int4 *)(Ut + (i64d)d * uplane + (i64d)(j0 + prow + 64 * u) * KB + k0 + ks + seg * 16);
         }
+    };
+    fetch(0);
+    for (int ks = 0; ks < K; ks += 64) {
         __syncthreads(); // the previous stage has been consumed
 #pragma unroll
         for (int d = 0; d < ND; d++) {
-            *(int4 *)(&s_a[d][ar0 * GI_LDS_STRIDE + aseg * 16]) = ra[d][0];
-            *(int4 *)(&s_a[d][(ar0 + 64) * GI_LDS_STRIDE + aseg * 16]) = ra[d][1];
-            *(int4 *)(&s_b[d][(tid >> 2) * GI_LDS_STRIDE + aseg * 16]) = rb[d];
+#pragma unroll
+            for (int u = 0; u < APT; u++) *(int4 *)(&s_a[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = ra[d][u];
+#pragma unroll
+            for (int u = 0; u < BPT; u++) *(int4 *)(&s_b[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = rb[d][u];
         }
         __syncthreads();
+        if (ks + 64 < K) fetch(ks + 64);
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             const int ko = kk * 32 + 16 * (lane >> 5);
-            v4i32 fa[ND], fb[ND][2];
+            v4i32 fa[ND][TM], fb[ND][TN];
 #pragma unroll
             for (int d = 0; d < ND; d++) {
-                fa[d] = *(const v4i32 *)(&s_a[d][(wave * 32 + (lane & 31)) * GI_LDS_STRIDE + ko]);
-                fb[d][0] = *(const v4i32 *)(&s_b[d][(lane & 31) * GI_LDS_STRIDE + ko]);
-                fb[d][1] = *(const v4i32 *)(&s_b[d][(32 + (lane & 31)) * GI_LDS_STRIDE + ko]);
+#pragma unroll
+                for (int m = 0; m < TM; m++) fa[d][m] = *(const v4i32 *)(&s_a[d][((wm * TM + m) * 32 + (lane & 31)) * GI_LDS_STRIDE + ko]);
+#pragma unroll
+                for (int n = 0; n < TN; n++) fb[d][n] = *(const v4i32 *)(&s_b[d][((wn * TN + n) * 32 + (lane & 31)) * GI_LDS_STRIDE + ko]);
             }
 #pragma unroll
-            for (int n = 0; n < 2; n++) {
-                acc[0][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[0][n], acc[0][n], 0, 0, 0);
-                if (ND == 2) {
-                    acc[A1][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[D1][n], acc[A1][n], 0, 0, 0);
-                    acc[A1][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[D1], fb[0][n], acc[A1][n], 0, 0, 0);
-                    acc[A2][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[D1], fb[D1][n], acc[A2][n], 0, 0, 0);
+            for (int m = 0; m < TM; m++)
+#pragma unroll
+                for (int n = 0; n < TN; n++) {
+                    acc[0][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0][m], fb[0][n], acc[0][m][n], 0, 0, 0);
+                    if (ND == 2) {
+                        acc[A1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0][m], fb[D1][n], acc[A1][m][n], 0, 0, 0);
+                        acc[A1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[D1][m], fb[0][n], acc[A1][m][n], 0, 0, 0);
+                        acc[A2][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[D1][m], fb[D1][n], acc[A2][m][n], 0, 0, 0);
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < TM; m++)
+#pragma unroll
+        for (int n = 0; n < TN; n++) {
+            const int col = j0 + (wn * TN + n) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mrow = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int gi = s_gi[mrow];
+                if (gi < 0 || col >= jb) continue;
+                int *d = D + (i64d)gi * ldc + col;
+                if (ND == 1) {
+                    // |acc| <= K * 127^2 < 2^25 for K <= 2048: 32-bit lazy reduction (|x / p| < 2^22) and one correction
+                    int x = zp_small_lazy(*d - acc[0][m][n][r], -F.finvp, (int)F.p);
+                    if (x > (int)F.halfp) x -= (int)F.p;
+                    else if (x < (int)F.mhalfp) x += (int)F.p;
+                    *d = x;
+                } else {
+                    const long long v = (long long)acc[0][m][n][r] + (long long)acc[A1][m][n][r] * 256 + (long long)acc[A2][m][n][r] * 65536;
+                    *d = zp_reduce(F, (long long)*d - v);
                 }
             }
         }
-    }
-#pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int col = j0 + n * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int gi = s_gi[mrow];
-            if (gi < 0 || col >= jb) continue;
-            long long v = (long long)acc[0][n][r];
-            if (ND == 2) v += (long long)acc[A1][n][r] * 256 + (long long)acc[A2][n][r] * 65536;
-            int *d = D + (i64d)gi * ldc + col;
-            *d = zp_reduce(F, (long long)*d - v);
-        }
-    }
 }

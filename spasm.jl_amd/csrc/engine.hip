@@ -1332,15 +1332,18 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
     }
     const int ND = F.p <= 255 ? 1 : 2;
     int KB = 1024;
-    if (const char *e = getenv("SPASM_AMD_DENSE_KB")) KB = std::max(64, atoi(e) / 64 * 64); // tests: several blocks on small matrices
-    // rows per workgroup of the panel kernel: a multiple of 64; resident in LDS when they fit (576 rows = 144 KB)
+    if (const char *e = getenv("SPASM_AMD_DENSE_KB")) KB = std::min(2048, std::max(64, atoi(e) / 64 * 64)); // tests: several blocks on small matrices
+    // rows per workgroup of the panel kernel: a multiple of 64; resident in LDS when they fit (144 KB: 2304 rows of bytes for
+    // p < 2^8, 1152 rows of shorts otherwise)
     int G = num_cu;
     int chunk = (int)((((i64)R + G - 1) / G + 63) / 64 * 64);
     if (chunk > 65536) return false; // (64 rows per thread at most)
     G = (int)(((i64)R + chunk - 1) / chunk);
     const int Rp = G * chunk;
-    const bool inlds = chunk <= 576;
-    const int Cp = (int)ldc; // a multiple of 64
+    const int xbytes = ND == 1 ? 1 : 2;
+    const int lds_rows = 147456 / (DP_W * xbytes);
+    const bool inlds = chunk <= lds_rows;
+    const int Cp = (int)ldc + 128; // (the GEMM stages whole tiles of 128 columns of Ut, starting at any multiple of 64)
     DevBuf<int> P, seq, candrow, invtab;
     DevBuf<signed char> Fd, Ut;
     DevBuf<PanelInfo> info;
@@ -1364,17 +1367,27 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(seq.p, 0xff, (size_t)Rp * sizeof(int), s));
     HIPCHK(hipMemsetAsync(pivrow_of_col.p, 0xff, ((size_t)C + 1) * sizeof(int), s));
-    const size_t lds = inlds ? (size_t)chunk * DP_W * sizeof(int) : 0;
+    const size_t lds = inlds ? (size_t)chunk * DP_W * (size_t)xbytes : 0;
     static bool attr_done = false;
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 576 * DP_W * (int)sizeof(int)));
+        HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024, signed char>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
+        HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024, short>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
         attr_done = true;
     }
     auto gemm = [&](int ja, int jb, int k0, int K, const int *rows, int nrows) {
         if (jb <= ja || K <= 0) return;
-        const dim3 grid((unsigned)cdiv(rows ? nrows : R, 128), (unsigned)cdiv(jb - ja, 64));
-        if (ND == 1) hipLaunchKernelGGL((k_gemm_i8<1>), grid, dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows, Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB);
-        else hipLaunchKernelGGL((k_gemm_i8<2>), grid, dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows, Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB);
+        // (1-D grid: the kernel orders the tiles itself, in bands of row tiles; a partial last band has fewer row tiles, and its
+        // tiles still number rows_in_band * ntn, so the total is simply ntm * ntn)
+        const int ntm = cdiv(rows ? nrows : R, 128);
+        if (ND == 1) {
+            const int ntn = cdiv(jb - ja, 128);
+            hipLaunchKernelGGL((k_gemm_i8<1, 2, 2, 2, 2>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows,
+                               Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB, ntm, ntn);
+        } else {
+            const int ntn = cdiv(jb - ja, 64);
+            hipLaunchKernelGGL((k_gemm_i8<2, 4, 1, 1, 2>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows,
+                               Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB, ntm, ntn);
+        }
     };
     auto trsm = [&](int q, int ja, int jb) {
         if (jb <= ja) return;
@@ -1399,8 +1412,9 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
                 const int *a_inv = invtab.p;
                 unsigned long long *a_stamps = stamps.p;
                 void *args[] = {&a_Rp, &a_chunk, &a_w, &a_c0, &a_F, &a_P, &a_seq, &a_pc, &a_info, &a_sy, &a_cand, &a_st, &a_inv, &a_stamps};
-                HIPCHK(hipLaunchCooperativeKernel(inlds ? (const void *)k_panel_lu<true, 1024> : (const void *)k_panel_lu<false, 1024>, dim3(G), dim3(1024),
-                                                  args, (unsigned)lds, s));
+                const void *fn = !inlds ? (const void *)k_panel_lu<false, 1024, int>
+                                 : ND == 1 ? (const void *)k_panel_lu<true, 1024, signed char> : (const void *)k_panel_lu<true, 1024, short>;
+                HIPCHK(hipLaunchCooperativeKernel(fn, dim3(G), dim3(1024), args, (unsigned)lds, s));
             }
             if (ND == 1) hipLaunchKernelGGL((k_panel_store<1>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
             else hipLaunchKernelGGL((k_panel_store<2>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
