@@ -118,12 +118,24 @@ void spasm_triplet_save(const struct spasm_triplet *T, void *file);  /* FILE*, s
 void spasm_csr_save(const struct spasm_csr *A, void *file);          /* FILE*, src/SpaSM.jl:523 */
 
 /* ---- spasm_certificate.c: the probabilistic self-check of a factorization (src/SpaSM.jl:934).  Host-side, O(nnz).
- * Checks (a) the shape of the echelon form: row k of U starts at its pivot column qinv^-1(k) with a 1, so the rows of U are
- * independent; (b) for random vectors x drawn from `seed`, that x*A reduces to zero modulo the rows of U, i.e. that the row
- * space of A lies in that of U (a wrong U escapes with probability <= 1/p per trial; 2 trials, 8 for p < 2^16).
- * Together: rank(A) <= r and U spans at least the rows of A.  libspasm's version also uses L (x*L*U == x*P*A); this
- * engine's LU has L = NULL, so "the rows of U lie in the row space of A" is NOT checked. ---- */
+ * Checks (a) the shape of the echelon form: every row of U holds a 1 on its pivot column qinv^-1(k) and U is (permuted)
+ * triangular, so its rows are independent; (b) for random vectors x drawn from `seed`, that x*A reduces to zero modulo the rows
+ * of U, i.e. that the row space of A lies in that of U (a wrong U escapes with probability <= 1/p per trial; 2 trials, 8 for
+ * p < 2^16).  Together: rank(A) <= r and U spans at least the rows of A.
+ * With fact->L (echelonize_opts.L) the check is two-sided, as libspasm's: (c) x*L*U == x*A for random x, i.e. A == L*U, and
+ * (d) the rows p[0 .. r) of L form a triangular matrix with a non-zero diagonal, so U = L_P^-1 A_P: every row of U lies in the
+ * row space of A and rank(A) == r.  Without L, (c) and (d) are skipped: a U with rows outside the row space of A passes. ---- */
 bool spasm_factorization_verify(const struct spasm_csr *A, const struct spasm_lu *fact, uint64_t seed);
+
+/* ---- spasm_solve.c (src/SpaSM.jl:895-923), for a factorization that carries L (echelonize with opts->L; the sparse rounds then
+ * keep their multiplier lists and the dense finish is not used).  L is n x r with A[i] == sum_k L[i][k] U[k]; the entry of row
+ * p[k] on column k is the pivot U's row k was divided by.
+ * spasm_gesv: X (rows of B x rows of A, zero outside the pivotal rows) with X*A == B; ok[k] tells whether row k of B is in the
+ *             row space.  Two batched triangular solves on the device (Y*U == B, then X_P*L_P == Y).
+ * spasm_solve: the same for one dense vector b (m entries) -> x (n = rows of A entries); false when there is no solution.
+ *             NOTE the prototype wrapper allocates x with fact.U.n entries (src/SpaSM.jl:898): bind it with size(fact.L, 1). ---- */
+struct spasm_csr *spasm_gesv(const struct spasm_lu *fact, const struct spasm_csr *B, bool *ok);
+bool spasm_solve(const struct spasm_lu *fact, const spasm_ZZp *b, spasm_ZZp *x);
 
 /* ---- spasm_ZZp.c surface (commented-out binding at src/SpaSM.jl:65; arithmetic restated :73-88,:383-390) ---- */
 void spasm_field_init(i64 p, spasm_field F);

@@ -16,6 +16,7 @@ from .api import (
     balanced,
     echelonize,
     factorization_verify,
+    gesv,
     kernel,
     last_rounds,
     load,
@@ -24,6 +25,7 @@ from .api import (
     rank,
     rref,
     save,
+    solve,
     sparse,
     sparse_triangular_solve,
     synth_csr,
@@ -31,6 +33,6 @@ from .api import (
 )
 
 __all__ = [
-    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "factorization_verify", "kernel",
+    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "factorization_verify", "gesv", "solve", "kernel",
     "last_rounds", "nnz", "prime0", "rank", "rref", "sparse", "sparse_triangular_solve", "synth_csr", "transpose",
 ]

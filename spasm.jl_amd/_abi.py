@@ -145,6 +145,8 @@ SIGNATURES = {
     "spasm_field_init": (None, [C.c_int64, _P(Field)]),
     "spasm_transpose": (_P(CsrStruct), [_P(CsrStruct)]),
     "spasm_factorization_verify": (C.c_bool, [_P(CsrStruct), _P(LuStruct), C.c_uint64]),
+    "spasm_gesv": (_P(CsrStruct), [_P(LuStruct), _P(CsrStruct), C.c_void_p]),
+    "spasm_solve": (C.c_bool, [_P(LuStruct), C.c_void_p, C.c_void_p]),
     "spasm_rref": (_P(CsrStruct), [_P(LuStruct), _P(C.c_int32)]),
     "spasm_triplet_alloc": (_P(TripletStruct), [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_bool]),
     "spasm_triplet_realloc": (None, [_P(TripletStruct), C.c_int64]),

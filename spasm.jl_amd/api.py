@@ -265,10 +265,10 @@ class LU:
         self.data = ptr
 
     @classmethod
-    def from_parts(cls, U, qinv, p):
+    def from_parts(cls, U, qinv, p, L=None):
         """An LU from its parts (layout reference src/SpaSM.jl:262-270), e.g. assembled from the rounds of the row-sharded
-        echelonize.  U: CSR whose ownership passes to the LU; qinv: m entries (row of U or -1); p: max(n, m) entries.
-        Everything is malloc'ed so that spasm_lu_free releases it like an LU of spasm_echelonize."""
+        echelonize.  U (and L, when given): CSRs whose ownership passes to the LU; qinv: m entries (row of U or -1); p: max(n, m)
+        entries.  Everything is malloc'ed so that spasm_lu_free releases it like an LU of spasm_echelonize."""
         libc = C.CDLL(None)
         libc.malloc.restype = C.c_void_p
         libc.malloc.argtypes = [C.c_size_t]
@@ -288,7 +288,9 @@ class LU:
         st = C.cast(mem, C.POINTER(_abi.LuStruct))
         st.contents.r = int(U.n)
         st.contents.complete = False
-        st.contents.L = None
+        st.contents.L = L.data if L is not None else None
+        if L is not None:
+            L._own = False
         st.contents.U = U.data
         st.contents.qinv = dup(qinv)
         st.contents.p = dup(p)
@@ -395,6 +397,37 @@ def rref(fact, verbose=False):
     if not ptr:
         raise SpasmError("spasm_rref failed: " + _abi.last_error())
     return CSR(ptr), rq[:m]
+
+
+def gesv(fact, B, verbose=False):
+    """gesv(fact::LU, B::CSR) (reference src/SpaSM.jl:907-923): solve X * A == B where A has been echelonized as `fact` WITH its
+    L factor (echelonize(A, L=True)).  Returns (X, ok): X is rows(B) x rows(A); ok[k] says whether row k of B has a solution."""
+    ok = np.zeros(max(B.n, 1), dtype=np.uint8)
+    with _quiet(not verbose):
+        ptr = _abi.lib().spasm_gesv(fact.data, B.data, ok.ctypes.data)
+    if not ptr:
+        raise SpasmError("spasm_gesv failed: " + _abi.last_error())
+    return CSR(ptr), ok[: B.n].astype(bool)
+
+
+def solve(fact, b, x=None):
+    """solve(fact::LU, b::Vector) (reference src/SpaSM.jl:889-905): x with x * A == b, or None when there is none.  b has one entry
+    per column of A, x one per ROW OF A (the prototype sizes x by fact.U.n; see include/spasm_amd.h)."""
+    st = fact.data.contents
+    if not st.L:
+        raise SpasmError("M.L is null")  # fact.L, :896
+    m, n = int(st.U.contents.m), int(st.L.contents.n)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    if b.shape != (m,):
+        raise ValueError(f"b must have {m} entries")
+    if x is None:
+        x = np.zeros(n, dtype=np.int32)
+    elif x.shape != (n,) or x.dtype != np.int32:
+        raise ValueError(f"x must be an int32 vector of {n} entries")
+    okv = _abi.lib().spasm_solve(fact.data, b.ctypes.data, x.ctypes.data)
+    if not okv and _abi.last_error():
+        raise SpasmError("spasm_solve failed: " + _abi.last_error())
+    return x if okv else None
 
 
 def factorization_verify(A, fact, seed=0):

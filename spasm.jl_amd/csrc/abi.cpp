@@ -481,6 +481,47 @@ extern "C" SPASM_API bool spasm_factorization_verify(const struct spasm_csr *A, 
         }
         for (int j = 0; j < m; j++) if (y[(size_t)j] != 0) return false;
     }
+    // (c), (d): with L the check is two-sided
+    if (fact->L) {
+        const struct spasm_csr *L = fact->L;
+        if (L->n != n || L->m != r || !fact->p || (uint64_t)L->field->p != p) return false;
+        // (d) the pivotal rows of L: entries only on columns <= their own, non-zero on it
+        std::vector<char> seen((size_t)std::max(n, 1), 0);
+        for (int k = 0; k < r; k++) {
+            const int i = fact->p[k];
+            if (i < 0 || i >= n || seen[(size_t)i]) return false;
+            seen[(size_t)i] = 1;
+            bool diag = false;
+            for (i64 q = L->p[i]; q < L->p[i + 1]; q++) {
+                if (L->j[q] < 0 || L->j[q] > k) return false;
+                if (L->j[q] == k) { if (res(L->x[q]) == 0 || diag) return false; diag = true; }
+            }
+            if (!diag) return false;
+        }
+        // (c) x * L * U == x * A
+        std::vector<uint64_t> yl((size_t)std::max(r, 1)), z((size_t)std::max(m, 1)), wv((size_t)std::max(m, 1));
+        Rng rng2(seed ^ 0x4C55564552494659ull);
+        for (int t = 0; t < trials; t++) {
+            std::fill(yl.begin(), yl.end(), 0);
+            std::fill(z.begin(), z.end(), 0);
+            std::fill(wv.begin(), wv.end(), 0);
+            for (int i = 0; i < n; i++) {
+                const uint64_t xi = rng2.below(p);
+                if (xi == 0) continue;
+                for (i64 q = A->p[i]; q < A->p[i + 1]; q++) wv[(size_t)A->j[q]] = (wv[(size_t)A->j[q]] + xi * res(A->x ? A->x[q] : 1) % p) % p;
+                for (i64 q = L->p[i]; q < L->p[i + 1]; q++) {
+                    if (L->j[q] < 0 || L->j[q] >= r) return false;
+                    yl[(size_t)L->j[q]] = (yl[(size_t)L->j[q]] + xi * res(L->x[q]) % p) % p;
+                }
+            }
+            for (int k = 0; k < r; k++) {
+                const uint64_t c = yl[(size_t)k];
+                if (c == 0) continue;
+                for (i64 q = U->p[k]; q < U->p[k + 1]; q++) z[(size_t)U->j[q]] = (z[(size_t)U->j[q]] + c * res(U->x[q]) % p) % p;
+            }
+            for (int j = 0; j < m; j++) if (z[(size_t)j] != wv[(size_t)j]) return false;
+        }
+    }
     return true;
 }
 

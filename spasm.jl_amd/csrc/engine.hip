@@ -313,6 +313,8 @@ struct Round {
     // columns no pivot row touches (kernels.hpp, k_close_cols ..).  Renumbers the pivots: the new ones first.  Returns how many
     // were added.  Single device only (the proposals would need a second all-reduce in a sharded round).
     DevBuf<int> closed, colcnt, prop, newflag, newscan;
+    DevBuf<int> pivval; // the pivot entries before scaling (the diagonal of L), filled by build_U when want_pivval
+    bool want_pivval = false;
     DevBuf<u64d> best2;
     int n_leftmost = 0, n_open = 0;
     int extend_pivots_on_open_columns(const DevMat &A)
@@ -397,8 +399,9 @@ struct Round {
         UPN.ensure((size_t)utotal + 1);
         if (npiv > 0) {
             constexpr int TEAM = 16;
+            if (want_pivval) pivval.ensure((size_t)npiv + 1);
             hipLaunchKernelGGL((k_build_U<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, stream, npiv, F, rowsrc, pivcol.p,
-                               PM.start.p, PM.len.p, PM.ent.p, qinv_r.p, uoff.p, Ufull.p, UPP.p, UPN.p, uhdr.p);
+                               PM.start.p, PM.len.p, PM.ent.p, qinv_r.p, uoff.p, Ufull.p, UPP.p, UPN.p, uhdr.p, want_pivval ? pivval.p : nullptr);
             HIPCHK(hipGetLastError());
         }
         free_cols = m - npiv;
@@ -1801,6 +1804,61 @@ void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStrea
     dense_eliminate(D, nnp, C, ldc, W.clist.p, row_orig.p, R.F, U, s);
 }
 
+// the L factor on the host, as it is collected: per chunk the rows it belongs to (original row of A per slot, entries per slot),
+// then the (row of U, value) pairs
+struct HostL {
+    std::vector<int> row;     // original row of every entry
+    std::vector<int> j, x;    // row of U, value
+};
+
+// the multiplier lists of the `cnt` row slots the last solve_phase of R filled (rows np_rows[off ..]) -> HostL; ubase = rows of U
+// that existed before this round
+void collect_L_lists(HostL &L, Round &R, const DevMat &cur, int off, int cnt, int ubase, hipStream_t s)
+{
+    if (cnt == 0) return;
+    DevBuf<i64d> lcnt, loff;
+    lcnt.alloc((size_t)cnt + 1); loff.alloc((size_t)cnt + 1);
+    hipLaunchKernelGGL(k_l_count, dim3(cdiv(((i64)cnt + 1) * 64, 256)), dim3(256), 0, s, cnt, R.Lstart.p, R.Llen.p, R.Lpool.p, lcnt.p);
+    HIPCHK(hipGetLastError());
+    R.scan.exclusive(lcnt.p, loff.p, (size_t)cnt + 1, s);
+    std::vector<i64d> h_off((size_t)cnt + 1);
+    std::vector<int> h_rows((size_t)cnt), h_orig((size_t)cur.n);
+    HIPCHK(hipMemcpyAsync(h_off.data(), loff.p, ((size_t)cnt + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_rows.data(), R.np_rows.p + off, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_orig.data(), cur.orig.p, (size_t)cur.n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const i64 tot = h_off[(size_t)cnt];
+    if (tot == 0) return;
+    DevBuf<int> oj, ox;
+    oj.alloc((size_t)tot); ox.alloc((size_t)tot);
+    hipLaunchKernelGGL(k_l_fill, dim3(cdiv((i64)cnt * 64, 256)), dim3(256), 0, s, cnt, ubase, R.Lstart.p, R.Llen.p, R.Lpool.p, R.Lidx.p, loff.p, oj.p, ox.p);
+    HIPCHK(hipGetLastError());
+    const size_t old = L.j.size();
+    L.j.resize(old + (size_t)tot); L.x.resize(old + (size_t)tot); L.row.resize(old + (size_t)tot);
+    HIPCHK(hipMemcpyAsync(L.j.data() + old, oj.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(L.x.data() + old, ox.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int t = 0; t < cnt; t++) {
+        const int o = h_orig[(size_t)h_rows[(size_t)t]];
+        for (i64 k = h_off[(size_t)t]; k < h_off[(size_t)t + 1]; k++) L.row[old + (size_t)k] = o;
+    }
+}
+
+// the diagonal: row U.orig[ubase + k] of A is pivval[k] times row ubase + k of U (plus what its own list said in earlier rounds)
+void collect_L_pivots(HostL &L, Round &R, const HostU &U, int ubase, hipStream_t s)
+{
+    const int np = R.npiv;
+    if (np == 0) return;
+    std::vector<int> pv((size_t)np);
+    HIPCHK(hipMemcpyAsync(pv.data(), R.pivval.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int k = 0; k < np; k++) {
+        L.row.push_back(U.orig[(size_t)ubase + (size_t)k]);
+        L.j.push_back(ubase + k);
+        L.x.push_back(pv[(size_t)k]);
+    }
+}
+
 struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
 {
     // max_round, min_pivot_proportion, enable_dense and sparsity_threshold (reference src/SpaSM.jl:329-337) decide how far the
@@ -1830,6 +1888,12 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     // the trip counters of the round statistics (applications, nnz_reduced, read_bytes) count multiplier-list entries: they are
     // exact only when the rounds keep to the lists, which costs about a third more time per round
     if (const char *e = getenv("SPASM_AMD_ROUND_STATS")) R->force_lists = atoi(e) != 0;
+    // echelonize_opts.L (reference src/SpaSM.jl:331): keep the multipliers.  They only exist as lists on the sparse path, so the
+    // rounds keep to the lists (with the pivot index of every record) and the dense finish is not used.
+    const bool want_L = opts->L;
+    const bool use_dense = opts->enable_dense && !want_L;
+    HostL HL;
+    if (want_L) { R->force_lists = true; R->want_idx = true; R->want_pivval = true; }
     int round = 0;
     i64 cur_live = n;
     bool gplu_finish = false; // the sparse rounds are over (max_round / min_pivot_proportion) and the dense finish is not an option
@@ -1837,7 +1901,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         {
             const i64 cfree = (i64)m - (i64)U.pivcol.size();
             const double cells = (double)cur_live * (double)cfree;
-            if (opts->enable_dense && cur_nnz > 0 && cells > 0 && cells <= (double)dense_max_entries() &&
+            if (use_dense && cur_nnz > 0 && cells > 0 && cells <= (double)dense_max_entries() &&
                 (double)cur_nnz > opts->sparsity_threshold * cells) {
                 spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                            cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
@@ -1870,7 +1934,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
                 // dense when the remainder is dense enough (the reference's rule) or small enough for the cubic work not to matter
                 // (2^28 cells: a 16384 x 16384 remainder); a large sparse remainder is better served by more sparse rounds
                 const bool worth = (double)cur_nnz > opts->sparsity_threshold * cells || cells <= (double)((i64)1 << 28);
-                if (opts->enable_dense && cells > 0 && cells <= (double)dense_max_entries() && worth) {
+                if (use_dense && cells > 0 && cells <= (double)dense_max_entries() && worth) {
                     spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                                cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
                     run_dense_tail(*cur, R->F, U, stream);
@@ -1915,7 +1979,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         double rec_per_row = 4.0 * (double)cur_nnz / (double)std::max(nnp, 1), slots_per_row = 0;
         double est_density = -1;
         const int free_now = m - (int)U.pivcol.size() - R->npiv;
-        const bool dense_possible = opts->enable_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries();
+        const bool dense_possible = use_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries();
         std::unique_ptr<DenseW> dw;
         if (nnp > 0 && dense_possible && !R->use_uinv) {
             // No Uinv: the rows of this round reach many pivots (or there are few rows), and the row sample below would walk those
@@ -1985,6 +2049,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
             R->run_scatter(*cur, R->np_rows.p + off, cnt);
             HIPCHK(hipEventRecord(R->ev[3], stream));
             R->fetch_counters();
+            if (want_L) collect_L_lists(HL, *R, *cur, off, cnt, (int)U.pivcol.size(), stream);
             {
                 float ms = 0;
                 if (nbatch == 0 && hipEventElapsedTime(&ms, R->ev[0], R->ev[1]) == hipSuccess) ms_pivots = ms; // incl. the probe
@@ -2052,7 +2117,11 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         R->hctr.stream_redo = acc.stream_redo;
         for (int c = 0; c < 16; c++) { R->hctr.class_ent[c] = acc.class_ent[c]; R->hctr.class_seg[c] = acc.class_seg[c]; }
         for (int c = 0; c < NCLASS; c++) R->hclass_count[c] = acc_class[c];
-        append_round_U(U, *R, *cur, stream);
+        {
+            const int ubase = (int)U.pivcol.size();
+            append_round_U(U, *R, *cur, stream);
+            if (want_L) collect_L_pivots(HL, *R, U, ubase, stream);
+        }
 
         spasm_amd_round_stats st;
         fill_stats(st, *R, round, cur->n, cur_nnz);
@@ -2098,9 +2167,25 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         for (int i = 0; i < n; i++) if (!used[(size_t)i]) p[w++] = i;
         for (; w < plen; w++) p[w] = -1;
     }
+    struct spasm_csr *Lc = nullptr;
+    if (want_L) {
+        // rows of L in the order of the rows of A; inside a row the entries arrive round by round, i.e. by ascending row of U
+        const i64 lnz = (i64)HL.j.size();
+        Lc = spasm_csr_alloc(n, r, lnz, prime, true);
+        if (!Lc) throw EngineError("out of host memory for L");
+        std::vector<i64> cntr((size_t)n + 1, 0);
+        for (i64 k = 0; k < lnz; k++) cntr[(size_t)HL.row[(size_t)k] + 1]++;
+        for (int i = 0; i < n; i++) cntr[(size_t)i + 1] += cntr[(size_t)i];
+        memcpy(Lc->p, cntr.data(), sizeof(i64) * ((size_t)n + 1));
+        for (i64 k = 0; k < lnz; k++) {
+            const i64 w = cntr[(size_t)HL.row[(size_t)k]]++;
+            Lc->j[w] = HL.j[(size_t)k];
+            Lc->x[w] = HL.x[(size_t)k];
+        }
+    }
     N->r = r;
     N->complete = false;
-    N->L = nullptr;
+    N->L = Lc;
     N->U = Uc;
     N->qinv = qinv;
     N->p = p;
@@ -2448,6 +2533,77 @@ struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const 
         for (int k = 0; k < nb; k++) slen[(size_t)k] = (int)(B->p[k + 1] - B->p[k]); // without pivots a row is solvable iff it is zero
     }
     if (ok) for (int k = 0; k < nb; k++) ok[k] = slen[(size_t)k] == 0;
+    return X;
+}
+
+// ------------------------------------------------------------------------------------------------
+// spasm_gesv / spasm_solve (reference src/SpaSM.jl:895-923): X * A == B from a factorization that carries L (echelonize_opts.L).
+// With A[i] = sum_k L[i][k] U[k]:  X * A = (X * L) * U, so   Y * U = B  (the batched triangular solve on the device, Y is
+// nb x r), then  X_P * L_P = Y  on the pivotal rows p[0 .. r) of A, whose rows of L form a lower triangular r x r matrix with the
+// pivots d_k = L[p[k]][k] on the diagonal (a row only holds multipliers of pivots elected before it).  Scaled to a unit diagonal
+// this is a second triangular solve of the same kind; X is zero outside the pivotal rows.  ok[b] = 1 when row b has a solution.
+// ------------------------------------------------------------------------------------------------
+struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok);
+
+struct spasm_csr *do_gesv(const struct spasm_lu *fact, const struct spasm_csr *B, unsigned char *ok)
+{
+    if (!fact || !fact->U || !fact->qinv || !fact->p) throw EngineError("incomplete factorization (U / qinv / p missing)");
+    if (!fact->L) throw EngineError("the factorization has no L: echelonize with L = true (reference src/SpaSM.jl:331)");
+    if (!B) throw EngineError("null right-hand side");
+    const struct spasm_csr *U = fact->U, *L = fact->L;
+    const int r = U->n, n = L->n, nb = B->n;
+    const i64 prime = U->field->p;
+    if (L->m != r) throw EngineError("L must have one column per row of U");
+    const ZpField F = zp_field_make(prime);
+    // the pivotal rows of L, scaled to a unit diagonal
+    std::vector<int> diag((size_t)std::max(r, 1), 0);
+    i64 mnz = 0;
+    for (int k = 0; k < r; k++) {
+        const int i = fact->p[k];
+        if (i < 0 || i >= n) throw EngineError("p does not name a row of A for every row of U");
+        mnz += L->p[i + 1] - L->p[i];
+    }
+    struct spasm_csr *M = spasm_csr_alloc(r, r, mnz, prime, true);
+    if (!M) throw EngineError("out of host memory");
+    std::unique_ptr<struct spasm_csr, void (*)(struct spasm_csr *)> Mguard(M, spasm_csr_free);
+    i64 w = 0;
+    for (int k = 0; k < r; k++) {
+        const int i = fact->p[k];
+        M->p[k] = w;
+        int d = 0;
+        for (i64 q = L->p[i]; q < L->p[i + 1]; q++) {
+            if (L->j[q] > k) throw EngineError("L is not triangular on the pivotal rows");
+            if (L->j[q] == k) d = L->x[q];
+        }
+        if (d == 0) throw EngineError("L has a zero on its diagonal");
+        diag[(size_t)k] = d;
+        const int dinv = zp_inverse(F, d);
+        for (i64 q = L->p[i]; q < L->p[i + 1]; q++) {
+            M->j[w] = L->j[q];
+            M->x[w] = L->j[q] == k ? 1 : zp_mul(F, dinv, L->x[q]);
+            w++;
+        }
+    }
+    M->p[r] = w;
+    std::vector<int> ident((size_t)std::max(r, 1));
+    for (int k = 0; k < r; k++) ident[(size_t)k] = k;
+    std::vector<unsigned char> ok1((size_t)std::max(nb, 1), 0), ok2((size_t)std::max(nb, 1), 0);
+    struct spasm_csr *Y = do_trisolve(U, fact->qinv, B, ok1.data());
+    std::unique_ptr<struct spasm_csr, void (*)(struct spasm_csr *)> Yguard(Y, spasm_csr_free);
+    struct spasm_csr *Xs = do_trisolve(M, ident.data(), Y, ok2.data());
+    std::unique_ptr<struct spasm_csr, void (*)(struct spasm_csr *)> Xguard(Xs, spasm_csr_free);
+    // X[b][p[k]] = Xs[b][k] / d_k
+    struct spasm_csr *X = spasm_csr_alloc(nb, n, spasm_nnz(Xs), prime, true);
+    if (!X) throw EngineError("out of host memory for X");
+    std::vector<int> dinv((size_t)std::max(r, 1));
+    for (int k = 0; k < r; k++) dinv[(size_t)k] = zp_inverse(F, diag[(size_t)k]);
+    for (int b = 0; b <= nb; b++) X->p[b] = Xs->p[b];
+    for (i64 q = 0; q < Xs->p[nb]; q++) {
+        const int k = Xs->j[q];
+        X->j[q] = fact->p[k];
+        X->x[q] = zp_mul(F, Xs->x[q], dinv[(size_t)k]);
+    }
+    if (ok) for (int b = 0; b < nb; b++) ok[b] = ok1[(size_t)b] && ok2[(size_t)b];
     return X;
 }
 
@@ -2996,6 +3152,52 @@ SPASM_API struct spasm_csr *spasm_amd_triangular_solve(const struct spasm_csr *U
     } catch (const std::exception &e) {
         spasm_set_error("spasm_amd_triangular_solve: %s", e.what());
         return nullptr;
+    }
+}
+
+// reference src/SpaSM.jl:915-923
+SPASM_API struct spasm_csr *spasm_gesv(const struct spasm_lu *fact, const struct spasm_csr *B, bool *ok)
+{
+    spasm_clear_error();
+    try {
+        static_assert(sizeof(bool) == 1, "ok is an array of bytes");
+        return do_gesv(fact, B, (unsigned char *)ok);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_gesv: %s", e.what());
+        return nullptr;
+    }
+}
+
+// reference src/SpaSM.jl:895-905: x (n = rows of A entries) with x * A == b (m entries); false when there is no solution
+SPASM_API bool spasm_solve(const struct spasm_lu *fact, const spasm_ZZp *b, spasm_ZZp *x)
+{
+    spasm_clear_error();
+    try {
+        if (!fact || !fact->U || !fact->L || !b || !x) throw EngineError("null argument (a factorization with L is needed)");
+        const int m = fact->U->m, n = fact->L->n;
+        const i64 prime = fact->U->field->p;
+        const ZpField F = zp_field_make(prime);
+        i64 nz = 0;
+        for (int j = 0; j < m; j++) nz += zp_reduce(F, (int64_t)b[j]) != 0;
+        struct spasm_csr *B = spasm_csr_alloc(1, m, nz, prime, true);
+        if (!B) throw EngineError("out of host memory");
+        std::unique_ptr<struct spasm_csr, void (*)(struct spasm_csr *)> Bguard(B, spasm_csr_free);
+        i64 w = 0;
+        B->p[0] = 0;
+        for (int j = 0; j < m; j++) {
+            const int v = zp_reduce(F, (int64_t)b[j]);
+            if (v != 0) { B->j[w] = j; B->x[w] = v; w++; }
+        }
+        B->p[1] = w;
+        unsigned char ok = 0;
+        struct spasm_csr *X = do_gesv(fact, B, &ok);
+        for (int i = 0; i < n; i++) x[i] = 0;
+        for (i64 q = X->p[0]; q < X->p[1]; q++) x[X->j[q]] = X->x[q];
+        spasm_csr_free(X);
+        return ok != 0;
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_solve: %s", e.what());
+        return false;
     }
 }
 

@@ -403,7 +403,8 @@ template <int TEAM>
 __global__ void k_build_U(int npiv, ZpField F, const int *__restrict__ rowsrc, const int *__restrict__ pivcol,
                           const i64d *__restrict__ start, const int *__restrict__ len, const int2 *__restrict__ ent,
                           const int *__restrict__ qinv_r, const i64d *__restrict__ uoff,
-                          int2 *__restrict__ Ufull, int2 *__restrict__ UPP, int2 *__restrict__ UPN, UHdr *__restrict__ uhdr)
+                          int2 *__restrict__ Ufull, int2 *__restrict__ UPP, int2 *__restrict__ UPN, UHdr *__restrict__ uhdr,
+                          int *__restrict__ pivval)
 {
     const int tl = threadIdx.x % TEAM;
     const int idx = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
@@ -448,6 +449,7 @@ __global__ void k_build_U(int npiv, ZpField F, const int *__restrict__ rowsrc, c
         h.npn = npn;
         h.len = ln;
         uhdr[idx] = h;
+        if (pivval) pivval[idx] = pv; // the entry of L on the diagonal: row = pv * (row of U) (reference src/SpaSM.jl:705-712)
     }
 }
 
@@ -2398,6 +2400,50 @@ __global__ void k_count_nonzero(i64d n, const int *__restrict__ v, u64d *__restr
     for (i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64d)gridDim.x * blockDim.x) c += v[i] != 0;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor((long long)c, o);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The L factor (echelonize_opts.L, reference src/SpaSM.jl:331; struct spasm_lu.L :266): the multipliers x_b of every reduced row
+// ARE its row of L (A[i] = sum_k L[i][k] U[k], :705-707), so a round only has to hand out the lists the solve kernels leave in
+// the record pool: per row slot the non-zero (row of U, multiplier) pairs, compacted.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_l_count(int nrows, const i64d *__restrict__ Lstart, const int *__restrict__ Llen, const int4 *__restrict__ Lpool, i64d *__restrict__ cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (t > nrows) return;
+    int c = 0;
+    if (t < nrows) {
+        const i64d ls = Lstart[t];
+        const int ll = Llen[t];
+        for (int i = lane; i < ll; i += 64) c += Lpool[ls + i].y != 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    }
+    if (lane == 0) cnt[t] = c;
+}
+
+__global__ void k_l_fill(int nrows, int ubase, const i64d *__restrict__ Lstart, const int *__restrict__ Llen, const int4 *__restrict__ Lpool,
+                         const int *__restrict__ Lidx, const i64d *__restrict__ off, int *__restrict__ oj, int *__restrict__ ox)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (t >= nrows) return;
+    const i64d ls = Lstart[t];
+    const int ll = Llen[t];
+    i64d pos = off[t];
+    const u64d below = (1ull << lane) - 1ull;
+    for (int i0 = 0; i0 < ll; i0 += 64) {
+        const int i = i0 + lane;
+        int v = 0, q = 0;
+        if (i < ll) { v = Lpool[ls + i].y; q = Lidx[ls + i]; }
+        const u64d m = __ballot(v != 0);
+        if (v != 0) {
+            const i64d w = pos + __popcll(m & below);
+            oj[w] = ubase + q;
+            ox[w] = v;
+        }
+        pos += __popcll(m);
+    }
 }
 
 // flag[j] = 1 for a column that holds entries (flag comes in from k_flag_cols) and carries no pivot of this round
