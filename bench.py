@@ -30,6 +30,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # scatter launch of each hash-table class (spasm.jl_amd/csrc/engine.hip, kClasses): k_scatter<LOGT, ...>
 SCATTER_KERNEL_PREFIX = ["k_scatter<8,", "k_scatter<9,", "k_scatter<10,", "k_scatter<11,", "k_scatter<12,", "k_scatter<13,",
                          "k_scatter<14,", None]
+# streaming twin of class c (stats classes 8 .. 14): k_wstream<LOGT = 8 + c, ...>
+STREAM_KERNEL_PREFIX = [f"k_wstream<{8 + c}," for c in range(7)]
+TRAFFIC_FILES = ["r02_final_traffic.json", "r01_final_traffic.json"]  # newest first: PMC passes of tools/final_profile.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -165,17 +168,21 @@ def main():
         k_ms = d["ms_class"][cls]
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # HBM traffic of that kernel from the PMC counters (collected in separate rocprofv3 passes and calibrated for
-        # this access shape, profiles/r01_final_traffic.json); only quoted for the workload it was measured on
-        prefix = SCATTER_KERNEL_PREFIX[cls] if (args.prime < 65536 and cls < 8) else None
+        # this access shape, profiles/r02_final_traffic.json); only quoted for the workload it was measured on
+        prefix = None
+        if args.prime < 65536:
+            prefix = SCATTER_KERNEL_PREFIX[cls] if cls < 8 else (STREAM_KERNEL_PREFIX[cls - 8] if cls < 15 else None)
         traffic = None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")))["kernels"]
-            if world == 1 and n == 1_000_000 and args.row_nnz == 20 and prefix:
-                hit = [v for k, v in prof.items() if k.startswith(prefix) and "true" in k]  # SMALL = true: p < 2^16
-                if len(hit) == 1:
-                    traffic = hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
+        for tf in TRAFFIC_FILES:
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", tf)))["kernels"]
+                if world == 1 and n == 1_000_000 and args.row_nnz == 20 and prefix:
+                    hit = [v for k, v in prof.items() if k.startswith(prefix) and "true" in k]  # SMALL = true: p < 2^16
+                    if len(hit) == 1:
+                        traffic = hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
+                        break
+            except (OSError, KeyError, ValueError):
+                pass
         roofline = {
             "bound": "hbm",
             "kernel": (f"k_stream class {cls - 8}" if cls >= 8 else f"k_scatter class {cls}") + f" ({d['rows_class'][cls]} rows)",

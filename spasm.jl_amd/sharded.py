@@ -269,17 +269,28 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
     blocks = []  # per round: (row lengths, columns, values, pivot columns, original rows) of its rows of U
     n_u = 0
     rounds = []
+    import time as _time
+
     try:
         while True:
+            t_round = _time.time()
             tot = all_gather_counts(list(eng.counts()), group).sum(dim=0)
             rows_left, nnz_left = int(tot[0]), int(tot[1])
             if nnz_left == 0:
                 break
             free_cols = m - n_u
             dense_enough = nnz_left > sparsity_threshold * rows_left * max(free_cols, 1)  # the single-device rule for its dense tail
+            # ... applied one round ahead as well, like the single-device density estimate (spasm_schur_estimate_density): when the
+            # fill keeps growing at the rate of the last round, would the NEXT Schur complement be dense?  Then it is never built
+            # sparse here (100k x 100k, 6 per row: the round that was skipped wrote 3.4e8 entries that the hand-off then had to
+            # gather: 9 of 15 s).
+            if rounds and not rounds[-1]["finish"] and rounds[-1]["nnz"] > 0 and nnz_left > rounds[-1]["nnz"]:
+                predicted = nnz_left * (nnz_left / rounds[-1]["nnz"])
+                dense_enough = dense_enough or predicted > sparsity_threshold * rows_left * max(free_cols, 1)
             if nnz_left <= finish_nnz or len(rounds) >= max_rounds or dense_enough:
                 # hand-off: every rank gets all remaining rows and finishes them (deterministic, so the results agree)
                 ids, p, j, x = eng.fetch_rows()
+                t_fetch = _time.time()
                 counts = all_gather_counts([len(ids), int(p[-1])], group)
                 dev = "cuda" if dist.is_initialized() and dist.get_backend(group) != "gloo" else "cpu"
                 g_ids = all_gather_var(torch.as_tensor(ids, dtype=torch.int64, device=dev), counts[:, 0].tolist(), group).cpu().numpy()
@@ -290,7 +301,9 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
                 starts = np.concatenate([[0], np.cumsum(g_len)])
                 sel = _ranges(starts[:-1][order], g_len[order])
                 rest = _virtual_csr(n, m, prime, g_ids[order], np.concatenate([[0], np.cumsum(g_len[order])]), g_ent[sel, 0], g_ent[sel, 1])
+                t_gather = _time.time()
                 fact = finish(rest)
+                t_finish = _time.time()
                 Uc, fp, fq = fact.U, np.asarray(fact.p), np.asarray(fact.qinv)
                 up, uj, ux = np.asarray(Uc.p), np.asarray(Uc.j), np.asarray(Uc.x)
                 col_of_row = np.full(fact.r, -1, dtype=np.int64)
@@ -298,10 +311,13 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
                 nzu = int(up[fact.r])
                 blocks.append((np.diff(up).astype(np.int64), np.array(uj[:nzu]), np.array(ux[:nzu]), col_of_row, fp[: fact.r].astype(np.int64)))
                 n_u += fact.r
-                rounds.append({"round": len(rounds), "finish": True, "rows": rows_left, "nnz": nnz_left, "npiv": int(fact.r)})
+                rounds.append({"round": len(rounds), "finish": True, "rows": rows_left, "nnz": nnz_left, "npiv": int(fact.r),
+                               "seconds": {"fetch_rows": t_fetch - t_round, "gather": t_gather - t_fetch, "finish": t_finish - t_gather,
+                                           "collect_U": _time.time() - t_finish}})
                 break
             keys = all_reduce_min(eng.elect(), group)
             npiv, n_own, nnz_own = eng.set_keys(keys)
+            t_elect = _time.time()
             if npiv == 0:
                 break
             counts = all_gather_counts([n_own, nnz_own], group)
@@ -309,15 +325,19 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
             hdr_all = all_gather_var(hdr, counts[:, 0].tolist(), group)
             ent_all = all_gather_var(ent, counts[:, 1].tolist(), group)
             eng.import_(hdr_all, ent_all)
+            t_exchange = _time.time()
             # the round's rows of U come from the engine as it built them on the device (scaled to a unit pivot, in pivot order):
             # nothing is recomputed on the host
             blk = eng.round_U()
             if len(blk[0]):
                 blocks.append(blk)
                 n_u += len(blk[0])
+            t_u = _time.time()
             eng.advance()  # the round runs; its Schur rows are the shard's matrix of the next round, still on the device
             rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv),
-                           "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4)})
+                           "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4),
+                           "seconds": {"elect": t_elect - t_round, "exchange_import": t_exchange - t_elect, "fetch_U": t_u - t_exchange,
+                                       "schur_advance": _time.time() - t_u}})
     finally:
         eng.close()
 

@@ -35,7 +35,7 @@ def main():
     mean = lambda v: sum(v) / len(v) if v else 0.0
     kernels = {}
     for k in sorted(fetch):
-        if not (k.startswith("k_scatter") or k.startswith("k_combine") or k.startswith("k_bin") or k.startswith("k_solve")):
+        if not k.startswith(("k_scatter", "k_combine", "k_bin", "k_solve", "k_wstream", "k_wplan", "k_stream_fix")):
             continue
         hit, miss = mean(tcc.get("TCC_HIT_sum", {}).get(k, [])), mean(tcc.get("TCC_MISS_sum", {}).get(k, []))
         kernels[k] = {

@@ -16,6 +16,8 @@ fact, info = sharded.echelonize_sharded(A, finish_nnz=int(os.environ.get("FINISH
 dist.barrier(); dt = time.time() - t
 if dist.get_rank() == 0:
     print(f"sharded x{dist.get_world_size()}: {dt:.2f}s rank {fact.r} rounds {[(r['finish'], r['npiv']) for r in info['rounds']]}", flush=True)
+    for r in info["rounds"]:
+        print("  round", r["round"], "rows", r["rows"], "nnz", r["nnz"], {k: round(v, 3) for k, v in r["seconds"].items()}, flush=True)
     t = time.time(); ref = S.echelonize(A); dt1 = time.time() - t
     print(f"single device: {dt1:.2f}s rank {ref.r} rounds {[r['npiv'] for r in S.last_rounds()]}", flush=True)
     assert ref.r == fact.r and S.factorization_verify(A, fact, 1)
