@@ -2,10 +2,10 @@
 tag=${1:-r01_final}
 cd "$(dirname "$0")/.."
 python tools/pmc_summary.py gpurun_out/final profiles/${tag}_traffic.json > /dev/null
-cp gpurun_out/final/trace/*/*_kernel_stats.csv profiles/${tag}_kernel_stats.csv
+cp "$(ls -t gpurun_out/final/trace/*/*_kernel_stats.csv | head -1)" profiles/${tag}_kernel_stats.csv
 cp gpurun_out/final/bench_full.json profiles/${tag}_bench.json
-cp gpurun_out/final/calib_FETCH_SIZE/*/*_counter_collection.csv profiles/${tag}_calibration_FETCH_SIZE.csv
-cp gpurun_out/final/calib_WRITE_SIZE/*/*_counter_collection.csv profiles/${tag}_calibration_WRITE_SIZE.csv
+cp "$(ls -t gpurun_out/final/calib_FETCH_SIZE/*/*_counter_collection.csv | head -1)" profiles/${tag}_calibration_FETCH_SIZE.csv
+cp "$(ls -t gpurun_out/final/calib_WRITE_SIZE/*/*_counter_collection.csv | head -1)" profiles/${tag}_calibration_WRITE_SIZE.csv
 cp gpurun_out/final/shard_time.txt profiles/${tag}_shard_time.txt
 [ -f gpurun_out/final/ablate_scatter.txt ] && cp gpurun_out/final/ablate_scatter.txt profiles/${tag}_ablations_scatter.txt
 [ -f gpurun_out/final/ablate_combine.txt ] && cp gpurun_out/final/ablate_combine.txt profiles/${tag}_ablations_combine.txt

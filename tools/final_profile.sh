@@ -8,7 +8,7 @@ timeout -k 10 400 python bench.py > gpurun_out/final/bench_full.json 2> gpurun_o
 ls gpurun_out/final
 # diagnostic builds (if present): phase ablations and instruction mix of the scatter / combine kernels
 if [ -f build/diag/libspasm_amd_ablate.so ]; then
-  (export SPASM_AMD_LIB=$PWD/build/diag/libspasm_amd_ablate.so; bash tools/ablate.sh > gpurun_out/final/ablate_scatter.txt 2>&1; bash tools/ablate_combine.sh > gpurun_out/final/ablate_combine.txt 2>&1)
+  (export SPASM_AMD_LIB=$PWD/build/diag/libspasm_amd_ablate.so; bash tools/ablate_stream.sh > gpurun_out/final/ablate_scatter.txt 2>&1; bash tools/ablate_combine.sh > gpurun_out/final/ablate_combine.txt 2>&1)
 fi
 bash tools/pmc_insts.sh final > /dev/null 2>&1
 python tools/shard_time.py 2>/dev/null | grep "G=" > gpurun_out/final/shard_time.txt
