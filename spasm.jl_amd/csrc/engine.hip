@@ -1283,9 +1283,37 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     (void)hipGetLastError(); // (an event that was never recorded makes hipEventElapsedTime fail: not an error of the engine)
 }
 
+// malloc'ed, uninitialised, geometrically growing int array whose buffer ends up in the spasm_csr the caller frees: the entries
+// of U go device -> this buffer -> caller, without a value-initialising resize (a memset of gigabytes) or a final copy
+struct HostInts {
+    int *ptr = nullptr;
+    size_t n = 0, cap = 0;
+    HostInts() {}
+    HostInts(const HostInts &) = delete;
+    HostInts &operator=(const HostInts &) = delete;
+    ~HostInts() { free(ptr); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    int *data() { return ptr; }
+    int *grow(size_t count) // room for `count` more; returns where they go
+    {
+        if (n + count > cap) {
+            const size_t want = std::max(n + count, cap + cap / 2 + 1024);
+            int *q = (int *)realloc(ptr, want * sizeof(int));
+            if (!q) throw EngineError("out of host memory for U");
+            ptr = q;
+            cap = want;
+        }
+        int *at = ptr + n;
+        n += count;
+        return at;
+    }
+    int *steal() { int *q = ptr; ptr = nullptr; n = cap = 0; return q; }
+};
+
 struct HostU {
     std::vector<i64> p;      // row pointers
-    std::vector<int> j, x;
+    HostInts j, x;
     std::vector<int> pivcol; // pivot column of each row
     std::vector<int> orig;   // originating row of the input
 };
@@ -1300,11 +1328,9 @@ void append_entries(HostU &U, const int2 *dent, i64 count, hipStream_t s)
     dx.alloc((size_t)count);
     hipLaunchKernelGGL(k_split_ent, dim3((unsigned)std::min<i64>((count + 255) / 256, 65536)), dim3(256), 0, s, (i64d)count, dent, dj.p, dx.p);
     HIPCHK(hipGetLastError());
-    const size_t old = U.j.size();
-    U.j.resize(old + (size_t)count);
-    U.x.resize(old + (size_t)count);
-    HIPCHK(hipMemcpyAsync(U.j.data() + old, dj.p, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(U.x.data() + old, dx.p, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, s));
+    int *hj = U.j.grow((size_t)count), *hx = U.x.grow((size_t)count);
+    HIPCHK(hipMemcpyAsync(hj, dj.p, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hx, dx.p, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
 }
 
@@ -1365,7 +1391,8 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
     const int Rp = G * chunk;
     const int xbytes = ND == 1 ? 1 : 2;
     const int lds_rows = 147456 / (DP_W * xbytes);
-    const bool inlds = chunk <= lds_rows;
+    const char *force_global = getenv("SPASM_AMD_PANEL_GLOBAL"); // tests: the in-place variant on small matrices
+    const bool inlds = chunk <= lds_rows && !(force_global && atoi(force_global));
     const int Cp = (int)ldc + 128; // (the GEMM stages whole tiles of 128 columns of Ut, starting at any multiple of 64)
     DevBuf<int> P, seq, candrow, invtab;
     DevBuf<signed char> Fd, Ut;
@@ -2166,12 +2193,15 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
 
     // ---- assemble the host LU (layout reference src/SpaSM.jl:262-270; ownership :273-277)
     const int r = (int)U.pivcol.size();
-    struct spasm_csr *Uc = spasm_csr_alloc(r, m, U.p.back(), prime, true);
+    struct spasm_csr *Uc = spasm_csr_alloc(r, m, 0, prime, true);
     if (!Uc) throw EngineError("out of host memory for U");
     memcpy(Uc->p, U.p.data(), sizeof(i64) * ((size_t)r + 1));
-    if (!U.j.empty()) {
-        memcpy(Uc->j, U.j.data(), sizeof(int) * U.j.size());
-        memcpy(Uc->x, U.x.data(), sizeof(int) * U.x.size());
+    if (!U.j.empty()) { // the buffers the entries were downloaded into become the arrays of U (malloc'ed, like spasm_csr_alloc's)
+        free(Uc->j);
+        free(Uc->x);
+        Uc->nzmax = (i64)U.j.size();
+        Uc->j = U.j.steal();
+        Uc->x = U.x.steal();
     }
     struct spasm_lu *N = (struct spasm_lu *)malloc(sizeof *N);
     const int plen = std::max(std::max(n, m), 1);

@@ -736,3 +736,32 @@ def test_consumers_accept_pivots_that_are_not_leftmost(S, O, n, m, p, density, s
     Ud = np.array(fact.U.todense().tolist(), dtype=object) % p
     Xd = np.array(X.todense().tolist(), dtype=object) % p
     assert ((Xd.dot(Ud) - (D % p)) % p == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(SPASM_AMD_DENSE_KB="128"), dict(SPASM_AMD_PANEL_GLOBAL="1", SPASM_AMD_DENSE_KB="192"),
+                                 dict(SPASM_AMD_MEM_BUDGET_MB="4"), dict(SPASM_AMD_DENSE_F64="1")],
+                         ids=["several_blocks", "panel_rows_in_global_memory", "dense_W_in_column_slabs", "f64_panels"])
+@pytest.mark.parametrize("kind,n,m,kw,prime", [(2, 4000, 1600, dict(row_nnz=40), 127), (1, 1500, 1200, dict(row_nnz=30), 65521)],
+                         ids=["p127_one_digit", "p65521_two_digits"])
+def test_dense_finish_variants(S, O, monkeypatch, env, kind, n, m, kw, prime):
+    """The code paths of the dense finish that default sizes only reach on large inputs, forced on small ones: several
+    1024-column blocks (two-level updates), the panel kernel working in global memory instead of LDS, the dense W built for a
+    few columns at a time, and the f64 panels primes above 2^16 use.  Same rank, pivot columns and kernel as the oracle; the
+    factorization verifies."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xD35E, **kw)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fact = S.echelonize(A, sparsity_threshold=0.1)
+    rounds = S.last_rounds()
+    for k in env:
+        monkeypatch.delenv(k)
+    if "SPASM_AMD_MEM_BUDGET_MB" not in env or kind == 2:
+        assert rounds[-1]["nnz_out"] == -1, rounds   # the round went straight to the dense finish
+    # (with a 4 MB budget the row sample of the p = 65521 case does not fit, so no estimate is made and the round is built sparse
+    # before the finish takes it; the Macaulay-like case estimates from columns and builds its dense W in slabs)
+    olu = O.echelonize(A)
+    assert fact.r == olu.r
+    assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
+    assert S.kernel(fact).rows() == O.kernel(olu).rows()
+    assert S.factorization_verify(A, fact, 9)
