@@ -44,7 +44,8 @@ struct PanelSync {          // reset by k_panel_load before every k_panel_lu lau
 };
 
 // ---- P[j][i] = D[i][c0 + j] (j < w; 0 beyond), i < R; rows R .. Rp-1 are zero
-__global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w, const int *__restrict__ D, i64d ldc, int *__restrict__ P, PanelSync *sy)
+template <typename DT>
+__global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w, const DT *__restrict__ D, i64d ldc, int *__restrict__ P, PanelSync *sy)
 {
     __shared__ int tile[DP_W][DP_W + 1];
     const int i0 = blockIdx.x * 64;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w
     for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, j = idx & 63;
         const int i = i0 + r;
-        tile[j][r] = (i < R && j < w) ? D[(i64d)i * ldc + c0 + j] : 0;
+        tile[j][r] = (i < R && j < w) ? (int)D[(i64d)i * ldc + c0 + j] : 0;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
@@ -276,9 +277,9 @@ __device__ __forceinline__ void zp_digits(const ZpField &F, int v, int &d0, int 
 
 // ---- after k_panel_lu: the panel's columns of D (non-pivot rows: zero; the panel's pivot rows: normalised), the multipliers as
 // digit planes F[d][i][slot0 + s] (0 where row i was a pivot already when pivot s was elected), and mtri.
-template <int ND>
+template <int ND, typename DT>
 __global__ __launch_bounds__(256) void k_panel_store(int R, int Rp, int c0, int w, ZpField F, const int *__restrict__ P, const int *__restrict__ seq,
-                                                    int *__restrict__ D, i64d ldc, PanelInfo *__restrict__ info, signed char *__restrict__ Fd, i64d fplane,
+                                                    DT *__restrict__ D, i64d ldc, PanelInfo *__restrict__ info, signed char *__restrict__ Fd, i64d fplane,
                                                     int KB, int slot0)
 {
     __shared__ int tile[DP_W][DP_W + 1];
@@ -330,14 +331,14 @@ __global__ __launch_bounds__(256) void k_panel_store(int R, int Rp, int c0, int 
             if (j == ct) v = 1;
             else if (j > ct) v = zp_mul(F, s_inv[t], tile[j][r]);
         }
-        D[(i64d)i * ldc + c0 + j] = v;
+        D[(i64d)i * ldc + c0 + j] = (DT)v;
     }
 }
 
 // ---- the pivot rows of one panel on the columns [ja, jb): u_t = inv_t (D[p_t][j] - sum_{s<t} mtri[t][s] u_s); D[p_t][j] = u_t and
 // the digit planes Ut[d][j][slot0 + t].  One thread per column.
-template <int ND>
-__global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, int *__restrict__ D, i64d ldc, const PanelInfo *__restrict__ info,
+template <int ND, typename DT>
+__global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, DT *__restrict__ D, i64d ldc, const PanelInfo *__restrict__ info,
                                                 signed char *__restrict__ Ut, i64d uplane, int KB, int slot0)
 {
     __shared__ int s_m[DP_W * DP_W];
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, int *
             for (int s = 0; s < t; s++) acc -= (long long)s_m[t * DP_W + s] * (long long)u[s]; // |term| < 2^30, 64 terms
             const int v = zp_mul(F, s_inv[t], zp_reduce(F, acc));
             u[t] = v;
-            D[(i64d)s_row[t] * ldc + j] = v;
+            D[(i64d)s_row[t] * ldc + j] = (DT)v;
             int d0, d1;
             zp_digits(F, v, d0, d1);
             w0[t >> 2] |= (d0 & 255) << (8 * (t & 3));
@@ -389,8 +390,8 @@ __global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, int *
 // C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 #define GI_LDS_STRIDE 80
 #define GI_BAND 32
-template <int ND, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, int *__restrict__ D, i64d ldc, const int *__restrict__ seq,
+template <int ND, int WM, int WN, int TM, int TN, typename DT>
+__global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, DT *__restrict__ D, i64d ldc, const int *__restrict__ seq,
                                                     const int *__restrict__ rows, int nrows, const signed char *__restrict__ Fd, i64d fplane,
                                                     const signed char *__restrict__ Ut, i64d uplane, int KB, int ntm, int ntn)
 {
@@ -499,16 +500,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k
                 const int mrow = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int gi = s_gi[mrow];
                 if (gi < 0 || col >= jb) continue;
-                int *d = D + (i64d)gi * ldc + col;
+                DT *d = D + (i64d)gi * ldc + col;
                 if (ND == 1) {
                     // |acc| <= K * 127^2 < 2^25 for K <= 2048: 32-bit lazy reduction (|x / p| < 2^22) and one correction
-                    int x = zp_small_lazy(*d - acc[0][m][n][r], -F.finvp, (int)F.p);
+                    int x = zp_small_lazy((int)*d - acc[0][m][n][r], -F.finvp, (int)F.p);
                     if (x > (int)F.halfp) x -= (int)F.p;
                     else if (x < (int)F.mhalfp) x += (int)F.p;
-                    *d = x;
+                    *d = (DT)x;
                 } else {
                     const long long v = (long long)acc[0][m][n][r] + (long long)acc[A1][m][n][r] * 256 + (long long)acc[A2][m][n][r] * 65536;
-                    *d = zp_reduce(F, (long long)*d - v);
+                    *d = (DT)zp_reduce(F, (long long)*d - v);
                 }
             }
         }

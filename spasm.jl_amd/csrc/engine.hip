@@ -13,6 +13,7 @@
 #include <vector>
 #include <memory>
 #include <stdexcept>
+#include <type_traits>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -1371,7 +1372,18 @@ i64 dense_max_entries()
 // The elimination proper for primes below 2^16 (dense.hpp): panels in a persistent cooperative kernel, int8 MFMA updates in two
 // levels.  Fills pivrow_of_col; returns false when the shape is outside what the panel kernel takes (the caller then uses the
 // f64 panels).
-bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F, DevBuf<int> &pivrow_of_col, hipStream_t s)
+// which element type the dense matrix of a finish gets: bytes / shorts when the int8 path of dense.hpp will take it (its block
+// updates are bound by reading and writing D), ints otherwise (f64 panels, rank-1 updates)
+int dense_elem_bytes(const ZpField &F, i64 R)
+{
+    const char *force64 = getenv("SPASM_AMD_DENSE_F64"); // diagnostics: the f64 panels for every prime
+    if (!F.small || (force64 && atoi(force64))) return 4;
+    if ((R + 255) / 256 > 65536) return 4; // more rows than the panel kernel takes (64 per thread of 256 workgroups)
+    return F.p <= 255 ? 1 : 2;
+}
+
+template <typename DT>
+bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, DevBuf<int> &pivrow_of_col, hipStream_t s)
 {
     static int num_cu = 0;
     if (!num_cu) {
@@ -1431,18 +1443,18 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
         const int ntm = cdiv(rows ? nrows : R, 128);
         if (ND == 1) {
             const int ntn = cdiv(jb - ja, 128);
-            hipLaunchKernelGGL((k_gemm_i8<1, 2, 2, 2, 2>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows,
+            hipLaunchKernelGGL((k_gemm_i8<1, 2, 2, 2, 2, DT>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows,
                                Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB, ntm, ntn);
         } else {
             const int ntn = cdiv(jb - ja, 64);
-            hipLaunchKernelGGL((k_gemm_i8<2, 4, 1, 1, 2>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows,
+            hipLaunchKernelGGL((k_gemm_i8<2, 4, 1, 1, 2, DT>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows,
                                Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB, ntm, ntn);
         }
     };
     auto trsm = [&](int q, int ja, int jb) {
         if (jb <= ja) return;
-        if (ND == 1) hipLaunchKernelGGL((k_trsm_i8<1>), dim3(cdiv(jb - ja, 64)), dim3(64), 0, s, ja, jb, F, D.p, (i64d)ldc, info.p + q, Ut.p, (i64d)uplane, KB, q * DP_W);
-        else hipLaunchKernelGGL((k_trsm_i8<2>), dim3(cdiv(jb - ja, 64)), dim3(64), 0, s, ja, jb, F, D.p, (i64d)ldc, info.p + q, Ut.p, (i64d)uplane, KB, q * DP_W);
+        if (ND == 1) hipLaunchKernelGGL((k_trsm_i8<1, DT>), dim3(cdiv(jb - ja, 64)), dim3(64), 0, s, ja, jb, F, D.p, (i64d)ldc, info.p + q, Ut.p, (i64d)uplane, KB, q * DP_W);
+        else hipLaunchKernelGGL((k_trsm_i8<2, DT>), dim3(cdiv(jb - ja, 64)), dim3(64), 0, s, ja, jb, F, D.p, (i64d)ldc, info.p + q, Ut.p, (i64d)uplane, KB, q * DP_W);
     };
     for (int b0 = 0; b0 < C; b0 += KB) {
         const int b1 = std::min(b0 + KB, C);
@@ -1451,7 +1463,7 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
         int q = 0;
         for (int c0 = b0; c0 < b1; c0 += DP_W, q++) {
             const int c1 = std::min(c0 + DP_W, b1), w = c1 - c0;
-            hipLaunchKernelGGL(k_panel_load, dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, D.p, (i64d)ldc, P.p, sync.p);
+            hipLaunchKernelGGL((k_panel_load<DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, D.p, (i64d)ldc, P.p, sync.p);
             {
                 int a_Rp = Rp, a_chunk = chunk, a_w = w, a_c0 = c0;
                 ZpField a_F = F;
@@ -1466,8 +1478,8 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
                                  : ND == 1 ? (const void *)k_panel_lu<true, 1024, signed char> : (const void *)k_panel_lu<true, 1024, short>;
                 HIPCHK(hipLaunchCooperativeKernel(fn, dim3(G), dim3(1024), args, (unsigned)lds, s));
             }
-            if (ND == 1) hipLaunchKernelGGL((k_panel_store<1>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
-            else hipLaunchKernelGGL((k_panel_store<2>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
+            if (ND == 1) hipLaunchKernelGGL((k_panel_store<1, DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
+            else hipLaunchKernelGGL((k_panel_store<2, DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
             // inside the block: the panel's pivot rows, then everybody else, K = 64
             trsm(q, c1, b1);
             gemm(c1, b1, q * DP_W, DP_W, nullptr, 0);
@@ -1505,8 +1517,11 @@ bool dense_eliminate_i8(DevBuf<int> &D, int R, int C, i64 ldc, const ZpField &F,
 
 // Leftmost-pivot elimination of a dense R x C matrix D (row-major, leading dimension ldc, residues mod p) whose column c is
 // column clist[c] of the matrix and whose row r comes from row row_orig[r] of the input; the pivot rows found are appended to U.
-int dense_eliminate(DevBuf<int> &D, int R, int C, i64 ldc, const int *clist, const int *row_orig, const ZpField &F, HostU &U, hipStream_t s)
+template <typename DT>
+int dense_eliminate(DevBuf<DT> &D, int R, int C, i64 ldc, const int *clist, const int *row_orig, const ZpField &F, HostU &U, hipStream_t s)
 {
+    const double te0 = spasm_wtime();
+    double te1 = te0;
     Scanner scan;
     DevBuf<int> is_piv, pivrow_of_col, prow, fcol;
     DevBuf<DenseState> st;
@@ -1517,47 +1532,51 @@ int dense_eliminate(DevBuf<int> &D, int R, int C, i64 ldc, const int *clist, con
     st.alloc(1);
     is_piv.zero(s); st.zero(s);
     const int rc = std::max(R, C);
-    const char *force64 = getenv("SPASM_AMD_DENSE_F64"); // diagnostics: the f64 panels for every prime
-    if (F.small && !(force64 && atoi(force64)) && dense_eliminate_i8(D, R, C, ldc, F, pivrow_of_col, s)) {
-        // (done: pivrow_of_col is filled, D holds the echelon form)
-    } else if (F.p <= ((i64)1 << 24)) {
-        // blocked: panels of DPB columns, f64-MFMA trailing update (exact: 64 * (p/2)^2 < 2^53)
-        const i64 R64 = ((i64)R + 63) / 64 * 64, ldu = ldc;
-        DevBuf<double> Lm, Upan;
-        DevBuf<int> pan_row, pan_inv;
-        Lm.alloc((size_t)R64 * DPB);
-        Upan.alloc((size_t)DPB * (size_t)ldu);
-        pan_row.alloc(DPB);
-        pan_inv.alloc(DPB);
-        for (int c0 = 0; c0 < C; c0 += DPB) {
-            const int c1 = std::min(c0 + DPB, C);
-            Lm.zero(s);
-            Upan.zero(s);
-            for (int c = c0; c < c1; c++) {
-                hipLaunchKernelGGL(k_panel_find, dim3(1), dim3(1024), 0, s, c, c0, c1, R, F, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, prow.p,
-                                   pan_row.p, pan_inv.p, st.p);
-                hipLaunchKernelGGL(k_panel_elim2, dim3(R), dim3(64), 0, s, c, c1, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, Lm.p, st.p);
-            }
-            HIPCHK(hipGetLastError());
-            if (c1 < C) {
-                hipLaunchKernelGGL(k_panel_trsm2, dim3(cdiv(C - c1, 64)), dim3(64), 0, s, c1, C, F, D.p, (i64d)ldc, Lm.p, pan_row.p, pan_inv.p, Upan.p,
-                                   (i64d)ldu, st.p);
-                hipLaunchKernelGGL(k_dense_gemm, dim3((unsigned)(R64 / 64), cdiv(C - c1, 64)), dim3(256), 0, s, c1, R, C, F, D.p, (i64d)ldc, Lm.p,
-                                   Upan.p, (i64d)ldu, is_piv.p, st.p);
-                HIPCHK(hipGetLastError());
-            }
-        }
-        HIPCHK(hipStreamSynchronize(s)); // Lm / Upan go out of scope
+    if constexpr (!std::is_same<DT, int>::value) {
+        // narrow D: the int8 path (dense_elem_bytes has checked that it applies); pivrow_of_col is filled, D holds the echelon form
+        if (!dense_eliminate_i8(D, R, C, ldc, F, pivrow_of_col, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
     } else {
-        for (int c = 0; c < C; c++) {
-            hipLaunchKernelGGL(k_dense_find, dim3(1), dim3(1024), 0, s, c, R, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, st.p);
-            hipLaunchKernelGGL(k_dense_scale, dim3(cdiv(rc, 256)), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, st.p);
-            hipLaunchKernelGGL(k_dense_store_prow, dim3(cdiv(C, 256)), dim3(256), 0, s, c, C, D.p, (i64d)ldc, prow.p, st.p);
-            hipLaunchKernelGGL(k_dense_elim, dim3(cdiv(C - c, 256), R), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, prow.p, fcol.p, st.p);
-            if ((c & 255) == 255) HIPCHK(hipGetLastError());
+        if (F.p <= ((i64)1 << 24)) {
+            // blocked: panels of DPB columns, f64-MFMA trailing update (exact: 64 * (p/2)^2 < 2^53)
+            const i64 R64 = ((i64)R + 63) / 64 * 64, ldu = ldc;
+            DevBuf<double> Lm, Upan;
+            DevBuf<int> pan_row, pan_inv;
+            Lm.alloc((size_t)R64 * DPB);
+            Upan.alloc((size_t)DPB * (size_t)ldu);
+            pan_row.alloc(DPB);
+            pan_inv.alloc(DPB);
+            for (int c0 = 0; c0 < C; c0 += DPB) {
+                const int c1 = std::min(c0 + DPB, C);
+                Lm.zero(s);
+                Upan.zero(s);
+                for (int c = c0; c < c1; c++) {
+                    hipLaunchKernelGGL(k_panel_find, dim3(1), dim3(1024), 0, s, c, c0, c1, R, F, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, prow.p,
+                                       pan_row.p, pan_inv.p, st.p);
+                    hipLaunchKernelGGL(k_panel_elim2, dim3(R), dim3(64), 0, s, c, c1, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, Lm.p, st.p);
+                }
+                HIPCHK(hipGetLastError());
+                if (c1 < C) {
+                    hipLaunchKernelGGL(k_panel_trsm2, dim3(cdiv(C - c1, 64)), dim3(64), 0, s, c1, C, F, D.p, (i64d)ldc, Lm.p, pan_row.p, pan_inv.p, Upan.p,
+                                       (i64d)ldu, st.p);
+                    hipLaunchKernelGGL(k_dense_gemm, dim3((unsigned)(R64 / 64), cdiv(C - c1, 64)), dim3(256), 0, s, c1, R, C, F, D.p, (i64d)ldc, Lm.p,
+                                       Upan.p, (i64d)ldu, is_piv.p, st.p);
+                    HIPCHK(hipGetLastError());
+                }
+            }
+            HIPCHK(hipStreamSynchronize(s)); // Lm / Upan go out of scope
+        } else {
+            for (int c = 0; c < C; c++) {
+                hipLaunchKernelGGL(k_dense_find, dim3(1), dim3(1024), 0, s, c, R, D.p, (i64d)ldc, is_piv.p, pivrow_of_col.p, st.p);
+                hipLaunchKernelGGL(k_dense_scale, dim3(cdiv(rc, 256)), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, is_piv.p, prow.p, fcol.p, st.p);
+                hipLaunchKernelGGL(k_dense_store_prow, dim3(cdiv(C, 256)), dim3(256), 0, s, c, C, D.p, (i64d)ldc, prow.p, st.p);
+                hipLaunchKernelGGL(k_dense_elim, dim3(cdiv(C - c, 256), R), dim3(256), 0, s, c, R, C, F, D.p, (i64d)ldc, prow.p, fcol.p, st.p);
+                if ((c & 255) == 255) HIPCHK(hipGetLastError());
+            }
         }
     }
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    te1 = spasm_wtime();
     // extract the pivot rows
     DevBuf<int> pflag, pscan;
     pflag.alloc((size_t)C + 1); pscan.alloc((size_t)C + 1);
@@ -1571,7 +1590,7 @@ int dense_eliminate(DevBuf<int> &D, int R, int C, i64 ldc, const int *clist, con
     DevBuf<i64d> ulen, uoff;
     ulen.alloc((size_t)npd + 1); uoff.alloc((size_t)npd + 1);
     ulen.zero(s);
-    hipLaunchKernelGGL(k_dense_count, dim3(C), dim3(256), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, ulen.p);
+    hipLaunchKernelGGL((k_dense_count<DT>), dim3(C), dim3(256), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, ulen.p);
     HIPCHK(hipGetLastError());
     scan.exclusive(ulen.p, uoff.p, (size_t)npd + 1, s);
     i64d tot = 0;
@@ -1580,7 +1599,7 @@ int dense_eliminate(DevBuf<int> &D, int R, int C, i64 ldc, const int *clist, con
     DevBuf<int2> Ufull;
     DevBuf<int> pivcol, porig;
     Ufull.alloc((size_t)tot + 1); pivcol.alloc((size_t)npd + 1); porig.alloc((size_t)npd + 1);
-    hipLaunchKernelGGL(k_dense_emit, dim3(C), dim3(64), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, uoff.p, clist, row_orig,
+    hipLaunchKernelGGL((k_dense_emit<DT>), dim3(C), dim3(64), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, uoff.p, clist, row_orig,
                        Ufull.p, pivcol.p, porig.p);
     HIPCHK(hipGetLastError());
     std::vector<i64d> off((size_t)npd + 1);
@@ -1596,7 +1615,8 @@ int dense_eliminate(DevBuf<int> &D, int R, int C, i64 ldc, const int *clist, con
         U.orig.push_back(po[(size_t)k]);
     }
     append_entries(U, Ufull.p, (i64)tot, s);
-    spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots\n", R, C, npd);
+    spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots [elimination %.2fs, rows of U to the host %.2fs]\n", R, C, npd, te1 - te0,
+               spasm_wtime() - te1);
     return npd;
 }
 
@@ -1628,15 +1648,24 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
     hipLaunchKernelGGL(k_col_map, dim3(cdiv(m, 256)), dim3(256), 0, s, m, cflag.p, cscan.p, cmap.p, clist.p);
     HIPCHK(hipGetLastError());
     const i64 ldc = ((i64)C + 63) / 64 * 64;
-    DevBuf<int> D, row_orig;
-    D.alloc((size_t)R * (size_t)ldc);
+    DevBuf<int> row_orig;
     row_orig.alloc((size_t)R + 1);
-    D.zero(s);
-    hipLaunchKernelGGL(k_dense_fill, dim3(cdiv((i64)R * 64, 256)), dim3(256), 0, s, R, rows.p, M.start.p, M.len.p, M.ent.p, cmap.p, D.p, (i64d)ldc);
-    HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_gather_int, dim3(cdiv(R, 256)), dim3(256), 0, s, R, rows.p, M.orig.p, row_orig.p);
     HIPCHK(hipGetLastError());
-    return dense_eliminate(D, R, C, ldc, clist.p, row_orig.p, F, U, s);
+    auto go = [&](auto tag) {
+        using DT = decltype(tag);
+        DevBuf<DT> D;
+        D.alloc((size_t)R * (size_t)ldc);
+        D.zero(s);
+        hipLaunchKernelGGL((k_dense_fill<DT>), dim3(cdiv((i64)R * 64, 256)), dim3(256), 0, s, R, rows.p, M.start.p, M.len.p, M.ent.p, cmap.p, D.p, (i64d)ldc);
+        HIPCHK(hipGetLastError());
+        return dense_eliminate(D, R, C, ldc, clist.p, row_orig.p, F, U, s);
+    };
+    switch (dense_elem_bytes(F, R)) {
+    case 1: return go((signed char)0);
+    case 2: return go((short)0);
+    default: return go((int)0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1763,18 +1792,18 @@ struct DenseW {
     }
 
     // the Schur rows of `rows` (local rows, device list) on the slab's columns: Dp[t][dcol0 + j]; Dp is zero there on entry
-    void rows_into(const int *rows, int nrows, int Cs, int *Dp, i64 ldc, int dcol0)
+    template <typename DT> void rows_into(const int *rows, int nrows, int Cs, DT *Dp, i64 ldc, int dcol0)
     {
         if (nrows == 0) return;
         row_lists(rows, nrows);
         constexpr int TEAM = 16;
-        hipLaunchKernelGGL((k_wd_own<TEAM>), dim3(cdiv((i64)nrows * TEAM, 256)), dim3(256), 0, s, nrows, rows, cur.start.p, cur.len.p, cur.ent.p, R.qinv_r.p,
+        hipLaunchKernelGGL((k_wd_own<TEAM, DT>), dim3(cdiv((i64)nrows * TEAM, 256)), dim3(256), 0, s, nrows, rows, cur.start.p, cur.len.p, cur.ent.p, R.qinv_r.p,
                            cmap_s.p, Dp, (i64d)ldc, dcol0);
         const int bt = threads_for(Cs);
         const unsigned gy = (unsigned)cdiv(Cs, 4 * bt);
-        if (R.F.small) hipLaunchKernelGGL((k_wd_rows<true>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, Wd.p, (i64d)Cs, Cs, Dp,
+        if (R.F.small) hipLaunchKernelGGL((k_wd_rows<true, DT>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, Wd.p, (i64d)Cs, Cs, Dp,
                                           (i64d)ldc, dcol0);
-        else hipLaunchKernelGGL((k_wd_rows<false>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, Wd.p, (i64d)Cs, Cs, Dp, (i64d)ldc,
+        else hipLaunchKernelGGL((k_wd_rows<false, DT>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, Wd.p, (i64d)Cs, Cs, Dp, (i64d)ldc,
                                 dcol0);
         HIPCHK(hipGetLastError());
     }
@@ -1824,31 +1853,42 @@ void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStrea
     DenseW &W = *prepared;
     const int C = W.C;
     if (C == 0 || nnp == 0) return;
+    const double tw0 = spasm_wtime();
     const i64 ldc = ((i64)C + 63) / 64 * 64;
-    DevBuf<int> D, row_orig;
-    D.alloc((size_t)nnp * (size_t)ldc);
-    D.zero(s);
-    row_orig.alloc((size_t)nnp + 1);
-    hipLaunchKernelGGL(k_gather_int, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, R.np_rows.p, cur.orig.p, row_orig.p);
-    HIPCHK(hipGetLastError());
-    // W for as many columns at a time as a third of the free memory holds
-    size_t fr = 0, tot = 0;
-    HIPCHK(hipMemGetInfo(&fr, &tot));
-    i64 budget = (i64)(fr / 3) + (i64)(W.Wd.n * sizeof(int));
-    if (const char *mb = getenv("SPASM_AMD_MEM_BUDGET_MB")) budget = std::max<i64>(atoll(mb), 1) << 18; // tests: several slabs
-    i64 Cs = std::min<i64>(ldc, std::max<i64>(64, budget / ((i64)std::max(R.npiv, 1) * 4) / 64 * 64));
-    int nslab = 0;
-    for (i64 s0 = 0; s0 < ldc; s0 += Cs, nslab++) {
-        const int w = (int)std::min<i64>(Cs, ldc - s0);
-        W.slab((int)s0, w, 0);
-        W.build_w(w);
-        W.rows_into(R.np_rows.p, nnp, w, D.p, ldc, (int)s0);
+    DevBuf<int> row_orig;
+    // (element type of D: dense_elem_bytes)
+    auto go = [&](auto tag) {
+        using DT = decltype(tag);
+        DevBuf<DT> D;
+        D.alloc((size_t)nnp * (size_t)ldc);
+        D.zero(s);
+        row_orig.alloc((size_t)nnp + 1);
+        hipLaunchKernelGGL(k_gather_int, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, R.np_rows.p, cur.orig.p, row_orig.p);
+        HIPCHK(hipGetLastError());
+        // W for as many columns at a time as a third of the free memory holds
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        i64 budget = (i64)(fr / 3) + (i64)(W.Wd.n * sizeof(int));
+        if (const char *mb = getenv("SPASM_AMD_MEM_BUDGET_MB")) budget = std::max<i64>(atoll(mb), 1) << 18; // tests: several slabs
+        i64 Cs = std::min<i64>(ldc, std::max<i64>(64, budget / ((i64)std::max(R.npiv, 1) * 4) / 64 * 64));
+        int nslab = 0;
+        for (i64 s0 = 0; s0 < ldc; s0 += Cs, nslab++) {
+            const int w = (int)std::min<i64>(Cs, ldc - s0);
+            W.slab((int)s0, w, 0);
+            W.build_w(w);
+            W.rows_into(R.np_rows.p, nnp, w, D.p, ldc, (int)s0);
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        spasm_logf("[echelonize/dense] Schur complement %d x %d through a dense W (%d pivots, %d levels, %d slab%s of columns) [%.2fs]\n", nnp, C, R.npiv,
+                   W.depth, nslab, nslab == 1 ? "" : "s", spasm_wtime() - tw0);
+        W.Wd.release();
+        dense_eliminate(D, nnp, C, ldc, W.clist.p, row_orig.p, R.F, U, s);
+    };
+    switch (dense_elem_bytes(R.F, nnp)) {
+    case 1: go((signed char)0); break;
+    case 2: go((short)0); break;
+    default: go((int)0); break;
     }
-    HIPCHK(hipStreamSynchronize(s));
-    spasm_logf("[echelonize/dense] Schur complement %d x %d through a dense W (%d pivots, %d levels, %d slab%s of columns)\n", nnp, C, R.npiv, W.depth,
-               nslab, nslab == 1 ? "" : "s");
-    W.Wd.release();
-    dense_eliminate(D, nnp, C, ldc, W.clist.p, row_orig.p, R.F, U, s);
 }
 
 // the L factor on the host, as it is collected: per chunk the rows it belongs to (original row of A per slot, entries per slot),

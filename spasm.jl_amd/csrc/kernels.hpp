@@ -2099,8 +2099,11 @@ __global__ void k_col_map(int m, const int *__restrict__ flag, const int *__rest
     else cmap[j] = -1;
 }
 
+// DT: the element type of the dense matrix -- int, or (dense.hpp path, primes below 2^16 / 2^8) short / signed char: the block
+// updates of the dense finish are bound by reading and writing D, and a balanced residue of such a prime fits
+template <typename DT>
 __global__ void k_dense_fill(int R, const int *__restrict__ rows, const i64d *__restrict__ start, const int *__restrict__ len,
-                             const int2 *__restrict__ ent, const int *__restrict__ cmap, int *__restrict__ D, i64d ldc)
+                             const int2 *__restrict__ ent, const int *__restrict__ cmap, DT *__restrict__ D, i64d ldc)
 {
     const int tl = threadIdx.x & 63;
     const int r = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -2110,7 +2113,7 @@ __global__ void k_dense_fill(int R, const int *__restrict__ rows, const i64d *__
     const int ln = len[row];
     for (int k = tl; k < ln; k += 64) {
         const int2 e = ent[st + k];
-        D[(i64d)r * ldc + cmap[e.x]] = e.y;
+        D[(i64d)r * ldc + cmap[e.x]] = (DT)e.y;
     }
 }
 
@@ -2183,7 +2186,8 @@ __global__ __launch_bounds__(256) void k_dense_elim(int c, int R, int C, ZpField
 }
 
 // U rows out of the eliminated dense matrix: pivot column c (dense index) -> row pivrow_of_col[c], entries at columns >= c
-__global__ void k_dense_count(int C, const int *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
+template <typename DT>
+__global__ void k_dense_count(int C, const DT *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
                               i64d *__restrict__ ulen)
 {
     // one workgroup per dense column; pscan = exclusive scan of (pivrow_of_col >= 0)
@@ -2200,7 +2204,8 @@ __global__ void k_dense_count(int C, const int *__restrict__ D, i64d ldc, const 
     if (threadIdx.x == 0) ulen[pscan[c]] = s_cnt;
 }
 
-__global__ void k_dense_emit(int C, const int *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
+template <typename DT>
+__global__ void k_dense_emit(int C, const DT *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
                              const i64d *__restrict__ uoff, const int *__restrict__ clist, const int *__restrict__ row_orig,
                              int2 *__restrict__ Ufull, int *__restrict__ pivcol, int *__restrict__ piv_orig)
 {
@@ -2213,7 +2218,7 @@ __global__ void k_dense_emit(int C, const int *__restrict__ D, i64d ldc, const i
     i64d pos = uoff[k];
     for (int j0 = c; j0 < C; j0 += 64) {
         const int j = j0 + lane;
-        const int v = j < C ? D[(i64d)p * ldc + j] : 0;
+        const int v = j < C ? (int)D[(i64d)p * ldc + j] : 0;
         const u64d m = __ballot(v != 0);
         if (v != 0) Ufull[pos + __popcll(m & lanemask_lt())] = make_int2(clist[j], v);
         pos += __popcll(m);
@@ -2355,9 +2360,9 @@ __global__ void k_wd_pfill(int nrows, const int *__restrict__ rows, const i64d *
 }
 
 // D[t][dcol0 + cmap_s[col]] = value for the entries on columns of the slab (D zero before; the columns of a row are distinct)
-template <int TEAM>
+template <int TEAM, typename DT>
 __global__ void k_wd_own(int nrows, const int *__restrict__ rows, const i64d *__restrict__ start, const int *__restrict__ len,
-                         const int2 *__restrict__ ent, const int *__restrict__ qinv_r, const int *__restrict__ cmap_s, int *__restrict__ D, i64d ldc,
+                         const int2 *__restrict__ ent, const int *__restrict__ qinv_r, const int *__restrict__ cmap_s, DT *__restrict__ D, i64d ldc,
                          int dcol0)
 {
     const int tl = threadIdx.x % TEAM;
@@ -2370,14 +2375,36 @@ __global__ void k_wd_own(int nrows, const int *__restrict__ rows, const i64d *__
         const int2 e = ent[st + k];
         if (qinv_r[e.x] >= 0) continue;
         const int j = cmap_s[e.x];
-        if (j >= 0) D[(i64d)t * ldc + dcol0 + j] = e.y;
+        if (j >= 0) D[(i64d)t * ldc + dcol0 + j] = (DT)e.y;
     }
 }
 
+// four consecutive elements of a dense row (the address is a multiple of four elements)
+__device__ __forceinline__ v4i32 dense_load4(const int *p) { return *(const v4i32 *)p; }
+__device__ __forceinline__ v4i32 dense_load4(const short *p)
+{
+    const int2 w = *(const int2 *)p;
+    return (v4i32){(int)(short)(w.x & 0xffff), w.x >> 16, (int)(short)(w.y & 0xffff), w.y >> 16};
+}
+__device__ __forceinline__ v4i32 dense_load4(const signed char *p)
+{
+    const int w = *(const int *)p;
+    return (v4i32){(int)(signed char)(w & 0xff), (int)(signed char)((w >> 8) & 0xff), (int)(signed char)((w >> 16) & 0xff), w >> 24};
+}
+__device__ __forceinline__ void dense_store4(int *p, v4i32 v) { *(v4i32 *)p = v; }
+__device__ __forceinline__ void dense_store4(short *p, v4i32 v)
+{
+    *(int2 *)p = make_int2((v.x & 0xffff) | (v.y << 16), (v.z & 0xffff) | (v.w << 16));
+}
+__device__ __forceinline__ void dense_store4(signed char *p, v4i32 v)
+{
+    *(int *)p = (v.x & 0xff) | ((v.y & 0xff) << 8) | ((v.z & 0xff) << 16) | (v.w << 24);
+}
+
 // dense Schur rows: D[t][dcol0 + j] += sum a * W[q][j] over the row's list (q, a).  blockIdx.x = row slot t
-template <bool SMALL>
+template <bool SMALL, typename DT>
 __global__ __launch_bounds__(256) void k_wd_rows(int nrows, ZpField F, const i64d *__restrict__ poff, const int2 *__restrict__ plist,
-                                                 const int *__restrict__ Wd, i64d ldw, int Cs, int *__restrict__ D, i64d ldc, int dcol0)
+                                                 const int *__restrict__ Wd, i64d ldw, int Cs, DT *__restrict__ D, i64d ldc, int dcol0)
 {
     const int t = blockIdx.x;
     const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
@@ -2389,8 +2416,8 @@ __global__ __launch_bounds__(256) void k_wd_rows(int nrows, ZpField F, const i64
         const int2 e = plist[k]; // (uniform over the workgroup)
         acc.fma(F, e.y, *(const v4i32 *)(Wd + (i64d)e.x * ldw + j));
     }
-    v4i32 *dst = (v4i32 *)(D + (i64d)t * ldc + dcol0 + j);
-    *dst = acc.finish(F, *dst);
+    DT *dst = D + (i64d)t * ldc + dcol0 + j;
+    dense_store4(dst, acc.finish(F, dense_load4(dst)));
     (void)nrows;
 }
 
