@@ -1360,18 +1360,15 @@ void append_round_U(HostU &U, const Round &R, const DevMat &A, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 // dense tail: leftmost-pivot elimination of the live part of `M`; its pivot rows are appended to U
 // ------------------------------------------------------------------------------------------------
-// cells (i32) the dense tail may hold: a third of the free device memory (beside it: 8-byte factors of 64 columns per row,
-// the U rows it emits), at least 2^31 cells
-i64 dense_max_entries()
+// cells the dense finish may hold: a third of the free device memory in bytes (beside it: the dense W of a slab of columns, the
+// digit planes of a block, the rows of U it emits), at least 2^31 cells; elem = bytes per cell (dense_elem_bytes)
+i64 dense_max_entries(int elem = 4)
 {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (i64)1 << 31;
-    return std::max<i64>((i64)1 << 31, (i64)(fr / 3) / 4);
+    return std::max<i64>((i64)1 << 31, (i64)(fr / 3) / std::max(elem, 1));
 }
 
-// The elimination proper for primes below 2^16 (dense.hpp): panels in a persistent cooperative kernel, int8 MFMA updates in two
-// levels.  Fills pivrow_of_col; returns false when the shape is outside what the panel kernel takes (the caller then uses the
-// f64 panels).
 // which element type the dense matrix of a finish gets: bytes / shorts when the int8 path of dense.hpp will take it (its block
 // updates are bound by reading and writing D), ints otherwise (f64 panels, rank-1 updates)
 int dense_elem_bytes(const ZpField &F, i64 R)
@@ -1988,7 +1985,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         {
             const i64 cfree = (i64)m - (i64)U.pivcol.size();
             const double cells = (double)cur_live * (double)cfree;
-            if (use_dense && cur_nnz > 0 && cells > 0 && cells <= (double)dense_max_entries() &&
+            if (use_dense && cur_nnz > 0 && cells > 0 && cells <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) &&
                 (double)cur_nnz > opts->sparsity_threshold * cells) {
                 spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                            cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
@@ -2021,7 +2018,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
                 // dense when the remainder is dense enough (the reference's rule) or small enough for the cubic work not to matter
                 // (2^28 cells: a 16384 x 16384 remainder); a large sparse remainder is better served by more sparse rounds
                 const bool worth = (double)cur_nnz > opts->sparsity_threshold * cells || cells <= (double)((i64)1 << 28);
-                if (use_dense && cells > 0 && cells <= (double)dense_max_entries() && worth) {
+                if (use_dense && cells > 0 && cells <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) && worth) {
                     spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                                cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
                     run_dense_tail(*cur, R->F, U, stream);
@@ -2066,7 +2063,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         double rec_per_row = 4.0 * (double)cur_nnz / (double)std::max(nnp, 1), slots_per_row = 0;
         double est_density = -1;
         const int free_now = m - (int)U.pivcol.size() - R->npiv;
-        const bool dense_possible = use_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries();
+        const bool dense_possible = use_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries(dense_elem_bytes(R->F, nnp));
         std::unique_ptr<DenseW> dw;
         if (nnp > 0 && dense_possible && !R->use_uinv) {
             // No Uinv: the rows of this round reach many pivots (or there are few rows), and the row sample below would walk those
