@@ -390,6 +390,18 @@ __global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, DT *_
 // C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 #define GI_LDS_STRIDE 80
 #define GI_BAND 32
+template <int ND, int APT, int BPT>
+__device__ __forceinline__ void gemm_i8_fetch(v4i32 (&ra)[ND][APT], v4i32 (&rb)[ND][BPT], const signed char *__restrict__ Fd, i64d fplane,
+                                              const signed char *__restrict__ Ut, i64d uplane, const i64d (&aoff)[APT], i64d boff, int KB, int ks)
+{
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+#pragma unroll
+        for (int u = 0; u < APT; u++) ra[d][u] = *(const v4i32 *)(Fd + (i64d)d * fplane + aoff[u] + ks);
+#pragma unroll
+        for (int u = 0; u < BPT; u++) rb[d][u] = *(const v4i32 *)(Ut + (i64d)d * uplane + boff + (i64d)(64 * u) * KB + ks);
+    }
+}
 template <int ND, int WM, int WN, int TM, int TN, typename DT>
 __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, DT *__restrict__ D, i64d ldc, const int *__restrict__ seq,
                                                     const int *__restrict__ rows, int nrows, const signed char *__restrict__ Fd, i64d fplane,
@@ -441,31 +453,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k
     int gia[APT];
 #pragma unroll
     for (int u = 0; u < APT; u++) gia[u] = s_gi[prow + 64 * u];
-    // software pipeline: the global loads of stage s + 1 are in flight while stage s is multiplied out of LDS
-    int4 ra[ND][APT], rb[ND][BPT];
-    auto fetch = [&](int ks) {
+    // software pipeline: the global loads of stage s + 1 are in flight while stage s is multiplied out of LDS.  (Check the
+    // ISA after touching this: when the staging registers end up in scratch memory every "prefetch" is waited for and spilled at once.)
+    // Rows that are skipped load row 0 instead of branching around the load; their products are never stored.
+    v4i32 ra[ND][APT], rb[ND][BPT]; // (native vectors: arrays of HIP's int4 struct stayed in scratch memory)
+    i64d aoff[APT];
 #pragma unroll
-        for (int d = 0; d < ND; d++) {
-            const signed char *fp = Fd + (i64d)d * fplane + k0 + ks + seg * 16;
-#pragma unroll
-            for (int u = 0; u < APT; u++) ra[d][u] = gia[u] >= 0 ? *(const int4 *)(fp + (i64d)gia[u] * KB) : make_int4(0, 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < BPT; u++) // (Ut is padded by 128 columns: always in range)
-                rb[d][u] = *(const int4 *)(Ut + (i64d)d * uplane + (i64d)(j0 + prow + 64 * u) * KB + k0 + ks + seg * 16);
-        }
-    };
-    fetch(0);
+    for (int u = 0; u < APT; u++) aoff[u] = (i64d)(gia[u] >= 0 ? gia[u] : 0) * KB + k0 + seg * 16;
+    const i64d boff = (i64d)(j0 + prow) * KB + k0 + seg * 16;
+    gemm_i8_fetch<ND, APT, BPT>(ra, rb, Fd, fplane, Ut, uplane, aoff, boff, KB, 0);
     for (int ks = 0; ks < K; ks += 64) {
         __syncthreads(); // the previous stage has been consumed
 #pragma unroll
         for (int d = 0; d < ND; d++) {
 #pragma unroll
-            for (int u = 0; u < APT; u++) *(int4 *)(&s_a[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = ra[d][u];
+            for (int u = 0; u < APT; u++) *(v4i32 *)(&s_a[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = ra[d][u];
 #pragma unroll
-            for (int u = 0; u < BPT; u++) *(int4 *)(&s_b[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = rb[d][u];
+            for (int u = 0; u < BPT; u++) *(v4i32 *)(&s_b[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = rb[d][u];
         }
         __syncthreads();
-        if (ks + 64 < K) fetch(ks + 64);
+        if (ks + 64 < K) gemm_i8_fetch<ND, APT, BPT>(ra, rb, Fd, fplane, Ut, uplane, aoff, boff, KB, ks + 64);
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             const int ko = kk * 32 + 16 * (lane >> 5);
@@ -490,27 +497,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k
                 }
         }
     }
+    // epilogue, tile by tile: the 16 elements of D a lane owns are loaded together (rows that are skipped read row 0 and are not
+    // stored), then reduced, then stored -- one round trip per tile, not one per element
 #pragma unroll
     for (int m = 0; m < TM; m++)
 #pragma unroll
         for (int n = 0; n < TN; n++) {
             const int col = j0 + (wn * TN + n) * 32 + (lane & 31);
+            const bool colok = col < jb;
+            const int ccol = colok ? col : ja;
+            int gis[16];
+            int dv[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int mrow = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int gi = s_gi[mrow];
-                if (gi < 0 || col >= jb) continue;
-                DT *d = D + (i64d)gi * ldc + col;
+                gis[r] = s_gi[mrow];
+                dv[r] = (int)D[(i64d)(gis[r] >= 0 ? gis[r] : 0) * ldc + ccol];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int x;
                 if (ND == 1) {
                     // |acc| <= K * 127^2 < 2^25 for K <= 2048: 32-bit lazy reduction (|x / p| < 2^22) and one correction
-                    int x = zp_small_lazy((int)*d - acc[0][m][n][r], -F.finvp, (int)F.p);
+                    x = zp_small_lazy(dv[r] - acc[0][m][n][r], -F.finvp, (int)F.p);
                     if (x > (int)F.halfp) x -= (int)F.p;
                     else if (x < (int)F.mhalfp) x += (int)F.p;
-                    *d = (DT)x;
                 } else {
                     const long long v = (long long)acc[0][m][n][r] + (long long)acc[A1][m][n][r] * 256 + (long long)acc[A2][m][n][r] * 65536;
-                    *d = (DT)zp_reduce(F, (long long)*d - v);
+                    x = zp_reduce(F, (long long)dv[r] - v);
                 }
+                if (gis[r] >= 0 && colok) D[(i64d)gis[r] * ldc + col] = (DT)x;
             }
         }
 }
