@@ -1676,7 +1676,8 @@ struct DenseW {
     hipStream_t s;
     Scanner scan;
     DevBuf<int> cflag, cscan, cmap, clist, cmap_s, order;
-    DevBuf<int> Wd;
+    DevBuf<unsigned char> Wd; // the dense W of the current slab, wbytes per element
+    int wbytes = 4;
     std::vector<int> lvl_off; // rows order[lvl_off[l-1] .. lvl_off[l]) make level l >= 1 (level 0 needs no combination)
     int C = 0, depth = 0;
     bool have_levels = false;
@@ -1747,19 +1748,28 @@ struct DenseW {
         levels();
         const int npiv = R.npiv;
         const i64 ldw = Cs;
-        Wd.ensure((size_t)std::max(npiv, 1) * (size_t)ldw);
-        HIPCHK(hipMemsetAsync(Wd.p, 0, (size_t)npiv * (size_t)ldw * sizeof(int), s));
-        constexpr int TEAM = 16;
-        hipLaunchKernelGGL((k_wd_seed<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, s, npiv, R.F, R.uhdr.p, R.UPN.p, cmap_s.p, Wd.p, (i64d)ldw);
-        HIPCHK(hipGetLastError());
+        Wd.ensure((size_t)std::max(npiv, 1) * (size_t)ldw * (size_t)wbytes);
+        HIPCHK(hipMemsetAsync(Wd.p, 0, (size_t)npiv * (size_t)ldw * (size_t)wbytes, s));
         const int bt = threads_for(Cs);
         const unsigned gy = (unsigned)cdiv(Cs, 4 * bt);
-        for (int l = 1; l <= depth; l++) {
-            const int lo = lvl_off[(size_t)l - 1], cnt = lvl_off[(size_t)l] - lo;
-            if (cnt == 0) continue;
-            if (R.F.small) hipLaunchKernelGGL((k_wd_level<true>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, Wd.p, (i64d)ldw, Cs);
-            else hipLaunchKernelGGL((k_wd_level<false>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, Wd.p, (i64d)ldw, Cs);
-            if ((l & 1023) == 0) HIPCHK(hipGetLastError());
+        auto go = [&](auto tag) {
+            using WT = decltype(tag);
+            WT *wd = (WT *)Wd.p;
+            constexpr int TEAM = 16;
+            hipLaunchKernelGGL((k_wd_seed<TEAM, WT>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, s, npiv, R.F, R.uhdr.p, R.UPN.p, cmap_s.p, wd, (i64d)ldw);
+            HIPCHK(hipGetLastError());
+            for (int l = 1; l <= depth; l++) {
+                const int lo = lvl_off[(size_t)l - 1], cnt = lvl_off[(size_t)l] - lo;
+                if (cnt == 0) continue;
+                if (R.F.small) hipLaunchKernelGGL((k_wd_level<true, WT>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, wd, (i64d)ldw, Cs);
+                else hipLaunchKernelGGL((k_wd_level<false, WT>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, wd, (i64d)ldw, Cs);
+                if ((l & 1023) == 0) HIPCHK(hipGetLastError());
+            }
+        };
+        switch (wbytes) {
+        case 1: go((signed char)0); break;
+        case 2: go((short)0); break;
+        default: go((int)0); break;
         }
         HIPCHK(hipGetLastError());
     }
@@ -1798,10 +1808,19 @@ struct DenseW {
                            cmap_s.p, Dp, (i64d)ldc, dcol0);
         const int bt = threads_for(Cs);
         const unsigned gy = (unsigned)cdiv(Cs, 4 * bt);
-        if (R.F.small) hipLaunchKernelGGL((k_wd_rows<true, DT>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, Wd.p, (i64d)Cs, Cs, Dp,
-                                          (i64d)ldc, dcol0);
-        else hipLaunchKernelGGL((k_wd_rows<false, DT>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, Wd.p, (i64d)Cs, Cs, Dp, (i64d)ldc,
-                                dcol0);
+        auto go = [&](auto tag) {
+            using WT = decltype(tag);
+            const WT *wd = (const WT *)Wd.p;
+            if (R.F.small) hipLaunchKernelGGL((k_wd_rows<true, DT, WT>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, wd, (i64d)Cs, Cs, Dp,
+                                              (i64d)ldc, dcol0);
+            else hipLaunchKernelGGL((k_wd_rows<false, DT, WT>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, wd, (i64d)Cs, Cs, Dp, (i64d)ldc,
+                                    dcol0);
+        };
+        switch (wbytes) {
+        case 1: go((signed char)0); break;
+        case 2: go((short)0); break;
+        default: go((int)0); break;
+        }
         HIPCHK(hipGetLastError());
     }
 
@@ -1865,9 +1884,10 @@ void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStrea
         // W for as many columns at a time as a third of the free memory holds
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
-        i64 budget = (i64)(fr / 3) + (i64)(W.Wd.n * sizeof(int));
+        W.wbytes = dense_elem_bytes(R.F, nnp) == 4 ? 4 : (R.F.p <= 255 ? 1 : 2); // (W holds residues like D does)
+        i64 budget = (i64)(fr / 3) + (i64)W.Wd.n;
         if (const char *mb = getenv("SPASM_AMD_MEM_BUDGET_MB")) budget = std::max<i64>(atoll(mb), 1) << 18; // tests: several slabs
-        i64 Cs = std::min<i64>(ldc, std::max<i64>(64, budget / ((i64)std::max(R.npiv, 1) * 4) / 64 * 64));
+        i64 Cs = std::min<i64>(ldc, std::max<i64>(64, budget / ((i64)std::max(R.npiv, 1) * W.wbytes) / 64 * 64));
         int nslab = 0;
         for (i64 s0 = 0; s0 < ldc; s0 += Cs, nslab++) {
             const int w = (int)std::min<i64>(Cs, ldc - s0);

@@ -2252,9 +2252,10 @@ __global__ void k_slab_cmap(int m, const int *__restrict__ cmap, int s0, int Cs,
     out[j] = o;
 }
 
-template <int TEAM>
+// WT: element type of the dense W (int, or short / signed char for primes below 2^16 / 2^8, like D)
+template <int TEAM, typename WT>
 __global__ void k_wd_seed(int npiv, ZpField F, const UHdr *__restrict__ uhdr, const int2 *__restrict__ UPN, const int *__restrict__ cmap_s,
-                          int *__restrict__ Wd, i64d ldw)
+                          WT *__restrict__ Wd, i64d ldw)
 {
     const int tl = threadIdx.x % TEAM;
     const int q = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
@@ -2263,7 +2264,7 @@ __global__ void k_wd_seed(int npiv, ZpField F, const UHdr *__restrict__ uhdr, co
     for (int k = tl; k < h.npn; k += TEAM) {
         const int2 e = UPN[(i64d)h.off + k];
         const int j = cmap_s[e.x];
-        if (j >= 0) Wd[(i64d)q * ldw + j] = zp_neg(F, e.y);
+        if (j >= 0) Wd[(i64d)q * ldw + j] = (WT)zp_neg(F, e.y);
     }
 }
 
@@ -2294,11 +2295,33 @@ template <> struct DenseAcc<false> { // lazy products |r| < 2^31.1 (ZpAcc<false>
     }
 };
 
+// four consecutive elements of a dense row (the address is a multiple of four elements)
+__device__ __forceinline__ v4i32 dense_load4(const int *p) { return *(const v4i32 *)p; }
+__device__ __forceinline__ v4i32 dense_load4(const short *p)
+{
+    const int2 w = *(const int2 *)p;
+    return (v4i32){(int)(short)(w.x & 0xffff), w.x >> 16, (int)(short)(w.y & 0xffff), w.y >> 16};
+}
+__device__ __forceinline__ v4i32 dense_load4(const signed char *p)
+{
+    const int w = *(const int *)p;
+    return (v4i32){(int)(signed char)(w & 0xff), (int)(signed char)((w >> 8) & 0xff), (int)(signed char)((w >> 16) & 0xff), w >> 24};
+}
+__device__ __forceinline__ void dense_store4(int *p, v4i32 v) { *(v4i32 *)p = v; }
+__device__ __forceinline__ void dense_store4(short *p, v4i32 v)
+{
+    *(int2 *)p = make_int2((v.x & 0xffff) | (v.y << 16), (v.z & 0xffff) | (v.w << 16));
+}
+__device__ __forceinline__ void dense_store4(signed char *p, v4i32 v)
+{
+    *(int *)p = (v.x & 0xff) | ((v.y & 0xff) << 8) | ((v.z & 0xff) << 16) | (v.w << 24);
+}
+
 // rows order[0 .. nrows) of W (one level of the pivot graph): W[q] -= sum v * W[c].  blockIdx.x = row, blockIdx.y = chunk of
 // 4 * blockDim.x columns; ldw and the slab width are multiples of 4
-template <bool SMALL>
+template <bool SMALL, typename WT>
 __global__ __launch_bounds__(256) void k_wd_level(int nrows, const int *__restrict__ order, ZpField F, const UHdr *__restrict__ uhdr,
-                                                  const int2 *__restrict__ UPP, int *__restrict__ Wd, i64d ldw, int Cs)
+                                                  const int2 *__restrict__ UPP, WT *__restrict__ Wd, i64d ldw, int Cs)
 {
     const int q = order[blockIdx.x];
     const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
@@ -2308,11 +2331,11 @@ __global__ __launch_bounds__(256) void k_wd_level(int nrows, const int *__restri
     const int2 *up = UPP + (i64d)h.off;
     for (int k = 0; k < h.npp; k++) {
         const int2 e = up[k]; // (uniform over the workgroup)
-        const v4i32 w = *(const v4i32 *)(Wd + (i64d)e.x * ldw + j);
+        const v4i32 w = dense_load4(Wd + (i64d)e.x * ldw + j);
         acc.fma(F, zp_neg(F, e.y), w);
     }
-    v4i32 *dst = (v4i32 *)(Wd + (i64d)q * ldw + j);
-    *dst = acc.finish(F, *dst);
+    WT *dst = Wd + (i64d)q * ldw + j;
+    dense_store4(dst, acc.finish(F, dense_load4(dst)));
     (void)nrows;
 }
 
@@ -2379,32 +2402,10 @@ __global__ void k_wd_own(int nrows, const int *__restrict__ rows, const i64d *__
     }
 }
 
-// four consecutive elements of a dense row (the address is a multiple of four elements)
-__device__ __forceinline__ v4i32 dense_load4(const int *p) { return *(const v4i32 *)p; }
-__device__ __forceinline__ v4i32 dense_load4(const short *p)
-{
-    const int2 w = *(const int2 *)p;
-    return (v4i32){(int)(short)(w.x & 0xffff), w.x >> 16, (int)(short)(w.y & 0xffff), w.y >> 16};
-}
-__device__ __forceinline__ v4i32 dense_load4(const signed char *p)
-{
-    const int w = *(const int *)p;
-    return (v4i32){(int)(signed char)(w & 0xff), (int)(signed char)((w >> 8) & 0xff), (int)(signed char)((w >> 16) & 0xff), w >> 24};
-}
-__device__ __forceinline__ void dense_store4(int *p, v4i32 v) { *(v4i32 *)p = v; }
-__device__ __forceinline__ void dense_store4(short *p, v4i32 v)
-{
-    *(int2 *)p = make_int2((v.x & 0xffff) | (v.y << 16), (v.z & 0xffff) | (v.w << 16));
-}
-__device__ __forceinline__ void dense_store4(signed char *p, v4i32 v)
-{
-    *(int *)p = (v.x & 0xff) | ((v.y & 0xff) << 8) | ((v.z & 0xff) << 16) | (v.w << 24);
-}
-
 // dense Schur rows: D[t][dcol0 + j] += sum a * W[q][j] over the row's list (q, a).  blockIdx.x = row slot t
-template <bool SMALL, typename DT>
+template <bool SMALL, typename DT, typename WT>
 __global__ __launch_bounds__(256) void k_wd_rows(int nrows, ZpField F, const i64d *__restrict__ poff, const int2 *__restrict__ plist,
-                                                 const int *__restrict__ Wd, i64d ldw, int Cs, DT *__restrict__ D, i64d ldc, int dcol0)
+                                                 const WT *__restrict__ Wd, i64d ldw, int Cs, DT *__restrict__ D, i64d ldc, int dcol0)
 {
     const int t = blockIdx.x;
     const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
@@ -2414,7 +2415,7 @@ __global__ __launch_bounds__(256) void k_wd_rows(int nrows, ZpField F, const i64
     DenseAcc<SMALL> acc;
     for (i64d k = lo; k < hi; k++) {
         const int2 e = plist[k]; // (uniform over the workgroup)
-        acc.fma(F, e.y, *(const v4i32 *)(Wd + (i64d)e.x * ldw + j));
+        acc.fma(F, e.y, dense_load4(Wd + (i64d)e.x * ldw + j));
     }
     DT *dst = D + (i64d)t * ldc + dcol0 + j;
     dense_store4(dst, acc.finish(F, dense_load4(dst)));
