@@ -247,6 +247,8 @@ struct Round {
     // timing
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t side = nullptr;     // the few rows of the largest table classes run beside the others
+    hipStream_t twin_s[3] = {nullptr, nullptr, nullptr}; // with `side`: the hash-table twins of the streaming classes, four abreast
+    hipEvent_t twin_ev[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t lane_s[4] = {nullptr, nullptr, nullptr, nullptr}; // further lanes of the streaming classes (lane 0 = the round's stream)
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -280,6 +282,8 @@ struct Round {
         for (auto &l : lane_s) if (l) (void)hipStreamDestroy(l);
         for (auto &e : ev_cls_done) if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
+        for (auto &e : twin_ev) if (e) (void)hipEventDestroy(e);
+        for (auto &l : twin_s) if (l) (void)hipStreamDestroy(l);
     }
 
     // ---- (1a) local candidates: best[j] = min over local rows with leftmost column j of (len, global row)
@@ -1077,17 +1081,33 @@ struct Round {
                 }
                 HIPCHK(hipStreamWaitEvent(lane_s[l], ev_fork, 0));
             }
+            // the hash-table twins (a handful of rows each: 20 - 50 us of one or two workgroups whatever the shard size) run two
+            // abreast on streams of their own: chained on one stream they were 0.15 ms of a 0.6 ms step of a 1/8 shard
+            // (HIP multiplexes streams over four hardware queues: with more than four streams in play a twin waiting for its event
+            // blocks the streaming kernels queued behind it -- 2.4 -> 3.0 ms per step with six streams; four it is)
+            static const int ntwin = [] { const char *e = getenv("SPASM_AMD_TWIN_STREAMS"); return std::min(4, std::max(1, e ? atoi(e) : 2)); }();
+            for (int t = 0; t < ntwin - 1; t++)
+                if (!twin_s[t]) {
+                    HIPCHK(hipStreamCreateWithFlags(&twin_s[t], hipStreamNonBlocking));
+                    HIPCHK(hipEventCreateWithFlags(&twin_ev[t], hipEventDisableTiming));
+                }
             for (int c = nhash - 1; c >= 0; c--) {
                 const int l = (nhash - 1 - c) % lanes;
                 hipStream_t lane = l ? lane_s[l] : stream;
                 launch_stream_cls(c, lane);
                 HIPCHK(hipEventRecord(ev_cls_done[c], lane));
-                HIPCHK(hipStreamWaitEvent(side, ev_cls_done[c], 0));
-                launch_class(c, side);
+                const int t = (nhash - 1 - c) % ntwin;
+                hipStream_t tw = t ? twin_s[t - 1] : side;
+                HIPCHK(hipStreamWaitEvent(tw, ev_cls_done[c], 0));
+                launch_class(c, tw);
             }
             for (int l = 1; l < lanes; l++) {
                 HIPCHK(hipEventRecord(lane_ev[l], lane_s[l]));
                 HIPCHK(hipStreamWaitEvent(stream, lane_ev[l], 0));
+            }
+            for (int t = 0; t < ntwin - 1; t++) {
+                HIPCHK(hipEventRecord(twin_ev[t], twin_s[t]));
+                HIPCHK(hipStreamWaitEvent(stream, twin_ev[t], 0));
             }
             launch_stream_fix(stream);
             launch_big(side);
