@@ -322,6 +322,7 @@ struct Round {
     // columns no pivot row touches (kernels.hpp, k_close_cols ..).  Renumbers the pivots: the new ones first.  Returns how many
     // were added.  Single device only (the proposals would need a second all-reduce in a sharded round).
     DevBuf<int> closed, colcnt, prop, newflag, newscan;
+    bool quiet_fallbacks = false; // a plan whose dry run sent no row past the first combine class: later runs skip those launches
     DevBuf<int> pivval; // the pivot entries before scaling (the diagonal of L), filled by build_U when want_pivval
     bool want_pivval = false;
     DevBuf<u64d> best2;
@@ -819,18 +820,22 @@ struct Round {
                 else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
                 HIPCHK(hipGetLastError());
             }
-            c.retry = overflow2_list.p;
-            c.retry_count = &ctr.p->combine_overflow;
-            c.overflow_list = overflow_list.p;
-            c.overflow_count = &ctr.p->solve_overflow;
-            {
-                constexpr int TEAM = 64, LOGC = 12, TPB = 64; // one wave per row, up to 2048 distinct pivots
-                const int grid = std::min(nrows, num_cu * 4);
-                if (F.small) hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, true>), dim3(grid), dim3(TPB), 0, stream, c);
-                else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
-                HIPCHK(hipGetLastError());
+            // (a plan that has seen its rows once knows whether anybody gets this far: three or four launches of ~8 us each, in
+            // order, are a tenth of the step of a 1/8 shard)
+            if (!quiet_fallbacks) {
+                c.retry = overflow2_list.p;
+                c.retry_count = &ctr.p->combine_overflow;
+                c.overflow_list = overflow_list.p;
+                c.overflow_count = &ctr.p->solve_overflow;
+                {
+                    constexpr int TEAM = 64, LOGC = 12, TPB = 64; // one wave per row, up to 2048 distinct pivots
+                    const int grid = std::min(nrows, num_cu * 4);
+                    if (F.small) hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, true>), dim3(grid), dim3(TPB), 0, stream, c);
+                    else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
+                    HIPCHK(hipGetLastError());
+                }
+                launch_chain(a, nrows, false); // what is left: chain classes
             }
-            launch_chain(a, nrows, false); // what is left: chain classes
         } else {
             launch_chain(a, nrows, true);
         }
@@ -2898,7 +2903,11 @@ void plan_dry_run(spasm_amd_schur_plan *P, i64 pool_guess)
     i64 tot2 = 0;
     // along W a row's stream is the sum of the runs of its entries on pivot columns: two runs that share pivot rows count them
     // twice, so these bounds can exceed the lists' -- size for both
-    if (R.use_w && !fl) tot2 = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, pool_guess);
+    if (R.use_w && !fl) {
+        tot2 = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, pool_guess);
+        const RoundCounters c2 = R.read_counters(); // the plan runs exactly this again: the same rows take the same classes
+        R.quiet_fallbacks = c2.combine_overflow == 0 && c2.solve_overflow == 0 && c2.solve_failed == 0;
+    }
     R.S.ent.ensure((size_t)std::max(tot, tot2) + 1);
 }
 
