@@ -2425,18 +2425,23 @@ static std::vector<int> pivot_topological_order(const struct spasm_csr *U, const
         if (a >= 0) { if (pc[(size_t)a] < 0) named++; pc[(size_t)a] = j; }
     }
     if (named != r) throw EngineError(w + ": qinv does not name one pivot column per row of U");
+    // (one pass over the entries of U, on all host threads: U has 10^9 entries on the large cases)
+    int bad_unit = 0, unordered = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(| : bad_unit, unordered)
     for (int a = 0; a < r; a++) {
         bool unit = false;
-        for (i64 k = U->p[a]; k < U->p[a + 1]; k++) if (U->j[k] == pc[(size_t)a] && U->x[k] == 1) unit = true;
-        if (!unit) throw EngineError(w + ": pivots of U must be 1");
-    }
-    std::vector<int> perm((size_t)std::max(r, 1));
-    bool ordered = true;
-    for (int a = 0; a < r && ordered; a++)
+        const int pca = pc[(size_t)a];
         for (i64 k = U->p[a]; k < U->p[a + 1]; k++) {
-            const int b = qinv[U->j[k]];
-            if (b >= 0 && b < a) { ordered = false; break; }
+            const int j = U->j[k];
+            if (j == pca) { if (U->x[k] == 1) unit = true; continue; }
+            const int b = qinv[j];
+            if (b >= 0 && b < a) unordered = 1;
         }
+        if (!unit) bad_unit = 1;
+    }
+    if (bad_unit) throw EngineError(w + ": pivots of U must be 1");
+    std::vector<int> perm((size_t)std::max(r, 1));
+    const bool ordered = !unordered;
     if (ordered) {
         for (int a = 0; a < r; a++) perm[(size_t)a] = a;
         return perm;
@@ -2756,6 +2761,7 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
     // pivot column of each row, unit pivots checked (reference src/SpaSM.jl:712), topological numbering
     std::vector<int> pc;
     const std::vector<int> perm = pivot_topological_order(U, qinv, "spasm_kernel", pc);
+    const double t_order = spasm_wtime();
     std::vector<int> idx_of((size_t)std::max(r, 1));
     for (int t = 0; t < r; t++) idx_of[(size_t)perm[(size_t)t]] = t;
 
@@ -2780,6 +2786,8 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
     hipStream_t s = nullptr;
     DevMat PM;
     upload_csr(U, 0, r, PM, s);
+    HIPCHK(hipStreamSynchronize(s));
+    const double t_upload = spasm_wtime();
     std::unique_ptr<Round> R(new Round());
     R->F = zp_field_make(prime);
     R->stream = s;
@@ -2795,6 +2803,8 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
     // Ut: row j = column j of U with entries labelled ridx(a)
     TransposeOut Ut;
     device_transpose(PM, r, nullptr, lab.p, 0, R->scan, s, Ut);
+    HIPCHK(hipStreamSynchronize(s));
+    const double t_transpose = spasm_wtime();
     DevMat T;
     T.n = m;
     T.m = r;
@@ -2847,6 +2857,8 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
         HIPCHK(hipStreamSynchronize(s));
         for (i64 q = 0; q < ktot; q++) { K->j[q] = ent[(size_t)q].x; K->x[q] = ent[(size_t)q].y; }
     }
+    spasm_logf("[kernel] pivot order %.2fs, U to the device %.2fs, transpose %.2fs, solves and K %.2fs\n", t_order - t0, t_upload - t_order,
+               t_transpose - t_upload, spasm_wtime() - t_transpose);
     spasm_logf("[kernel] done in %.1fs. NNZ(K) = %lld\n", spasm_wtime() - t0, (long long)spasm_nnz(K));
     return K;
 }

@@ -13,5 +13,5 @@ for r in S.last_rounds():
     print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k in ("round","rows_in","nnz_in","npiv","rows_out","nnz_out","nnz_reduced","ms_pivots","ms_solve","ms_scatter","dense")}, flush=True)
 if "--verify" in sys.argv:
     t0 = time.time(); ok = S.factorization_verify(A, fact, 1); print(f"factorization_verify {ok} in {time.time()-t0:.2f}s", flush=True)
-t0 = time.time(); K = S.kernel(fact); t1 = time.time()
+t0 = time.time(); K = S.kernel(fact, verbose=("-v" in sys.argv)); t1 = time.time()
 print(f"kernel {t1-t0:.3f}s dim {K.n} nnz(K) {S.nnz(K)}")
