@@ -203,6 +203,28 @@ def main():
             "per_class_rows": {"hash": d["rows_class"][:8], "stream": d["rows_class"][8:15]},
             "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"], "stream_fix_ms": round(d["ms_class"][15], 4),
         }
+        # beside the algorithmic bytes, (i) the measured HBM bytes of a whole round and (ii) the compulsory floor
+        # 8 (nnz(A) + nnz(U)) + 8 (n + r): every entry of A and of the pivot rows read once, one pointer pair per row
+        try:
+            Uc = lib.spasm_amd_schur_plan_fetch_U(plan, None, None)
+            if Uc:
+                nnz_u = int(lib.spasm_nnz(Uc))
+                lib.spasm_csr_free(Uc)
+                roofline["compulsory_floor_bytes"] = 8 * (int(d["nnz_in"]) + nnz_u) + 8 * (my_rows + int(d["npiv"]))
+        except Exception:
+            pass
+        if traffic is not None:
+            # the kernels every step launches once (streaming classes, plan, fix-ups, binning); the hash-table and combine kernels
+            # only see the few rows handed back, and their per-dispatch means in the profile include the building of W
+            step_kernels = ("k_wstream<", "k_wplan<", "k_stream_fix", "k_bin")
+            try:
+                fetch = sum(v["fetch_bytes"] for k, v in prof.items() if k.startswith(step_kernels))
+                write = sum(v["write_bytes"] for k, v in prof.items() if k.startswith(step_kernels))
+                roofline["round_traffic"] = {"fetch_bytes": fetch, "write_bytes": write, "source": tf,
+                                             "kernels": "k_wstream x7 + k_wplan + k_stream_fix + k_bin (PMC, mean per dispatch)",
+                                             "fetch_over_algorithmic_read": round(fetch / d["read_bytes"], 3) if d["read_bytes"] else None}
+            except Exception:
+                pass
         out = {
             "metric": "Schur nnz reduced/sec (GF(p) echelonize), 1Mx1M CSR",
             "value": value,
