@@ -455,32 +455,38 @@ extern "C" SPASM_API bool spasm_factorization_verify(const struct spasm_csr *A, 
     if ((int)order.size() != r) return false; // a cycle: not an echelon form under any permutation
     // (b) random combinations of the rows of A must reduce to zero
     const int trials = p < 65536 ? 8 : 2;
-    std::vector<uint64_t> y((size_t)std::max(m, 1));
-    Rng rng(seed ^ 0x5350415346564552ull);
+    // (the trials are independent: one host thread each, every trial with a generator of its own derived from the seed)
+    int failed = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : failed)
     for (int t = 0; t < trials; t++) {
-        std::fill(y.begin(), y.end(), 0);
-        for (int i = 0; i < n; i++) {
+        std::vector<uint64_t> y((size_t)std::max(m, 1), 0);
+        Rng rng(seed ^ 0x5350415346564552ull ^ ((uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull));
+        bool bad = false;
+        for (int i = 0; i < n && !bad; i++) {
             const uint64_t xi = rng.below(p);
             if (xi == 0) continue;
             for (i64 q = A->p[i]; q < A->p[i + 1]; q++) {
                 const int c = A->j[q];
-                if (c < 0 || c >= m) return false;
+                if (c < 0 || c >= m) { bad = true; break; }
                 y[(size_t)c] = (y[(size_t)c] + xi * res(A->x ? A->x[q] : 1) % p) % p; // xi, residue < 2^32: the product fits 64 bits
             }
         }
         // rows in topological order: row k touches, among pivot columns, only those of rows after it, so an eliminated column
         // stays zero
-        for (int k : order) {
-            const int j = pivcol[(size_t)k];
-            if (y[(size_t)j] == 0) continue;
-            const uint64_t c = y[(size_t)j];
-            for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
-                const size_t col = (size_t)U->j[q];
-                y[col] = (y[col] + (p - c * res(U->x[q]) % p)) % p;
+        if (!bad)
+            for (int k : order) {
+                const int j = pivcol[(size_t)k];
+                if (y[(size_t)j] == 0) continue;
+                const uint64_t c = y[(size_t)j];
+                for (i64 q = U->p[k]; q < U->p[k + 1]; q++) {
+                    const size_t col = (size_t)U->j[q];
+                    y[col] = (y[col] + (p - c * res(U->x[q]) % p)) % p;
+                }
             }
-        }
-        for (int j = 0; j < m; j++) if (y[(size_t)j] != 0) return false;
+        for (int j = 0; j < m && !bad; j++) if (y[(size_t)j] != 0) bad = true;
+        if (bad) failed = 1;
     }
+    if (failed) return false;
     // (c), (d): with L the check is two-sided
     if (fact->L) {
         const struct spasm_csr *L = fact->L;
