@@ -5,8 +5,9 @@
 // to right, the pivot of a column is the FIRST row, not yet a pivot, that holds a non-zero in it -- organised in two levels:
 //
 //   panel (64 columns)   copied transposed into P[64][rows]; ONE persistent cooperative kernel eliminates it column by column
-//                        with the rows of every workgroup resident in LDS and one grid barrier per column (k_panel_lu): the
-//                        election is an atomicMin per workgroup, the elected row travels through a 256-byte global record.
+//                        with the rows of every workgroup resident in LDS (as bytes / shorts) and one grid barrier per column
+//                        (k_panel_lu): every workgroup publishes its bid and its candidate row in a 320-byte record of
+//                        write-through stores, arrives on one of 64 counters, and reads the winner's record behind the barrier.
 //                        The multipliers stay in P where they were read, as in an in-place LU.
 //   block (KB columns)   the panels of a block update only the columns of the block (K = 64); the columns right of the block
 //                        are updated once per block with K = KB.
@@ -15,7 +16,8 @@
 //                        base-256 digits -- one for p < 2^8, two for p < 2^16 (three accumulators: d0*d0, d0*d1 + d1*d0, d1*d1)
 //                        -- and recombined in 64 bits, so the result is exact.
 // The multipliers F[row][slot] and the normalised pivot rows Ut[column][slot] are kept as digit planes with the K index
-// contiguous, the layout both MFMA operands want (16 consecutive k per lane).
+// contiguous, the layout both MFMA operands want (16 consecutive k per lane).  The dense matrix D itself is kept as bytes
+// (p < 2^8) or shorts (template parameter DT): its block updates are bound by reading and writing it.
 #pragma once
 
 #include "kernels.hpp"
