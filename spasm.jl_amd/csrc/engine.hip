@@ -323,6 +323,8 @@ struct Round {
     // were added.  Single device only (the proposals would need a second all-reduce in a sharded round).
     DevBuf<int> closed, colcnt, prop, newflag, newscan;
     bool quiet_fallbacks = false; // a plan whose dry run sent no row past the first combine class: later runs skip those launches
+    bool quiet_known = false;     // set once a plan's dry run is over: the rows and the matrix of its solves do not change any more
+    int gathered_n = -1;
     DevBuf<int> pivval; // the pivot entries before scaling (the diagonal of L), filled by build_U when want_pivval
     bool want_pivval = false;
     DevBuf<u64d> best2;
@@ -652,7 +654,7 @@ struct Round {
             const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), npool_words = NPOOL * POOL_STRIDE;
             const int span = std::max(std::max(nctr_words, npool_words), npiv + 1);
             hipLaunchKernelGGL(k_solve_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, npiv, (unsigned *)ctr.p, nctr_words, pool_ctr.p,
-                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p, sflag.p);
+                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p, sflag.p, (u64d *)nullptr);
             HIPCHK(hipGetLastError());
         }
         hipLaunchKernelGGL(k_uinv_records, dim3(cdiv(((i64)npiv + 1) * 8, 256)), dim3(256), 0, stream, npiv, UinvStart.p, UinvLen.p, UinvPool.p, uhdr.p,
@@ -707,8 +709,11 @@ struct Round {
             static_assert(sizeof(RoundCounters) % 4 == 0, "cleared word by word");
             const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), npool_words = NPOOL * POOL_STRIDE;
             const int span = std::max(std::max(nctr_words, npool_words), nrows + 1);
+            // (the counters of the plan kernel's own-entry regions are cleared here as well: one launch less per step)
+            const bool wmode = use_uinv && use_w && !force_lists && !self_idx && !want_idx;
+            if (wmode) own_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
             hipLaunchKernelGGL(k_solve_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, nrows, (unsigned *)ctr.p, nctr_words, pool_ctr.p,
-                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p, sflag.p);
+                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p, sflag.p, wmode ? own_ctr.p : (u64d *)nullptr);
             HIPCHK(hipGetLastError());
         }
         if (nrows == 0) return;
@@ -741,8 +746,12 @@ struct Round {
         if (use_uinv) {
             rstart.ensure((size_t)nrows + 1);
             rlen.ensure((size_t)nrows + 1);
-            hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, rstart.p, rlen.p);
-            HIPCHK(hipGetLastError());
+            // (a plan reduces the same rows of the same matrix every time: their (start, length) pairs are gathered once)
+            if (!(quiet_known && gathered_n == nrows)) {
+                hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, rstart.p, rlen.p);
+                HIPCHK(hipGetLastError());
+                gathered_n = nrows;
+            }
             CombineArgs c;
             c.nrows = nrows;
             c.self_idx = self_idx;
@@ -794,7 +803,6 @@ struct Round {
                 wp.own_base = (unsigned)(utotal + wtotal);
                 wp.own_cap = (u64d)own_total / (u64d)npool_active;
                 wp.own_ctr = own_ctr.p;
-                HIPCHK(hipMemsetAsync(own_ctr.p, 0, (size_t)NPOOL * POOL_STRIDE * sizeof(u64d), stream));
                 wp.Lstart = Lstart.p;
                 wp.Llen = Llen.p;
                 wp.bound = bound.p;
@@ -919,7 +927,7 @@ struct Round {
         S.m = m;
         nlaunch = 0;
         if (nrows == 0) return;
-        HIPCHK(hipMemsetAsync(class_count.p, 0, NCLASS * sizeof(int), stream));
+        // (class_count was cleared by the reset kernel of the solve that precedes every scatter)
         int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1; // 12-byte slots: the 2^14 table exceeds LDS
         // the streaming kernel goes along the rows of W (the plan kernel marks the rows it can take)
         const bool streaming = use_w && !building_w && !force_lists;
@@ -2919,6 +2927,7 @@ void plan_dry_run(spasm_amd_schur_plan *P, i64 pool_guess)
         tot2 = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, pool_guess);
         const RoundCounters c2 = R.read_counters(); // the plan runs exactly this again: the same rows take the same classes
         R.quiet_fallbacks = c2.combine_overflow == 0 && c2.solve_overflow == 0 && c2.solve_failed == 0;
+        R.quiet_known = true;
     }
     R.S.ent.ensure((size_t)std::max(tot, tot2) + 1);
 }

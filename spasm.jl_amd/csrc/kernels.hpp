@@ -1641,11 +1641,11 @@ __global__ void k_colinfo(int m, const int *__restrict__ qinv_r, const i64d *__r
 // cost): statistics and pool counters zero, class counts zero, every row's pivot-column mask "none", bound[n] = 0
 __global__ void k_solve_reset(int n, unsigned *__restrict__ ctr_words, int nctr_words, u64d *__restrict__ pool_ctr, int npool_words,
                               int *__restrict__ class_count, int nclass, i64d *__restrict__ bound, long long *__restrict__ pmask,
-                              int *__restrict__ sflag)
+                              int *__restrict__ sflag, u64d *__restrict__ own_ctr)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < nctr_words) ctr_words[t] = 0;
-    if (t < npool_words) pool_ctr[t] = 0;
+    if (t < npool_words) { pool_ctr[t] = 0; if (own_ctr) own_ctr[t] = 0; } // (the plan kernel's own-entry regions: same layout)
     if (t < nclass) class_count[t] = 0;
     if (t <= n) { pmask[t] = -1; sflag[t] = 0; }
     if (t == n) bound[n] = 0;
