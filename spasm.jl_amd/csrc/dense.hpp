@@ -4,7 +4,7 @@
 // datatype spasm_datatype_choose picks, prototypes reference src/SpaSM.jl:805-812, enum :373).  Same elimination -- columns left
 // to right, the pivot of a column is the FIRST row, not yet a pivot, that holds a non-zero in it -- organised in two levels:
 //
-//   panel (64 columns)   copied transposed into P[64][rows]; ONE persistent cooperative kernel eliminates it column by column
+//   panel (64 columns)   copied transposed into P[64][rows] (same element type as D); ONE persistent cooperative kernel eliminates it column by column
 //                        with the rows of every workgroup resident in LDS (as bytes / shorts) and one grid barrier per column
 //                        (k_panel_lu): every workgroup publishes its bid and its candidate row in a 320-byte record of
 //                        write-through stores, arrives on one of 64 counters, and reads the winner's record behind the barrier.
@@ -47,7 +47,7 @@ struct PanelSync {          // reset by k_panel_load before every k_panel_lu lau
 
 // ---- P[j][i] = D[i][c0 + j] (j < w; 0 beyond), i < R; rows R .. Rp-1 are zero
 template <typename DT>
-__global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w, const DT *__restrict__ D, i64d ldc, int *__restrict__ P, PanelSync *sy)
+__global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w, const DT *__restrict__ D, i64d ldc, DT *__restrict__ P, PanelSync *sy)
 {
     __shared__ int tile[DP_W][DP_W + 1];
     const int i0 = blockIdx.x * 64;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_panel_load(int R, int Rp, int c0, int w
     __syncthreads();
     for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
         const int j = idx >> 6, r = idx & 63;
-        if (i0 + r < Rp) P[(i64d)j * Rp + i0 + r] = tile[j][r];
+        if (i0 + r < Rp) P[(i64d)j * Rp + i0 + r] = (DT)tile[j][r];
     }
 }
 
@@ -153,10 +153,11 @@ __device__ __forceinline__ int zp_axpy_small(const ZpField &F, int a, int b, int
 // (L2 / MALL resident; only the owner of a row ever reads or writes it).  seq[i] = sequence number of the pivot row i became,
 // -1 while it is none.  candrow: 2 x gridDim.x records of DP_REC ints (the candidate row, the inverse of its entry in the current
 // column, the bid).
-// XT: how a residue is kept in LDS -- signed char for p < 2^8, short for p < 2^16 (balanced residues fit), so that 2304 / 1152 rows
-// per workgroup stay resident instead of 576; int for the in-place (global memory) variant.
+// XT: how a residue is kept, in P and in LDS -- signed char for p < 2^8, short for p < 2^16 (balanced residues fit), so that
+// 2304 / 1152 rows per workgroup stay resident in LDS instead of 576, and the in-place variant (more rows than that: it is bound by
+// streaming P through L2 / HBM once per column) moves a quarter / half of the bytes.
 template <bool INLDS, int NT, typename XT>
-__global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c0, ZpField F, int *__restrict__ P, int *__restrict__ seq,
+__global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c0, ZpField F, XT *__restrict__ P, int *__restrict__ seq,
                                                  int *__restrict__ pivrow_of_col, PanelInfo *__restrict__ info, PanelSync *sy, int *candrow,
                                                  DenseState *st, const int *__restrict__ invtab, unsigned long long *stamps)
 {
@@ -168,10 +169,10 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
     const int tid = threadIdx.x;
     const int base = blockIdx.x * chunk;
     const i64d xs = INLDS ? (i64d)chunk : (i64d)Rp; // stride between the columns of the row storage
-    XT *X = INLDS ? s_x : (XT *)(P + base); // (XT = int when !INLDS)
+    XT *X = INLDS ? s_x : P + base;
     if (INLDS) {
         for (int j = 0; j < DP_W; j++)
-            for (int r = tid; r < chunk; r += NT) s_x[j * chunk + r] = (XT)P[(i64d)j * Rp + base + r];
+            for (int r = tid; r < chunk; r += NT) s_x[j * chunk + r] = P[(i64d)j * Rp + base + r];
     }
     // the status of the rows this thread owns (r = tid + NT k): bit k set = not a pivot (yet)
     unsigned long long live = 0;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
     if (INLDS) {
         __syncthreads();
         for (int j = 0; j < DP_W; j++)
-            for (int r = tid; r < chunk; r += NT) P[(i64d)j * Rp + base + r] = (int)s_x[j * chunk + r];
+            for (int r = tid; r < chunk; r += NT) P[(i64d)j * Rp + base + r] = s_x[j * chunk + r];
     }
     if (blockIdx.x == 0 && tid == 0) {
         info->npp = npp;
@@ -280,7 +281,7 @@ __device__ __forceinline__ void zp_digits(const ZpField &F, int v, int &d0, int 
 // ---- after k_panel_lu: the panel's columns of D (non-pivot rows: zero; the panel's pivot rows: normalised), the multipliers as
 // digit planes F[d][i][slot0 + s] (0 where row i was a pivot already when pivot s was elected), and mtri.
 template <int ND, typename DT>
-__global__ __launch_bounds__(256) void k_panel_store(int R, int Rp, int c0, int w, ZpField F, const int *__restrict__ P, const int *__restrict__ seq,
+__global__ __launch_bounds__(256) void k_panel_store(int R, int Rp, int c0, int w, ZpField F, const DT *__restrict__ P, const int *__restrict__ seq,
                                                     DT *__restrict__ D, i64d ldc, PanelInfo *__restrict__ info, signed char *__restrict__ Fd, i64d fplane,
                                                     int KB, int slot0)
 {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void k_panel_store(int R, int Rp, int c0, int 
     if (threadIdx.x < DP_W) { s_col[threadIdx.x] = info->col[threadIdx.x]; s_inv[threadIdx.x] = info->inv[threadIdx.x]; s_row[threadIdx.x] = info->row[threadIdx.x]; }
     for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
         const int j = idx >> 6, r = idx & 63;
-        tile[j][r] = i0 + r < Rp ? P[(i64d)j * Rp + i0 + r] : 0;
+        tile[j][r] = i0 + r < Rp ? (int)P[(i64d)j * Rp + i0 + r] : 0;
     }
     __syncthreads();
     // multipliers: thread r (< 64) of each group of 64 writes the 64 slots of its row, 16 at a time
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void k_panel_store(int R, int Rp, int c0, int 
     if (blockIdx.x == 0)
         for (int idx = threadIdx.x; idx < DP_W * DP_W; idx += 256) {
             const int t = idx >> 6, s = idx & 63;
-            info->mtri[idx] = (s < t && t < npp) ? P[(i64d)s_col[s] * Rp + s_row[t]] : 0;
+            info->mtri[idx] = (s < t && t < npp) ? (int)P[(i64d)s_col[s] * Rp + s_row[t]] : 0;
         }
     __syncthreads();
     // D: rows that are no pivots get zeros; the panel's own pivot rows their normalised entries; older pivot rows stay as they are

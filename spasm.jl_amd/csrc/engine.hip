@@ -1436,7 +1436,8 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     const char *force_global = getenv("SPASM_AMD_PANEL_GLOBAL"); // tests: the in-place variant on small matrices
     const bool inlds = chunk <= lds_rows && !(force_global && atoi(force_global));
     const int Cp = (int)ldc + 128; // (the GEMM stages whole tiles of 128 columns of Ut, starting at any multiple of 64)
-    DevBuf<int> P, seq, candrow, invtab;
+    DevBuf<DT> P;
+    DevBuf<int> seq, candrow, invtab;
     DevBuf<signed char> Fd, Ut;
     DevBuf<PanelInfo> info;
     DevBuf<PanelSync> sync;
@@ -1462,8 +1463,7 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     const size_t lds = inlds ? (size_t)chunk * DP_W * (size_t)xbytes : 0;
     static bool attr_done = false;
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024, signed char>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
-        HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024, short>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
+        HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
         attr_done = true;
     }
     auto gemm = [&](int ja, int jb, int k0, int K, const int *rows, int nrows) {
@@ -1497,15 +1497,15 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
             {
                 int a_Rp = Rp, a_chunk = chunk, a_w = w, a_c0 = c0;
                 ZpField a_F = F;
-                int *a_P = P.p, *a_seq = seq.p, *a_pc = pivrow_of_col.p, *a_cand = candrow.p;
+                DT *a_P = P.p;
+                int *a_seq = seq.p, *a_pc = pivrow_of_col.p, *a_cand = candrow.p;
                 PanelInfo *a_info = info.p + q;
                 PanelSync *a_sy = sync.p;
                 DenseState *a_st = st.p;
                 const int *a_inv = invtab.p;
                 unsigned long long *a_stamps = stamps.p;
                 void *args[] = {&a_Rp, &a_chunk, &a_w, &a_c0, &a_F, &a_P, &a_seq, &a_pc, &a_info, &a_sy, &a_cand, &a_st, &a_inv, &a_stamps};
-                const void *fn = !inlds ? (const void *)k_panel_lu<false, 1024, int>
-                                 : ND == 1 ? (const void *)k_panel_lu<true, 1024, signed char> : (const void *)k_panel_lu<true, 1024, short>;
+                const void *fn = inlds ? (const void *)k_panel_lu<true, 1024, DT> : (const void *)k_panel_lu<false, 1024, DT>;
                 HIPCHK(hipLaunchCooperativeKernel(fn, dim3(G), dim3(1024), args, (unsigned)lds, s));
             }
             if (ND == 1) hipLaunchKernelGGL((k_panel_store<1, DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
