@@ -264,7 +264,8 @@ ORC_API int orc_sparse_triangular_solve(const struct spasm_csr *U, const struct 
  *   - a column is closed when a leftmost-pivot row holds it, open otherwise;
  *   - a non-pivot row proposes its open column of smallest occupancy among the non-pivot rows (ties: leftmost);
  *   - per column the sparsest proposing row wins (ties: lowest row);
- *   - a winner is accepted when no other column of its row received a proposal.
+ *   - a winner is accepted when no other column of its row received a proposal;
+ *   - the accepted rows become pivot rows, their columns are closed, and the rows left propose again (up to 4 passes).
  * Accepted rows enter U BEFORE the leftmost-pivot rows of the round (they may hold leftmost-pivot columns, never the other
  * way round), so U stays in topological order.  n_open, when given, receives the number of pivots this search added. */
 
@@ -308,48 +309,63 @@ static int fl_pivots_ex(const struct spasm_csr *A, struct spasm_csr *U, int *qin
     }
     int npiv = 0, nopen = 0;
     if (on_columns) {
-        char *left = calloc((size_t)(n > 0 ? n : 1), 1);   /* row is a leftmost pivot */
+        /* up to OPEN_PASSES passes (kernels.hpp): the rows a pass accepts become pivot rows, their columns are closed, and the
+         * rows left propose again; the pivots of a LATER pass enter U BEFORE those of an earlier one */
+        enum { OPEN_PASSES = 4 };
+        char *taken = calloc((size_t)(n > 0 ? n : 1), 1);   /* row is a pivot row (leftmost, or of an earlier pass) */
         char *closed = calloc((size_t)(m > 0 ? m : 1), 1);
-        int *cnt = calloc((size_t)(m > 0 ? m : 1), sizeof(int));
+        int *cnt = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
         int *best2 = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
-        int *prop = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
-        int any = 0;
-        for (int j = 0; j < m; j++) {
-            best2[j] = -1;
-            if (best[j] >= 0) { left[best[j]] = 1; any = 1; }
-        }
+        int *pcol = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1)); /* accepted (column, row) pairs, pass after pass */
+        int *prow = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+        int pstart[OPEN_PASSES + 2];
+        int npass = 0, any = 0;
+        pstart[0] = 0;
+        for (int j = 0; j < m; j++) if (best[j] >= 0) { taken[best[j]] = 1; any = 1; }
         if (any) {
             for (int i = 0; i < n; i++)
-                for (i64 k = A->p[i]; k < A->p[i + 1]; k++) {
-                    if (left[i]) closed[A->j[k]] = 1;
-                    else cnt[A->j[k]]++;
+                if (taken[i]) for (i64 k = A->p[i]; k < A->p[i + 1]; k++) closed[A->j[k]] = 1;
+            for (int pass = 1; pass <= OPEN_PASSES; pass++) {
+                for (int j = 0; j < m; j++) { cnt[j] = 0; best2[j] = -1; }
+                for (int i = 0; i < n; i++)
+                    if (!taken[i]) for (i64 k = A->p[i]; k < A->p[i + 1]; k++) cnt[A->j[k]]++;
+                for (int i = 0; i < n; i++) {
+                    if (taken[i]) continue;
+                    i64 lo = A->p[i], hi = A->p[i + 1];
+                    int c = -1;
+                    for (i64 k = lo; k < hi; k++) {
+                        int j = A->j[k];
+                        if (closed[j]) continue;
+                        if (c < 0 || cnt[j] < cnt[c] || (cnt[j] == cnt[c] && j < c)) c = j;
+                    }
+                    if (c < 0) continue;
+                    int b = best2[c];
+                    if (b < 0 || (hi - lo) < (A->p[b + 1] - A->p[b])) best2[c] = i;
                 }
-            for (int i = 0; i < n; i++) {
-                prop[i] = -1;
-                if (left[i]) continue;
-                i64 lo = A->p[i], hi = A->p[i + 1];
-                int c = -1;
-                for (i64 k = lo; k < hi; k++) {
-                    int j = A->j[k];
-                    if (closed[j]) continue;
-                    if (c < 0 || cnt[j] < cnt[c] || (cnt[j] == cnt[c] && j < c)) c = j;
+                int at = pstart[pass - 1];
+                for (int j = 0; j < m; j++) {
+                    int i = best2[j];
+                    if (i < 0) continue;
+                    int clash = 0;
+                    for (i64 k = A->p[i]; k < A->p[i + 1]; k++) if (A->j[k] != j && best2[A->j[k]] >= 0) clash = 1;
+                    if (clash) continue;
+                    pcol[at] = j; prow[at] = i; at++;
                 }
-                if (c < 0) continue;
-                prop[i] = c;
-                int b = best2[c];
-                if (b < 0 || (hi - lo) < (A->p[b + 1] - A->p[b])) best2[c] = i;
+                pstart[pass] = at;
+                if (at == pstart[pass - 1]) break;
+                npass = pass;
+                for (int t = pstart[pass - 1]; t < at; t++) {
+                    taken[prow[t]] = 1;
+                    for (i64 k = A->p[prow[t]]; k < A->p[prow[t] + 1]; k++) closed[A->j[k]] = 1;
+                }
             }
-            for (int j = 0; j < m; j++) {
-                int i = best2[j];
-                if (i < 0) continue;
-                int clash = 0;
-                for (i64 k = A->p[i]; k < A->p[i + 1]; k++) if (A->j[k] != j && best2[A->j[k]] >= 0) clash = 1;
-                if (clash) continue;
-                emit_pivot_row(A, i, j, U, qinv, is_piv, Uorig, orig);
-                nopen++;
-            }
+            for (int pass = npass; pass >= 1; pass--)
+                for (int t = pstart[pass - 1]; t < pstart[pass]; t++) {
+                    emit_pivot_row(A, prow[t], pcol[t], U, qinv, is_piv, Uorig, orig);
+                    nopen++;
+                }
         }
-        free(left); free(closed); free(cnt); free(best2); free(prop);
+        free(taken); free(closed); free(cnt); free(best2); free(pcol); free(prow);
     }
     for (int j = 0; j < m; j++) {
         int i = best[j];

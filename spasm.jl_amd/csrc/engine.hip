@@ -329,39 +329,59 @@ struct Round {
     bool want_pivval = false;
     DevBuf<u64d> best2;
     int n_leftmost = 0, n_open = 0;
+    DevBuf<int> newpass, newidx, newrow_of_col, newrows;
     int extend_pivots_on_open_columns(const DevMat &A)
     {
         n_leftmost = npiv;
         n_open = 0;
         if (npiv == 0 || A.n == 0) return 0;
         closed.ensure((size_t)m + 1); colcnt.ensure((size_t)m + 1); newflag.ensure((size_t)m + 1); newscan.ensure((size_t)m + 1);
+        newpass.ensure((size_t)m + 1); newidx.ensure((size_t)m + 1); newrow_of_col.ensure((size_t)m + 1); newrows.ensure((size_t)m + 1);
         best2.ensure((size_t)m + 1);
         prop.ensure((size_t)A.n + 1);
         is_piv.ensure((size_t)A.n + 1);
         HIPCHK(hipMemsetAsync(closed.p, 0, ((size_t)m + 1) * sizeof(int), stream));
-        HIPCHK(hipMemsetAsync(colcnt.p, 0, ((size_t)m + 1) * sizeof(int), stream));
-        HIPCHK(hipMemsetAsync(newflag.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(newpass.p, 0, ((size_t)m + 1) * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(is_piv.p, 0, ((size_t)A.n + 1) * sizeof(int), stream));
-        hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best2.p);
         hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, 0, 1, A.n, pivrow.p, is_piv.p);
         constexpr int TEAM = 8;
         hipLaunchKernelGGL((k_close_cols<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, stream, npiv, pivrow.p, A.start.p, A.len.p, A.ent.p, closed.p);
-        hipLaunchKernelGGL(k_col_histogram, dim3(cdiv((i64)A.n * 8, 256)), dim3(256), 0, stream, A.n, is_piv.p, A.start.p, A.len.p, A.ent.p, colcnt.p);
-        hipLaunchKernelGGL((k_propose_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, 0, 1, is_piv.p, A.start.p, A.len.p, A.ent.p,
-                           closed.p, colcnt.p, prop.p, best2.p);
-        hipLaunchKernelGGL((k_accept_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, 0, 1, A.start.p, A.len.p, A.ent.p, prop.p,
-                           best2.p, newflag.p);
-        HIPCHK(hipGetLastError());
-        scan.exclusive(newflag.p, newscan.p, (size_t)m + 1, stream);
-        int nnew = 0;
-        HIPCHK(hipMemcpyAsync(&nnew, newscan.p + m, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        int count[OPEN_PASSES + 1] = {0};
+        int nnew = 0, npass = 0;
+        for (int pass = 1; pass <= OPEN_PASSES; pass++) {
+            HIPCHK(hipMemsetAsync(colcnt.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+            HIPCHK(hipMemsetAsync(newflag.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+            hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best2.p);
+            hipLaunchKernelGGL(k_col_histogram, dim3(cdiv((i64)A.n * 8, 256)), dim3(256), 0, stream, A.n, is_piv.p, A.start.p, A.len.p, A.ent.p, colcnt.p);
+            hipLaunchKernelGGL((k_propose_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, 0, 1, is_piv.p, A.start.p, A.len.p,
+                               A.ent.p, closed.p, colcnt.p, prop.p, best2.p);
+            hipLaunchKernelGGL((k_accept_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, 0, 1, A.start.p, A.len.p, A.ent.p,
+                               prop.p, best2.p, newflag.p);
+            HIPCHK(hipGetLastError());
+            scan.exclusive(newflag.p, newscan.p, (size_t)m + 1, stream);
+            int nacc = 0;
+            HIPCHK(hipMemcpyAsync(&nacc, newscan.p + m, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (nacc == 0) break;
+            hipLaunchKernelGGL(k_record_open, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, pass, newflag.p, newscan.p, best2.p, newpass.p, newidx.p,
+                               newrow_of_col.p, newrows.p, is_piv.p);
+            hipLaunchKernelGGL((k_close_cols<TEAM>), dim3(cdiv((i64)nacc * TEAM, 256)), dim3(256), 0, stream, nacc, newrows.p, A.start.p, A.len.p, A.ent.p,
+                               closed.p);
+            HIPCHK(hipGetLastError());
+            count[pass] = nacc;
+            nnew += nacc;
+            npass = pass;
+        }
         if (nnew == 0) return 0;
-        // renumber: open-column pivots 0 .. nnew-1, leftmost pivots behind them (colscan still holds their ascending numbering)
+        // renumber: the open-column pivots first (last pass first), the leftmost pivots behind them (colscan still holds their ascending
+        // numbering)
+        int base[OPEN_PASSES + 2] = {0};
+        for (int pass = npass, at = 0; pass >= 1; pass--) { base[pass] = at; at += count[pass]; }
+        static_assert(OPEN_PASSES == 4, "k_col_assign2 takes the bases of four passes");
         pivrow.ensure((size_t)npiv + nnew + 1);
         pivcol.ensure((size_t)npiv + nnew + 1);
-        hipLaunchKernelGGL(k_col_assign2, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, nnew, best.p, best2.p, newflag.p, newscan.p, colscan.p, qinv_r.p,
-                           pivrow.p, pivcol.p);
+        hipLaunchKernelGGL(k_col_assign2, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, nnew, make_int4(base[1], base[2], base[3], base[4]), best.p, newpass.p,
+                           newidx.p, newrow_of_col.p, colscan.p, qinv_r.p, pivrow.p, pivcol.p);
         HIPCHK(hipGetLastError());
         npiv += nnew;
         n_open = nnew;

@@ -239,9 +239,13 @@ __global__ void k_col_assign(int m, const u64d *__restrict__ best, const int *__
 //      fill-in; per column the sparsest proposing row wins (ties: lowest row), as in the leftmost election;
 //   4. a winner is accepted when none of its OTHER columns was won by anybody: accepted rows then do not contain each other's
 //      pivot columns, leftmost-pivot rows do not contain them either (they are open), so U stays triangular when the new
-//      pivots are numbered before the leftmost ones.
+//      pivots are numbered before the leftmost ones;
+//   5. the accepted rows become pivot rows, their columns are closed, and 2 - 4 run again (up to OPEN_PASSES times, until a pass
+//      accepts nothing): rows that lost their column, or clashed, get another chance on what is still open.  Pivots of a later pass
+//      are numbered before those of an earlier one (their rows may hold earlier pivot columns, never the other way round).
 // Deterministic and order-free, so the CPU oracle can take the same pivots (oracle/spasm_oracle.c: fl_on_columns).
 // ------------------------------------------------------------------------------------------------
+#define OPEN_PASSES 4
 template <int TEAM>
 __global__ void k_close_cols(int npiv, const int *__restrict__ rowsrc, const i64d *__restrict__ start, const int *__restrict__ len,
                              const int2 *__restrict__ ent, int *__restrict__ closed)
@@ -338,19 +342,42 @@ __global__ void k_col_flags2(int m, const u64d *__restrict__ best, const int *__
     if (j == m) flflag[j] = 0;
     (void)newflag;
 }
-__global__ void k_col_assign2(int m, int nnew, const u64d *__restrict__ best, const u64d *__restrict__ best2, const int *__restrict__ newflag,
-                              const int *__restrict__ newscan, const int *__restrict__ flscan, int *__restrict__ qinv_r, int *__restrict__ pivrow,
+// the pivots a pass of the search accepted: their pass, their rank inside it (ascending column), their row; the rows become pivot
+// rows for the next pass (is_piv) and are listed (newrows) so that their columns can be closed
+__global__ void k_record_open(int m, int pass, const int *__restrict__ newflag, const int *__restrict__ newscan, const u64d *__restrict__ best2,
+                              int *__restrict__ newpass, int *__restrict__ newidx, int *__restrict__ newrow_of_col, int *__restrict__ newrows,
+                              int *__restrict__ is_piv)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m || !newflag[j]) return;
+    const int row = (int)(unsigned)(best2[j] & 0xffffffffull);
+    newpass[j] = pass;
+    newidx[j] = newscan[j];
+    newrow_of_col[j] = row;
+    newrows[newscan[j]] = row;
+    is_piv[row] = 1;
+}
+
+// numbering: the open-column pivots of the LAST pass first, then the earlier passes, each by ascending column, then the leftmost
+// pivots by ascending column.  base.x/y/z/w = first index of pass 1 / 2 / 3 / 4; nnew = all open-column pivots.
+__global__ void k_col_assign2(int m, int nnew, int4 base, const u64d *__restrict__ best, const int *__restrict__ newpass, const int *__restrict__ newidx,
+                              const int *__restrict__ newrow_of_col, const int *__restrict__ flscan, int *__restrict__ qinv_r, int *__restrict__ pivrow,
                               int *__restrict__ pivcol)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    int idx = -1;
-    u64d b = NO_BEST;
-    if (newflag[j]) { idx = newscan[j]; b = best2[j]; }
-    else if (best[j] != NO_BEST) { idx = nnew + flscan[j]; b = best[j]; }
+    int idx = -1, row = -1;
+    const int ps = newpass[j];
+    if (ps > 0) {
+        idx = (ps == 1 ? base.x : ps == 2 ? base.y : ps == 3 ? base.z : base.w) + newidx[j];
+        row = newrow_of_col[j];
+    } else if (best[j] != NO_BEST) {
+        idx = nnew + flscan[j];
+        row = (int)(unsigned)(best[j] & 0xffffffffull);
+    }
     qinv_r[j] = idx;
     if (idx >= 0) {
-        pivrow[idx] = (int)(unsigned)(b & 0xffffffffull);
+        pivrow[idx] = row;
         pivcol[idx] = j;
     }
 }
