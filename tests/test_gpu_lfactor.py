@@ -26,7 +26,7 @@ def lu_product_rows(L, U, p):
 
 CASES = [
     ("fixed_nnz", 1, 1500, 1500, dict(row_nnz=5), 65521, {}),
-    ("three_rounds_then_finish", 1, 3000, 3000, dict(row_nnz=6), 65521, dict(enable_greedy_pivot_search=True)),
+    ("three_rounds_then_finish", 1, 1200, 1200, dict(row_nnz=6), 65521, dict(enable_greedy_pivot_search=True)),
     ("macaulay_like", 2, 2000, 800, dict(row_nnz=30), 127, {}),
     ("big_prime_wide", 1, 600, 900, dict(row_nnz=6), 0xFFFFFFFB, dict(enable_greedy_pivot_search=True)),
     ("bernoulli_tall", 0, 900, 400, dict(density=0.02), 2147483647, {}),
