@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- Schur nnz reduced / second on BASELINE config 3 (1M x 1M CSR, 20 nnz/row, p = 65521).
 
-One "step" = one pass of the hot path over the synthetic matrix: the Schur round of the matrix
-(solve kernel + scatter kernels of libspasm_amd.so) with the matrix, the round's pivot rows U and
-all work buffers already resident in HBM.  With N GPUs (one process per GPU, launched by
-torch.distributed.run) the non-pivot rows are block-partitioned over the ranks (BASELINE config 4,
-strong scaling: the matrix is fixed); every rank elects the same pivots and holds the same U, rows
-never move.  For N > 1 every rank uploads only its row block and the round's pivot rows are exchanged once in
+One "step" = one pass of the hot path over the synthetic matrix: the WHOLE Schur step of the round, as the reference's
+spasm_schur does it (src/SpaSM.jl:761-762, the per-row solve :694-713 is inside): W = -(I + U_PP)^-1 U_PN rebuilt from the
+round's pivot rows U level by level, the plan of every non-pivot row, the streaming scatter -- with the matrix, U and all
+work buffers already resident in HBM.  Nothing the step needs is cached from one step to the next except U itself (the
+output of the pivot search, spasm_pivots_extract_structural, which is not part of the metric).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run).
+With N GPUs (one process per GPU) the non-pivot rows are dealt to the ranks (rank r: rows r, r + N, ...; BASELINE config 4,
+strong scaling: the matrix is fixed); every rank elects the same pivots and holds the same U, rows never move.  For N > 1 every rank uploads only its row block and the round's pivot rows are exchanged once in
 the setup (all-reduce(MIN) of the election keys + all-gather of the elected rows, RCCL over xGMI, timed on its own and
 reported as `pivot_row_exchange_rank0`; SPASM_BENCH_EXCHANGE=0 replicates the matrix instead, explicitly); the timed
 region has no data-path collective.  A failing exchange ends the run with a non-zero exit code.
@@ -47,6 +49,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one.  A child process, started before anything here touches the GPU (never an exec
+        # from a process that has initialised HIP); rank 0 of the children prints the JSON line on the inherited stdout.
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,12 +210,13 @@ def main():
             "traffic": traffic,
             "bytes_per_launch": k_bytes,
             "ms_per_launch": round(k_ms, 4),
-            "round_algorithmic_read_GBs": round(d["read_bytes"] / ((d["ms_solve"] + d["ms_scatter"]) * 1e-3) / 1e9, 1)
-            if (d["ms_solve"] + d["ms_scatter"]) > 0 else None,
-            # per-round setup the timed steps do not repeat (a plan keeps Uinv and W): wall time with host synchronisations
-            "round_ms": {"solve": round(d["ms_solve"], 4), "scatter": round(d["ms_scatter"], 4),
-                         "uinv_build": round(d["ms_uinv"], 4), "w_build": round(d["ms_w"], 4)},
-            "ms_per_round_incl_setup": round(ms_per_step + d["ms_uinv"] + d["ms_w"], 4),
+            "round_algorithmic_read_GBs": round(read_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1), 1) if ms_per_step > 0 else None,
+            "round_frac_of_peak": round(read_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1) / HBM_PEAK_GBS, 4) if ms_per_step > 0 else None,
+            # the phases of one step (HIP events of the profiled extra step): W level by level, the plan of the rows, the scatter
+            "round_ms": {"w_build": round(d["ms_wbuild"], 4), "plan": round(d["ms_solve"], 4), "scatter": round(d["ms_scatter"], 4)},
+            "w": {"levels": d["w_levels"], "entries": d["w_entries"], "long_rows": d["w_long_rows"]},
+            # once per round, outside the step: the levels of the pivot graph (part of the pivot bookkeeping) + sizing + first build
+            "levels_and_first_w_build_ms": round(d["ms_w"], 4),
             "per_class_ms": {"hash": [round(x, 4) for x in d["ms_class"][:8]], "stream": [round(x, 4) for x in d["ms_class"][8:15]]},
             "per_class_rows": {"hash": d["rows_class"][:8], "stream": d["rows_class"][8:15]},
             "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"], "stream_fix_ms": round(d["ms_class"][15], 4),

@@ -181,12 +181,19 @@ struct spasm_amd_round_stats {
     i64 seg_class[16];
     i64 stream_fix;       /* duplicate columns the streaming kernels merged after the fact */
     i64 stream_redo;      /* rows the streaming kernels handed back to the hash-table kernels */
-    /* per-round setup of the Schur complement, wall time with its host synchronisations: Uinv = (I + U_PP)^-1 and
-     * W = -Uinv * U_PN (included in ms_pivots of an echelonize round; a plan builds them once, when it is created) */
+    /* per-round setup, wall time with its host synchronisations: ms_uinv = Uinv = (I + U_PP)^-1 (rounds that keep to the
+     * multiplier lists; 0 when the round goes along W); ms_w = the levels of the pivot graph + sizing + the first build of W
+     * (included in ms_pivots of an echelonize round; a plan pays them when it is created, and rebuilds W in every run: ms_wbuild) */
     double ms_uinv;
     double ms_w;
     i64 npiv_open;        /* of npiv: pivots the "Faugere-Lachartre on columns" search added to the leftmost-entry ones
                            * (echelonize rounds with enable_greedy_pivot_search; 0 for plans, which keep to leftmost entries) */
+    /* W = -(I + U_PP)^-1 U_PN as the Schur step builds it, level by level of the pivot graph (csrc/wlevel.hpp): device time of
+     * the build inside the last plan run (it is part of every run), levels, entries of W, rows left to the workgroup kernel */
+    double ms_wbuild;
+    i64 w_levels;
+    i64 w_entries;
+    i64 w_long_rows;
 };
 
 typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;

@@ -94,6 +94,10 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
         ("ms_uinv", C.c_double),
         ("ms_w", C.c_double),
         ("npiv_open", C.c_int64),
+        ("ms_wbuild", C.c_double),
+        ("w_levels", C.c_int64),
+        ("w_entries", C.c_int64),
+        ("w_long_rows", C.c_int64),
     ]
 
     def as_dict(self):

@@ -7,9 +7,11 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "stream.hpp"
+#include "wlevel.hpp"
 #include "dense.hpp"
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <vector>
 #include <memory>
 #include <stdexcept>
@@ -208,16 +210,29 @@ struct Round {
     DevBuf<int2> fixbuf;            // per row slot: SFIX duplicates found by the streaming kernels, merged by k_stream_fix
     DevBuf<int> fixcnt;
     bool use_stream = true;         // SPASM_AMD_STREAM=0 turns W and the streaming scatter off
-    // W = -(I + U_PP)^-1 U_PN (stream.hpp): its rows live behind U_PN in the UPN buffer
+    // W = -(I + U_PP)^-1 U_PN (stream.hpp), built level by level of the pivot graph (wlevel.hpp).  One buffer, addressed by 32-bit
+    // offsets: [U_PN | the own non-pivot entries of the rows the plan kernel takes | the rows of W]
     bool use_w = false;
     bool force_lists = false;       // keep to the multiplier lists even when W is there (exact trip counters: they count list entries)
-    DevBuf<int4> Wrec, wcol;
-    DevBuf<i64d> Wstart;
-    DevBuf<int> Wlen, wreject_list;
-    DevMat Zrows;                   // npiv rows without entries: what W is scattered "from"
-    i64 wtotal = 0;
-    i64 own_total = 0;              // entries of the part of the UPN buffer behind W that takes the rows' own non-pivot entries
+    DevBuf<int4> wcol;              // per pivot column: {pivot index, length, offset} of its row of W
+    DevBuf<int2> wrow;              // the same per pivot index: {offset, length}
+    DevBuf<int> wreject_list;
+    i64 wtotal = 0;                 // entries of W's region handed out by the last build
+    i64 wcap = 0;                   // entries of W's region
+    i64 w_entries = 0, w_long_rows = 0; // entries of W, rows the workgroup kernel built (statistics of the first build)
+    i64 own_base = 0, wbase = 0;    // where the own entries / the rows of W start in the buffer
+    i64 own_total = 0;              // entries of the part of the buffer that takes the rows' own non-pivot entries
     DevBuf<u64d> own_ctr;           // its bump counters
+    DevBuf<u64d> wstate, wblk;      // cursor + statistics of the build; the blocks its waves carve rows from
+    DevBuf<int> wbig_list, wbig_count;
+    std::vector<int> wbig_at;       // per level: long rows the first build of this U left to the workgroup kernel
+    int wave_per_cu_blocks = 0;     // resident workgroups of k_wlevel_wave per CU
+    // levels of the pivot graph: level L = lev_order[lev_start[L] .. lev_start[L + 1])
+    DevBuf<int> lev, lev_keys, lev_iota, lev_order, lev_start_d, lev_flag;
+    DevBuf<unsigned char> sort_tmp;
+    std::vector<int> lev_start;
+    int depth = -1;                 // deepest level; -1: no levels (not computed, or the graph is deeper than WMAXLEV)
+    bool quiet_rejects = false;     // a plan whose dry run saw the plan kernel reject no row: later runs skip the chain-solve launches
     DevBuf<u64d> pool_ctr;          // NPOOL sharded bump counters
     int npool_active = NPOOL;       // regions in use by the current solve
     u64d region_cap = 0;
@@ -245,7 +260,7 @@ struct Round {
     i64 s_total_bound = 0;
     int free_cols = 0;
     // timing
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t side = nullptr;     // the few rows of the largest table classes run beside the others
     hipStream_t twin_s[3] = {nullptr, nullptr, nullptr}; // with `side`: the hash-table twins of the streaming classes, four abreast
     hipEvent_t twin_ev[3] = {nullptr, nullptr, nullptr};
@@ -487,15 +502,17 @@ struct Round {
     }
 
     // chain solve: small teams first, then one wave per row, then the unbounded fallback
-    void launch_chain(SolveArgs a, int nrows, bool first_class)
+    // (only, only_count: when given, the row slots to solve -- what the plan kernel left -- instead of all of them)
+    void launch_chain(SolveArgs a, int nrows, bool first_class, const int *only = nullptr, const int *only_count = nullptr)
     {
         if (first_class) {
-            a.retry = nullptr;
-            a.retry_count = nullptr;
+            a.retry = only;
+            a.retry_count = only_count;
             a.overflow_list = overflow_list.p;
             a.overflow_count = &ctr.p->solve_overflow;
             constexpr int TEAM = 8, CAP = 128, TPB = 256;
-            hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(cdiv((i64)nrows * TEAM, TPB)), dim3(TPB), 0, stream, a);
+            const int grid = only ? std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 8) : cdiv((i64)nrows * TEAM, TPB);
+            hipLaunchKernelGGL((k_solve<TEAM, CAP, TPB>), dim3(grid), dim3(TPB), 0, stream, a);
             HIPCHK(hipGetLastError());
         }
         BigSolveArgs b;
@@ -554,6 +571,7 @@ struct Round {
     }
     void prepare_w(i64 expected_rows, i64 own_entries)
     {
+        HIPCHK(hipStreamSynchronize(stream));
         const double t0 = spasm_wtime();
         prepare_w_(expected_rows, own_entries);
         HIPCHK(hipStreamSynchronize(stream));
@@ -658,79 +676,174 @@ struct Round {
         }
     }
 
-    // W = -(I + U_PP)^-1 U_PN, once per round, after prepare_uinv: row i = - sum over the entries (j, u) of row i of Uinv of u * U_PN[j],
-    // i.e. a scatter round over npiv rows without entries of their own whose "multiplier lists" are the rows of Uinv.  Costs about
-    // uinv_nnz / npiv times the entries of U_PN: worth it when many more rows than pivots are reduced.
-    // own_entries: upper bound of the entries of the rows that will be reduced along W (their non-pivot entries are copied behind W)
+    // ---- levels of the pivot graph (wlevel.hpp): relaxation on the device, rows ordered by level with a stable radix sort (a
+    // level's rows in ascending pivot index: the build is the same every time).  Part of the pivot bookkeeping of a round, like the
+    // reference's topological reordering of the pivots (README.md:21-24); the Schur step proper (build_w_levels ..) has no
+    // host synchronisation.
+    void build_levels()
+    {
+        depth = -1;
+        if (npiv == 0) return;
+        lev.ensure((size_t)npiv + 1);
+        lev_keys.ensure((size_t)npiv + 1);
+        lev_iota.ensure((size_t)npiv + 1);
+        lev_order.ensure((size_t)npiv + 1);
+        lev_start_d.ensure(WMAXLEV + 4);
+        lev_flag.ensure(4);
+        HIPCHK(hipMemsetAsync(lev.p, 0, ((size_t)npiv + 1) * sizeof(int), stream));
+        bool converged = false;
+        // a launch moves every row at least one level on: WMAXLEV + 2 launches settle any graph that is not too deep
+        for (int batch = 0; batch * 8 < WMAXLEV + 2 && !converged; batch++) {
+            for (int it = 0; it < 8; it++) {
+                if (it == 7) HIPCHK(hipMemsetAsync(lev_flag.p, 0, sizeof(int), stream));
+                hipLaunchKernelGGL(k_lev_relax, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, uhdr.p, UPP.p, lev.p, it == 7 ? lev_flag.p : (int *)nullptr, 2);
+            }
+            HIPCHK(hipGetLastError());
+            int ch = 1;
+            HIPCHK(hipMemcpyAsync(&ch, lev_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            converged = ch == 0;
+        }
+        if (!converged) return;
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, lev_iota.p);
+        HIPCHK(hipGetLastError());
+        {
+            size_t bytes = 0;
+            HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, lev.p, lev_keys.p, lev_iota.p, lev_order.p, (size_t)npiv, 0, 10, stream));
+            sort_tmp.ensure(bytes);
+            HIPCHK(rocprim::radix_sort_pairs(sort_tmp.p, bytes, lev.p, lev_keys.p, lev_iota.p, lev_order.p, (size_t)npiv, 0, 10, stream));
+        }
+        hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(WMAXLEV + 4 <= 256 ? 256 : 512), 0, stream, WMAXLEV + 3, npiv, lev_start_d.p);
+        hipLaunchKernelGGL(k_lev_starts, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, lev_keys.p, lev_start_d.p, WMAXLEV + 1);
+        HIPCHK(hipGetLastError());
+        lev_start.assign(WMAXLEV + 3, npiv);
+        int deepest = 0;
+        HIPCHK(hipMemcpyAsync(lev_start.data(), lev_start_d.p, (WMAXLEV + 3) * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&deepest, lev_keys.p + (npiv - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (deepest > WMAXLEV) return;
+        depth = deepest;
+        lev_start[(size_t)depth + 1] = npiv;
+    }
+
+    // ---- W, level by level (kernels only: part of every Schur step).  first: the build that follows build_U -- the workgroup kernel
+    // runs behind every level and the caller then notes where it had work (wbig_at); later builds of the same U skip the others.
+    void build_w_levels(bool first)
+    {
+        const int nblk_words = 2 * num_cu * 16 * 4;
+        hipLaunchKernelGGL(k_wbuild_reset, dim3(cdiv(std::max(nblk_words, WMAXLEV + 2), 256)), dim3(256), 0, stream, wstate.p, wblk.p, nblk_words, wbig_count.p,
+                           WMAXLEV + 2);
+        HIPCHK(hipGetLastError());
+        if (!wave_per_cu_blocks) {
+            int nb = 0;
+            if (F.small) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wlevel_wave<true>, 256, 0));
+            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wlevel_wave<false>, 256, 0));
+            wave_per_cu_blocks = std::min(std::max(nb, 1), 16);
+            if (F.small) HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl_wg_lds_bytes<true>()));
+            else HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl_wg_lds_bytes<false>()));
+        }
+        WLevelArgs a;
+        a.uhdr = uhdr.p;
+        a.UPP = UPP.p;
+        a.buf = UPN.p;
+        a.wrow = wrow.p;
+        a.wcol = wcol.p;
+        a.pivcol = pivcol.p;
+        a.wstate = wstate.p;
+        a.wbase = (unsigned)wbase;
+        a.wcap = (u64d)wcap;
+        a.wblk = wblk.p;
+        a.big_list = wbig_list.p;
+        a.F = F;
+        for (int L = 0; L <= depth; L++) {
+            a.cnt = lev_start[(size_t)L + 1] - lev_start[(size_t)L];
+            if (a.cnt <= 0) continue;
+            a.order = lev_order.p + lev_start[(size_t)L];
+            a.big_count = wbig_count.p + L;
+            const int grid = std::min(cdiv(a.cnt, 4), num_cu * wave_per_cu_blocks);
+            if (F.small) hipLaunchKernelGGL(k_wlevel_wave<true>, dim3(grid), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(k_wlevel_wave<false>, dim3(grid), dim3(256), 0, stream, a);
+            if (L > 0 && (first || wbig_at[(size_t)L] > 0)) {
+                const int g2 = first ? num_cu : std::min(num_cu, wbig_at[(size_t)L]);
+                if (F.small) hipLaunchKernelGGL(k_wlevel_wg<true>, dim3(g2), dim3(256), wl_wg_lds_bytes<true>(), stream, a);
+                else hipLaunchKernelGGL(k_wlevel_wg<false>, dim3(g2), dim3(256), wl_wg_lds_bytes<false>(), stream, a);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
+
+    // Decides whether this round goes along W, sizes the [U_PN | own | W] buffer and builds W once (synchronises: the outcome of
+    // the build is read back).  Worth it when many more rows than pivots are reduced; a W much larger than U means long chains,
+    // which the multiplier lists serve better.
+    // own_entries: upper bound of the entries of the rows that will be reduced along W (their non-pivot entries are copied into
+    // the buffer by the plan kernel)
     void prepare_w_(i64 expected_rows, i64 own_entries)
     {
         use_w = false;
         wtotal = 0;
-        if (!use_uinv || !use_stream || m >= (1 << 24) || npiv == 0 || expected_rows < 2 * (i64)npiv) return;
-        const i64 nrec = (i64)UinvPool.n;
-        Wrec.ensure((size_t)nrec + 1);
-        alloc_solve(npiv, 1 << 16);
-        {
-            const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), npool_words = NPOOL * POOL_STRIDE;
-            const int span = std::max(std::max(nctr_words, npool_words), npiv + 1);
-            hipLaunchKernelGGL(k_solve_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, npiv, (unsigned *)ctr.p, nctr_words, pool_ctr.p,
-                               npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p, sflag.p, (u64d *)nullptr);
-            HIPCHK(hipGetLastError());
-        }
-        hipLaunchKernelGGL(k_uinv_records, dim3(cdiv(((i64)npiv + 1) * 8, 256)), dim3(256), 0, stream, npiv, UinvStart.p, UinvLen.p, UinvPool.p, uhdr.p,
-                           Wrec.p, bound.p, (i64d)free_cols);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(Lstart.p, UinvStart.p, (size_t)npiv * sizeof(i64d), hipMemcpyDeviceToDevice, stream));
-        HIPCHK(hipMemcpyAsync(Llen.p, UinvLen.p, (size_t)npiv * sizeof(int), hipMemcpyDeviceToDevice, stream));
-        run_bounds(npiv);
-        const i64 tot = fetch_total_bound(npiv);
+        if (!use_stream || force_lists || want_idx || m >= (1 << 24) || npiv == 0 || expected_rows < 2 * (i64)npiv) return;
+        build_levels();
+        if (depth < 0) return;
         // room for the rows' own entries: what they have, half as much again for uneven regions, and a block per team of the plan kernel
-        const i64 own_room = own_entries + own_entries / 2 + (i64)num_cu * 16 * 16 * 256 + NPOOL;
-        // offsets into the U_PN + W + own buffer are 32-bit; a W much larger than U means long chains: the lists cope better
-        if (utotal + tot + own_room >= (i64)0xffffffffLL || tot > 64 * std::max<i64>(utotal, 1 << 16)) return;
-        size_t fr = 0, totmem = 0;
-        HIPCHK(hipMemGetInfo(&fr, &totmem));
-        if ((size_t)(tot + utotal + own_room) * 2 * sizeof(int2) > fr / 2) return;
-        S.ent.ensure((size_t)tot + 1);
-        Zrows.n = npiv;
-        Zrows.m = m;
-        Zrows.start.ensure((size_t)npiv + 1);
-        Zrows.len.ensure((size_t)npiv + 1);
-        Zrows.orig.ensure((size_t)npiv + 1);
-        Zrows.ent.ensure(1);
-        HIPCHK(hipMemsetAsync(Zrows.start.p, 0, ((size_t)npiv + 1) * sizeof(i64d), stream));
-        HIPCHK(hipMemsetAsync(Zrows.len.p, 0, ((size_t)npiv + 1) * sizeof(int), stream));
-        HIPCHK(hipMemsetAsync(Zrows.orig.p, 0, ((size_t)npiv + 1) * sizeof(int), stream));
-        run_scatter(Zrows, nullptr, npiv, Wrec.p);
-        fetch_counters(); // synchronises; throws if a table filled up
-        // behind U_PN in one buffer, so that a record's offset means the same to every scatter kernel
-        DevBuf<int2> both;
-        both.alloc((size_t)(utotal + tot + own_room) + 1);
-        if (utotal > 0) HIPCHK(hipMemcpyAsync(both.p, UPN.p, (size_t)utotal * sizeof(int2), hipMemcpyDeviceToDevice, stream));
-        if (tot > 0) HIPCHK(hipMemcpyAsync(both.p + utotal, S.ent.p, (size_t)tot * sizeof(int2), hipMemcpyDeviceToDevice, stream));
-        Wstart.ensure((size_t)npiv + 1);
-        Wlen.ensure((size_t)npiv + 1);
-        HIPCHK(hipMemcpyAsync(Wstart.p, sstart.p, ((size_t)npiv + 1) * sizeof(i64d), hipMemcpyDeviceToDevice, stream));
-        HIPCHK(hipMemcpyAsync(Wlen.p, S.len.p, (size_t)npiv * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        const i64 own_room = ((own_entries + own_entries / 2 + (i64)num_cu * 16 * 16 * 256 + NPOOL) + 15) & ~(i64)15;
+        own_base = (utotal + 15) & ~(i64)15;
+        wbase = own_base + own_room;
+        // offsets into the buffer are 32-bit
+        i64 cap = std::min<i64>(64 * std::max<i64>(utotal, 1 << 16), (i64)0xffffffffLL - wbase - 64);
+        {
+            // memory only vetoes (the route changes, not the result): half of what is free beside the buffer already there
+            size_t fr = 0, totmem = 0;
+            HIPCHK(hipMemGetInfo(&fr, &totmem));
+            const i64 have = (i64)UPN.n;
+            const i64 room = have + (i64)(fr / 2 / sizeof(int2));
+            if (wbase + cap + 1 > room) cap = room - wbase - 1;
+        }
+        cap &= ~(i64)15;
+        if (cap < 4 * std::max<i64>(utotal, 1 << 12)) return;
+        if ((i64)UPN.n < wbase + cap + 1) {
+            DevBuf<int2> both;
+            both.alloc((size_t)(wbase + cap) + 1);
+            if (utotal > 0) HIPCHK(hipMemcpyAsync(both.p, UPN.p, (size_t)utotal * sizeof(int2), hipMemcpyDeviceToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            UPN = std::move(both);
+        }
+        wcap = cap;
+        wrow.ensure((size_t)npiv + 1);
         wcol.ensure((size_t)m + 1);
-        hipLaunchKernelGGL(k_wcolinfo, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, qinv_r.p, Wstart.p, Wlen.p, (i64d)utotal, wcol.p);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(stream));
-        UPN = std::move(both);
-        wtotal = tot;
-        own_total = own_room;
+        wbig_list.ensure((size_t)npiv + 1);
+        wbig_count.ensure(WMAXLEV + 4);
+        wstate.ensure(WS_WORDS);
+        wblk.ensure((size_t)2 * num_cu * 16 * 4);
         own_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
+        pbits.ensure((size_t)cdiv(m, 256) * 8 + 2);
+        hipLaunchKernelGGL(k_pbits, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, qinv_r.p, pbits.p);
+        HIPCHK(hipGetLastError());
+        wbig_at.assign((size_t)depth + 2, 0);
+        build_w_levels(true);
+        u64d ws[WS_WORDS];
+        HIPCHK(hipMemcpyAsync(ws, wstate.p, sizeof ws, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(wbig_at.data(), wbig_count.p, ((size_t)depth + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (ws[WS_ERROR]) throw EngineError("a hash table of the W build filled up (internal bound violated)");
+        // rows that could not be built send the rows that need them to the multiplier lists: a few are fine, many mean W does not pay
+        if (ws[WS_UNAVAIL] * 64 > (u64d)npiv) return;
+        wtotal = (i64)std::min<u64d>(ws[WS_CURSOR], (u64d)cap);
+        w_entries = (i64)ws[WS_ENTRIES];
+        w_long_rows = (i64)ws[WS_BIGROWS];
+        own_total = own_room;
         use_w = true;
     }
 
     void run_solve(const DevMat &M, const int *rows, const int *self_idx, int nrows)
     {
+        // the plan along the rows of W; what it leaves (streams beyond the streaming classes, rows that are bound to be full of
+        // duplicate columns, rows that need a row of W that could not be built) goes through the multiplier lists
+        const bool wmode = use_w && !force_lists && !self_idx && !want_idx;
         {
             static_assert(sizeof(RoundCounters) % 4 == 0, "cleared word by word");
             const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), npool_words = NPOOL * POOL_STRIDE;
             const int span = std::max(std::max(nctr_words, npool_words), nrows + 1);
             // (the counters of the plan kernel's own-entry regions are cleared here as well: one launch less per step)
-            const bool wmode = use_uinv && use_w && !force_lists && !self_idx && !want_idx;
             if (wmode) own_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
             hipLaunchKernelGGL(k_solve_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, nrows, (unsigned *)ctr.p, nctr_words, pool_ctr.p,
                                npool_words, class_count.p, (int)NCLASS, bound.p, pmask.p, sflag.p, wmode ? own_ctr.p : (u64d *)nullptr);
@@ -754,7 +867,7 @@ struct Round {
         a.Lpool2 = nullptr;
         a.lpool_cap = region_cap;
         a.pool_ctr = pool_ctr.p;
-            a.npool = npool_active;
+        a.npool = npool_active;
         a.Lstart = Lstart.p;
         a.Llen = Llen.p;
         a.bound = bound.p;
@@ -763,109 +876,110 @@ struct Round {
         a.overflow_count = &ctr.p->solve_overflow;
         a.ctr = ctr.p;
         a.F = F;
-        if (use_uinv) {
-            rstart.ensure((size_t)nrows + 1);
-            rlen.ensure((size_t)nrows + 1);
-            // (a plan reduces the same rows of the same matrix every time: their (start, length) pairs are gathered once)
-            if (!(quiet_known && gathered_n == nrows)) {
-                hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, rstart.p, rlen.p);
-                HIPCHK(hipGetLastError());
-                gathered_n = nrows;
+        if (!wmode && !use_uinv) {
+            launch_chain(a, nrows, true);
+            return;
+        }
+        rstart.ensure((size_t)nrows + 1);
+        rlen.ensure((size_t)nrows + 1);
+        // (a plan reduces the same rows of the same matrix every time: their (start, length) pairs are gathered once)
+        if (!(quiet_known && gathered_n == nrows)) {
+            hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, rstart.p, rlen.p);
+            HIPCHK(hipGetLastError());
+            gathered_n = nrows;
+        }
+        if (wmode) {
+            wreject_list.ensure((size_t)nrows + 1);
+            WPlanArgs wp;
+            wp.nrows = nrows;
+            wp.rstart = rstart.p;
+            wp.rlen = rlen.p;
+            wp.ent = M.ent.p;
+            wp.pbits = pbits.p;
+            wp.wcol = wcol.p;
+            wp.Lpool = Lpool.p;
+            wp.lpool_cap = region_cap;
+            wp.pool_ctr = pool_ctr.p;
+            wp.npool = npool_active;
+            wp.upn = UPN.p;
+            wp.own_base = (unsigned)own_base;
+            wp.own_cap = (u64d)own_total / (u64d)npool_active;
+            wp.own_ctr = own_ctr.p;
+            wp.Lstart = Lstart.p;
+            wp.Llen = Llen.p;
+            wp.bound = bound.p;
+            wp.pmask = pmask.p;
+            wp.sflag = sflag.p;
+            wp.free_cols = free_cols;
+            wp.max_bound = (int)kClasses[kNumStreamClasses - 1].cap;
+            wp.wave_row_bound = (int)kClasses[2].cap;
+            wp.overflow_list = wreject_list.p;
+            wp.overflow_count = &ctr.p->wplan_reject;
+            wp.ctr = ctr.p;
+            wp.F = F;
+            constexpr int TEAM = 16, TPB = 256;
+            hipLaunchKernelGGL((k_wplan<TEAM, TPB>), dim3(std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 16)), dim3(TPB), 0, stream, wp);
+            HIPCHK(hipGetLastError());
+            if (!use_uinv) {
+                // no Uinv beside W: the rows the plan kernel left are solved by elimination chains
+                // (a plan that has seen its rows once knows whether anybody gets this far)
+                if (!quiet_rejects) launch_chain(a, nrows, true, wreject_list.p, &ctr.p->wplan_reject);
+                return;
             }
-            CombineArgs c;
-            c.nrows = nrows;
-            c.self_idx = self_idx;
-            c.rstart = rstart.p;
-            c.rlen = rlen.p;
-            c.ent = M.ent.p;
-            c.colinfo = colinfo.p;
-            c.pbits = pbits.p;
-            c.uhdr = uhdr.p;
-            c.UinvPool = UinvPool.p;
-            c.Lpool = Lpool.p;
-            c.Lidx = want_idx ? Lidx.p : nullptr;
-            c.sflag = nullptr; // (only the plan along W marks rows for the streaming kernel)
-            c.lpool_cap = region_cap;
-            c.pool_ctr = pool_ctr.p;
-            c.npool = npool_active;
-            c.Lstart = Lstart.p;
-            c.Llen = Llen.p;
-            c.bound = bound.p;
-            c.pmask = pmask.p;
-            c.free_cols = free_cols;
-            c.retry = nullptr;
-            c.retry_count = nullptr;
-            c.overflow_list = overflow2_list.p;
-            c.overflow_count = &ctr.p->combine_overflow;
-            c.ctr = ctr.p;
+        }
+        CombineArgs c;
+        c.nrows = nrows;
+        c.self_idx = self_idx;
+        c.rstart = rstart.p;
+        c.rlen = rlen.p;
+        c.ent = M.ent.p;
+        c.colinfo = colinfo.p;
+        c.pbits = pbits.p;
+        c.uhdr = uhdr.p;
+        c.UinvPool = UinvPool.p;
+        c.Lpool = Lpool.p;
+        c.Lidx = want_idx ? Lidx.p : nullptr;
+        c.sflag = nullptr; // (only the plan along W marks rows for the streaming kernel)
+        c.lpool_cap = region_cap;
+        c.pool_ctr = pool_ctr.p;
+        c.npool = npool_active;
+        c.Lstart = Lstart.p;
+        c.Llen = Llen.p;
+        c.bound = bound.p;
+        c.pmask = pmask.p;
+        c.free_cols = free_cols;
+        c.retry = wmode ? wreject_list.p : nullptr;
+        c.retry_count = wmode ? &ctr.p->wplan_reject : nullptr;
+        c.overflow_list = overflow2_list.p;
+        c.overflow_count = &ctr.p->combine_overflow;
+        c.ctr = ctr.p;
+        {
+            const char *dbg = getenv("SPASM_DBG"); // timing ablations (diagnostic builds only)
+            c.dbg = dbg ? atoi(dbg) : 0;
+        }
+        c.F = F;
+        {
+            constexpr int TEAM = 16, LOGC = 8, TPB = 256; // up to 128 distinct pivots per row
+            const int grid = std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 8);
+            if (F.small) hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, true>), dim3(grid), dim3(TPB), 0, stream, c);
+            else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
+            HIPCHK(hipGetLastError());
+        }
+        // (a plan that has seen its rows once knows whether anybody gets this far: three or four launches of ~8 us each, in
+        // order, are a tenth of the step of a 1/8 shard)
+        if (!quiet_fallbacks) {
+            c.retry = overflow2_list.p;
+            c.retry_count = &ctr.p->combine_overflow;
+            c.overflow_list = overflow_list.p;
+            c.overflow_count = &ctr.p->solve_overflow;
             {
-                const char *dbg = getenv("SPASM_DBG"); // timing ablations (diagnostic builds only)
-                c.dbg = dbg ? atoi(dbg) : 0;
-            }
-            c.F = F;
-            const bool wmode = use_w && !force_lists && !self_idx && !want_idx;
-            if (wmode) {
-                // the plan along the rows of W; what it leaves (streams beyond the streaming classes, rows that are bound to be full
-                // of duplicate columns) goes through the multiplier lists below
-                wreject_list.ensure((size_t)nrows + 1);
-                WPlanArgs wp;
-                wp.nrows = nrows;
-                wp.rstart = rstart.p;
-                wp.rlen = rlen.p;
-                wp.ent = M.ent.p;
-                wp.pbits = pbits.p;
-                wp.wcol = wcol.p;
-                wp.Lpool = Lpool.p;
-                wp.lpool_cap = region_cap;
-                wp.pool_ctr = pool_ctr.p;
-                wp.npool = npool_active;
-                wp.upn = UPN.p;
-                wp.own_base = (unsigned)(utotal + wtotal);
-                wp.own_cap = (u64d)own_total / (u64d)npool_active;
-                wp.own_ctr = own_ctr.p;
-                wp.Lstart = Lstart.p;
-                wp.Llen = Llen.p;
-                wp.bound = bound.p;
-                wp.pmask = pmask.p;
-                wp.sflag = sflag.p;
-                wp.free_cols = free_cols;
-                wp.max_bound = (int)kClasses[kNumStreamClasses - 1].cap;
-                wp.wave_row_bound = (int)kClasses[2].cap;
-                wp.overflow_list = wreject_list.p;
-                wp.overflow_count = &ctr.p->wplan_reject;
-                wp.ctr = ctr.p;
-                wp.F = F;
-                constexpr int TEAM = 16, TPB = 256;
-                hipLaunchKernelGGL((k_wplan<TEAM, TPB>), dim3(std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 16)), dim3(TPB), 0, stream, wp);
-                HIPCHK(hipGetLastError());
-                c.retry = wreject_list.p;
-                c.retry_count = &ctr.p->wplan_reject;
-            }
-            {
-                constexpr int TEAM = 16, LOGC = 8, TPB = 256; // up to 128 distinct pivots per row
-                const int grid = std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 8);
+                constexpr int TEAM = 64, LOGC = 12, TPB = 64; // one wave per row, up to 2048 distinct pivots
+                const int grid = std::min(nrows, num_cu * 4);
                 if (F.small) hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, true>), dim3(grid), dim3(TPB), 0, stream, c);
                 else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
                 HIPCHK(hipGetLastError());
             }
-            // (a plan that has seen its rows once knows whether anybody gets this far: three or four launches of ~8 us each, in
-            // order, are a tenth of the step of a 1/8 shard)
-            if (!quiet_fallbacks) {
-                c.retry = overflow2_list.p;
-                c.retry_count = &ctr.p->combine_overflow;
-                c.overflow_list = overflow_list.p;
-                c.overflow_count = &ctr.p->solve_overflow;
-                {
-                    constexpr int TEAM = 64, LOGC = 12, TPB = 64; // one wave per row, up to 2048 distinct pivots
-                    const int grid = std::min(nrows, num_cu * 4);
-                    if (F.small) hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, true>), dim3(grid), dim3(TPB), 0, stream, c);
-                    else hipLaunchKernelGGL((k_combine<TEAM, LOGC, TPB, false>), dim3(grid), dim3(TPB), 0, stream, c);
-                    HIPCHK(hipGetLastError());
-                }
-                launch_chain(a, nrows, false); // what is left: chain classes
-            }
-        } else {
-            launch_chain(a, nrows, true);
+            launch_chain(a, nrows, false); // what is left: chain classes
         }
     }
 
@@ -938,11 +1052,9 @@ struct Round {
         return tot;
     }
 
-    // `recs`: the records the row lists index (the multiplier pool; the records of W's rows when W itself is built)
-    void run_scatter(const DevMat &M, const int *rows, int nrows, const int4 *recs = nullptr)
+    void run_scatter(const DevMat &M, const int *rows, int nrows)
     {
-        const bool building_w = recs != nullptr;
-        if (!recs) recs = Lpool.p;
+        const int4 *recs = Lpool.p;
         S.n = nrows;
         S.m = m;
         nlaunch = 0;
@@ -950,7 +1062,7 @@ struct Round {
         // (class_count was cleared by the reset kernel of the solve that precedes every scatter)
         int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1; // 12-byte slots: the 2^14 table exceeds LDS
         // the streaming kernel goes along the rows of W (the plan kernel marks the rows it can take)
-        const bool streaming = use_w && !building_w && !force_lists;
+        const bool streaming = use_w && !force_lists && !want_idx;
         BinArgs b;
         b.nrows = nrows;
         b.bound = bound.p;
@@ -988,7 +1100,7 @@ struct Round {
         a.F = F;
         {
             const char *dbg = getenv("SPASM_DBG"); // timing ablations of the scatter kernel (wrong results when set)
-            a.dbg = dbg && !building_w ? atoi(dbg) : 0;
+            a.dbg = dbg ? atoi(dbg) : 0;
         }
         a.stamps = nullptr;
 #ifdef SPASM_STAMPS
@@ -1334,6 +1446,12 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     st.stream_redo = R.hctr.stream_redo;
     st.ms_uinv = R.ms_uinv;
     st.ms_w = R.ms_w;
+    if (R.use_w) {
+        if (hipEventElapsedTime(&ms, R.ev[4], R.ev[1]) == hipSuccess) st.ms_wbuild = ms;
+        st.w_levels = R.depth + 1;
+        st.w_entries = R.w_entries;
+        st.w_long_rows = R.w_long_rows;
+    }
     (void)hipGetLastError(); // (an event that was never recorded makes hipEventElapsedTime fail: not an error of the engine)
 }
 
@@ -2103,8 +2221,11 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         }
         R->mark_local(*cur, 0);
         R->build_U(*cur, R->pivrow.p);
-        R->prepare_uinv(R->nnp);
+        // W (level by level, no Uinv) when many more rows than pivots are reduced and the pivot graph is shallow; otherwise Uinv
+        // for the multiplier lists, or elimination chains when that is too dense as well
         R->prepare_w(R->nnp, cur_nnz);
+        if (R->use_w) { R->use_uinv = false; R->ms_uinv = 0; }
+        else R->prepare_uinv(R->nnp);
         const int nnp = R->nnp;
         // The multiplier records and the slots of the Schur rows of ALL non-pivot rows normally fit (config 3: 0.5 + 4.6 GB).
         // Rounds whose rows reach tens of thousands of pivots (Macaulay-like) can need more than the device has: the rows
@@ -2138,7 +2259,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         const int free_now = m - (int)U.pivcol.size() - R->npiv;
         const bool dense_possible = use_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries(dense_elem_bytes(R->F, nnp));
         std::unique_ptr<DenseW> dw;
-        if (nnp > 0 && dense_possible && !R->use_uinv) {
+        if (nnp > 0 && dense_possible && !R->use_uinv && !R->use_w) {
             // No Uinv: the rows of this round reach many pivots (or there are few rows), and the row sample below would walk those
             // reaches one dependent step at a time (1.7 s for 2048 rows of the 200k x 80k Macaulay-like case).  Sample COLUMNS
             // instead: the Schur complement on 64 of its columns, all rows, through a dense W.
@@ -2927,6 +3048,16 @@ struct spasm_amd_shard {
 
 namespace {
 
+// what a plan's round needs beside U: W when the round can go along it (rebuilt by every run: it is part of the Schur step),
+// else Uinv for the multiplier lists
+void plan_prepare(spasm_amd_schur_plan *P)
+{
+    Round &R = P->R;
+    R.prepare_w((i64)1 << 62, P->nnz_in);
+    if (R.use_w) { R.use_uinv = false; R.ms_uinv = 0; }
+    else R.prepare_uinv();
+}
+
 // dry run of the solve on the multiplier lists: sizes the record pool and the Schur slots (the bounds along W are no larger)
 // and counts the reference's trip counters once
 void plan_dry_run(spasm_amd_schur_plan *P, i64 pool_guess)
@@ -2947,6 +3078,7 @@ void plan_dry_run(spasm_amd_schur_plan *P, i64 pool_guess)
         tot2 = R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, pool_guess);
         const RoundCounters c2 = R.read_counters(); // the plan runs exactly this again: the same rows take the same classes
         R.quiet_fallbacks = c2.combine_overflow == 0 && c2.solve_overflow == 0 && c2.solve_failed == 0;
+        R.quiet_rejects = c2.wplan_reject == 0;
         R.quiet_known = true;
     }
     R.S.ent.ensure((size_t)std::max(tot, tot2) + 1);
@@ -3069,8 +3201,7 @@ spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries
     if (n_entries > 0) HIPCHK(hipMemcpyAsync(PM.ent.p, ent_dev, (size_t)n_entries * sizeof(int2), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipEventRecord(R.ev[0], s));
     R.build_U(PM, P->rowsrc.p);
-    R.prepare_uinv(); // a plan is run many times: Uinv always pays
-    R.prepare_w((i64)1 << 62, P->nnz_in);
+    plan_prepare(P);
     HIPCHK(hipEventRecord(R.ev[1], s));
     plan_dry_run(P, 4 * std::max<i64>(P->nnz_in, 1 << 14));
     S->plan = nullptr; // ownership passes to the caller
@@ -3183,8 +3314,7 @@ spasm_amd_schur_plan *plan_create(const struct spasm_csr *A, int lo, int hi, int
     R.assign_pivots();
     R.mark_local(P->A, 0, lo, hi, 1, stride);
     R.build_U(P->A, R.pivrow.p);
-    R.prepare_uinv(); // a plan is run many times: Uinv always pays
-    R.prepare_w((i64)1 << 62, P->nnz_in);
+    plan_prepare(P.get());
     HIPCHK(hipEventRecord(R.ev[1], s));
     plan_dry_run(P.get(), 4 * spasm_nnz(A));
     return P.release();
@@ -3194,6 +3324,11 @@ void plan_run(spasm_amd_schur_plan *P, hipStream_t s)
 {
     Round &R = P->R;
     R.stream = s;
+    // the whole Schur step of the round (reference spasm_schur, src/SpaSM.jl:761-762: the per-row solve is inside it): W from
+    // U, the plan of every row, the scatter.  ev[4] .. ev[1] = the W build.
+    HIPCHK(hipEventRecord(R.ev[4], s));
+    if (R.use_w) R.build_w_levels(false);
+    else if (R.use_uinv) R.prepare_uinv();
     HIPCHK(hipEventRecord(R.ev[1], s));
     R.run_solve(P->A, R.np_rows.p, nullptr, R.nnp);
     R.run_bounds(R.nnp);

@@ -280,43 +280,10 @@ __device__ __forceinline__ void stream_report(unsigned res, unsigned old, bool p
 // (x_b * U_PN with x_b = B[k]_P * Uinv, re-associated; same x_a, reference src/SpaSM.jl:704-707).  A row of config 3 applies
 // ~34 pivot rows of ~17 entries through its multiplier list; it has ~3.4 entries on pivot columns, and their rows of W hold the
 // same ~580 entries in 3.4 contiguous runs: no multiplier list to build, and a wave streams a run 64 entries at a time with
-// every lane busy.  W is built once per round by the hash-table scatter kernel from the rows of Uinv (k_uinv_records below
-// turns them into its records); the entries of W live behind those of U_PN in one buffer, so a record {position << 16 | len,
-// -a_c, offset, len} reads the same for every scatter kernel.
+// every lane busy.  W is built by every Schur step, level by level of the pivot graph (wlevel.hpp); its rows live in one buffer
+// with U_PN and the rows' own entries, so a record {position << 16 | len, -a_c, offset, len} reads the same for every scatter
+// kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_uinv_records(int npiv, const i64d *__restrict__ UinvStart, const int *__restrict__ UinvLen, const int2 *__restrict__ UinvPool,
-                               const UHdr *__restrict__ uhdr, int4 *__restrict__ rec, i64d *__restrict__ bound, i64d free_cols)
-{
-    constexpr int TEAM = 8;
-    const int tl = threadIdx.x % TEAM;
-    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
-    if (i > npiv) return;
-    if (i == npiv) { if (tl == 0) bound[i] = 0; return; }
-    const i64d st = UinvStart[i];
-    const int ln = UinvLen[i];
-    i64d b = 0;
-    for (int k = tl; k < ln; k += TEAM) {
-        const int2 e = UinvPool[st + k];
-        UHdr h; h.off = 0; h.npn = 0;
-        if (e.y != 0) h = uhdr[e.x];
-        rec[st + k] = make_int4(0, e.y, (int)h.off, h.npn);
-        b += h.npn;
-    }
-    for (int o = TEAM / 2; o > 0; o >>= 1) b += __shfl_xor(b, o, TEAM);
-    if (tl == 0) bound[i] = b < free_cols ? b : free_cols;
-}
-
-// per column: {pivot index or -1, length of its row of W, offset of that row in the U_PN + W buffer, -}
-__global__ void k_wcolinfo(int m, const int *__restrict__ qinv_r, const i64d *__restrict__ Wstart, const int *__restrict__ Wlen, i64d wbase,
-                           int4 *__restrict__ wcol)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const int q = qinv_r[j];
-    int4 r = make_int4(q, 0, 0, 0);
-    if (q >= 0) { r.y = Wlen[q]; r.z = (int)(unsigned)(wbase + Wstart[q]); }
-    wcol[j] = r;
-}
 
 // ------------------------------------------------------------------------------------------------
 // The plan of a row's Schur row under W: the run of every entry on a pivot column, cut into chunks of 64 entries with one record
@@ -331,12 +298,12 @@ struct WPlanArgs {
     const int *rlen;
     const int2 *ent;
     const unsigned *pbits;     // bit j: column j is a pivot column of this round
-    const int4 *wcol;
-    int4 *Lpool;               // records {position << 16 | entries, -multiplier, offset in the U_PN + W + own buffer, entries}
+    const int4 *wcol;          // per pivot column: {pivot index, length of its row of W (-1: not available), offset, -}
+    int4 *Lpool;               // records {position << 16 | entries, -multiplier, offset in the U_PN + own + W buffer, entries}
     u64d lpool_cap;            // records per pool region
     u64d *pool_ctr;
     int npool;
-    int2 *upn;                 // the U_PN + W + own buffer: the rows' own entries on non-pivot columns are copied behind W
+    int2 *upn;                 // the U_PN + own + W buffer: the rows' own entries on non-pivot columns are copied in front of W
     unsigned own_base;         // where that part starts
     u64d own_cap;              // entries per region of it
     u64d *own_ctr;             // its bump counters (NPOOL, POOL_STRIDE apart)
@@ -424,7 +391,7 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
             if (isP) ci = a.wcol[e.x];
             if (k0 == 0) { ci_a = ci; pa = isP; }
             if (k0 == TEAM) { ci_b = ci; pb = isP; }
-            zero_own |= valid && e.y == 0;
+            zero_own |= valid && (e.y == 0 || (isP && ci.y < 0)); // (a row of W that could not be built: the lists take the row)
             const u64d mP = team_ballot<TEAM>(isP);
             if (k0 < 64) pm |= mP << (k0 & 63);
             int tot;

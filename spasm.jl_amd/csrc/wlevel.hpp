@@ -1,0 +1,485 @@
+// wlevel.hpp -- W = -(I + U_PP)^-1 * U_PN built level by level of the pivot graph (no Uinv, no host synchronisation).
+//
+// W is what lets a non-pivot row's Schur row be written as  x_a = B[k]_N + sum_c a_c * W[qinv(c)]  (stream.hpp; the solve
+// x_b * U + x_a = B[k] of reference src/SpaSM.jl:694-713 re-associated).  Row q of W satisfies
+//        W[q] = -U_PN[q] - sum over the entries (c, v) of U_PP[q] of v * W[c]
+// and U_PP only refers to pivots that come later in the topological order, so with
+//        level(q) = 0 when U_PP[q] is empty, 1 + max level(c) otherwise
+// all rows of one level are independent: one launch per level, every row a sparse combination of finished rows.  (The reference
+// reaches the same pivot rows by a depth-first search per row, spasm_reach, src/SpaSM.jl:627-628; the levels are the breadth-first
+// image of that search, computed once per round for all rows.)
+//
+// A row is merged in an LDS hash table (column -> lazy accumulator) sized by its bound npn + sum len(W[c]), swept, compacted and
+// stored behind the rows before it: a wave per row up to 512 entries (k_wlevel_wave), the workgroup for longer ones
+// (k_wlevel_wg).  Output space comes from one cursor; a wave takes 1024 entries at a time, so the cursor sees one atomic per
+// ~6 rows, and keeps what is left of its block for the next level.  A row that cannot be built (longer than the largest table,
+// or the region is full) is published with length -1: the plan kernel sends the rows that would need it to the multiplier lists.
+#pragma once
+#include "kernels.hpp"
+
+constexpr int WMAXLEV = 254;                    // deeper pivot graphs keep to the multiplier lists
+constexpr int WL_TMAX = 1024;                   // table slots of a wave
+constexpr int WL_WAVE_BOUND = WL_TMAX / 2;      // longest bound a wave takes (tables at most half full)
+constexpr int WL_NCD = 64;                      // chunk descriptors of a wave
+constexpr u64d WL_BLK = 1024;                   // entries a wave takes from the cursor at a time
+constexpr int WL_WG_NCD = 512;                  // chunk descriptors of a workgroup batch (256 dependencies + the longest bound / 64)
+// wstate words
+constexpr int WS_CURSOR = 0, WS_UNAVAIL = 1, WS_ERROR = 2, WS_ENTRIES = 3, WS_BIGROWS = 4, WS_WORDS = 8;
+
+// one bit per column: is it a pivot column of this round?  (blockDim.x is a multiple of 64: whole waves, whole bitmap words)
+__global__ void k_pbits(int m, const int *__restrict__ qinv_r, unsigned *__restrict__ pbits)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = j < m ? qinv_r[j] : -1;
+    const u64d b = __ballot(q >= 0);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 31) == 0) pbits[j >> 5] = (unsigned)(b >> lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// levels of the pivot graph by relaxation: lev[q] = max(lev[q], 1 + max lev[c]).  Every launch sees at least the values the
+// launch before it left, so `depth + 1` launches reach the fixed point; *changed (when given) tells whether this one moved
+// anything.  The loads and stores race with those of other threads on purpose (monotone: a stale value only delays).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lev_relax(int npiv, const UHdr *__restrict__ uhdr, const int2 *__restrict__ UPP, int *lev, int *changed, int sweeps)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= npiv) return;
+    const UHdr h = uhdr[q];
+    if (h.npp == 0) return;
+    int cur = __hip_atomic_load(&lev[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ch = false;
+    for (int s = 0; s < sweeps; s++) {
+        int l = 0;
+        for (int k = 0; k < h.npp; k++) {
+            const int c = UPP[(size_t)h.off + k].x;
+            l = max(l, __hip_atomic_load(&lev[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1);
+        }
+        if (l > cur) {
+            cur = l;
+            ch = true;
+            __hip_atomic_store(&lev[q], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (ch && changed) *changed = 1;
+}
+
+// keys = the levels in ascending order: lev_start[L] = first position of level L (levels are contiguous: a row of level L
+// depends on one of level L - 1); lev_start[] is prefilled with npiv
+__global__ void k_lev_starts(int npiv, const int *__restrict__ keys, int *__restrict__ lev_start, int maxlev)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npiv) return;
+    const int k = keys[i];
+    const int kp = i ? keys[i - 1] : -1;
+    for (int L = kp + 1; L <= k && L <= maxlev; L++) lev_start[L] = i;
+}
+
+__global__ void k_fill_int(int n, int v, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+// what a build starts from: cursor and statistics zero, every wave without a block, no long rows at any level
+__global__ void k_wbuild_reset(u64d *__restrict__ wstate, u64d *__restrict__ wblk, int nblk_words, int *__restrict__ big_count, int nlev)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < WS_WORDS) wstate[t] = 0;
+    if (t < nblk_words) wblk[t] = 0;
+    if (t < nlev) big_count[t] = 0;
+}
+
+struct WLevelArgs {
+    int cnt;                   // rows of this level
+    const int *order;          // their pivot indices
+    const UHdr *uhdr;
+    const int2 *UPP;           // {pivot index, value} of the entries on other pivot columns
+    int2 *buf;                 // [U_PN | own entries of the plan | W]: rows of W are read and written here
+    int2 *wrow;                // per pivot index: {offset in buf, length} of its row of W (length -1: not available)
+    int4 *wcol;                // per pivot COLUMN: {pivot index, length, offset, 0} -- what the plan kernel reads
+    const int *pivcol;
+    u64d *wstate;              // WS_* words
+    unsigned wbase;            // where W starts in buf
+    u64d wcap;                 // entries of W's region
+    u64d *wblk;                // per wave slot of the wave kernel: {next free entry, end} of its block (relative to wbase)
+    int *big_list;             // rows of this level left to the workgroup kernel
+    int *big_count;
+    ZpField F;
+};
+
+// `need` entries (rounded up to 16: rows start on 128-byte lines) from the wave's block, or from the cursor when the block is
+// used up / the row is long; ~0 when the region is full.  Wave-uniform.
+__device__ __forceinline__ u64d wl_take(u64d &pos, u64d &end, int need, u64d *cursor, u64d cap)
+{
+    const int lane = threadIdx.x & 63;
+    const u64d n = ((u64d)need + 15ull) & ~15ull;
+    if (n == 0) return 0;
+    if (n > WL_BLK / 2) {
+        u64d b = 0;
+        if (lane == 0) b = atomicAdd(cursor, n);
+        b = __shfl(b, 0);
+        return b + n <= cap ? b : ~0ull;
+    }
+    if (pos + n > end) {
+        u64d b = 0;
+        if (lane == 0) b = atomicAdd(cursor, WL_BLK);
+        b = __shfl(b, 0);
+        if (b + WL_BLK > cap) return ~0ull;
+        pos = b;
+        end = b + WL_BLK;
+    }
+    const u64d r = pos;
+    pos += n;
+    return r;
+}
+
+// N entries of a lane into a table of mask + 1 slots (a power of two, at most half full): all pending CAS of a round are in
+// flight at once (as table_add_n, with the table size at run time).  Returns false when an entry found no slot.
+template <bool SMALL, int N>
+__device__ __forceinline__ bool wl_insert_n(int *key, typename ZpAcc<SMALL>::type *val, unsigned mask, int shift, const int (&c)[N],
+                                            const typename ZpAcc<SMALL>::type (&v)[N], unsigned pending)
+{
+    unsigned h[N], st[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const unsigned x = (unsigned)c[j] * 0x9E3779B1u;
+        h[j] = x >> shift;
+        st[j] = ((x >> 7) & mask) | 1u;
+    }
+    for (unsigned round = 0; pending != 0 && round <= mask; round++) {
+        int k[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            k[j] = 0;
+            if (pending & (1u << j)) k[j] = atomicCAS(&key[h[j]], EMPTY_KEY, c[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (pending & (1u << j)) {
+                if (k[j] == EMPTY_KEY || k[j] == c[j]) {
+                    if (SMALL) atomicAdd((int *)&val[h[j]], (int)v[j]);
+                    else atomicAdd((u64d *)&val[h[j]], (u64d)v[j]);
+                    pending &= ~(1u << j);
+                } else {
+                    h[j] = (h[j] + st[j]) & mask;
+                }
+            }
+        }
+    }
+    return pending == 0;
+}
+
+// the chunks [t0, t0 + 4), [t0 + tstep, ...) .. of a descriptor list in LDS: up to 64 consecutive entries each, multiplied and
+// accumulated; the loads of a group of 4 are in flight together
+template <bool SMALL>
+__device__ __forceinline__ bool wl_consume(lds_vint *cd_off, lds_vint *cd_len, lds_vint *cd_mul, int C, int t0, int tstep, const int2 *buf, int *key,
+                                           typename ZpAcc<SMALL>::type *val, unsigned mask, int shift, const ZpField &F)
+{
+    typedef typename ZpAcc<SMALL>::type Acc;
+    const int lane = threadIdx.x & 63;
+    bool ok = true;
+    for (int g0 = t0; g0 < C; g0 += tstep) {
+        int2 e[4];
+        int cl[4], cm[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = min(g0 + u, C - 1);
+            const unsigned co = (unsigned)cd_off[t];
+            cl[u] = g0 + u < C ? cd_len[t] : 0;
+            cm[u] = cd_mul[t];
+            e[u] = buf[(size_t)co + (unsigned)min(lane, max(cl[u] - 1, 0))]; // unconditional, clamped into the chunk
+        }
+        int cc[4];
+        Acc vv[4];
+        unsigned pend = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            cc[u] = e[u].x;
+            vv[u] = ZpAcc<SMALL>::mul_lazy(F, cm[u], e[u].y);
+            if (lane < cl[u]) pend |= 1u << u;
+        }
+        ok &= wl_insert_n<SMALL, 4>(key, val, mask, shift, cc, vv, pend);
+    }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one level, a wave per row
+// ------------------------------------------------------------------------------------------------
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
+{
+    typedef typename ZpAcc<SMALL>::type Acc;
+    __shared__ int s_key[4][WL_TMAX];
+    __shared__ Acc s_val[4][WL_TMAX];
+    __shared__ int s_cd[4][3][WL_NCD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int *key = s_key[wave];
+    Acc *val = s_val[wave];
+    lds_vint *cd_off = (lds_vint *)s_cd[wave][0], *cd_len = (lds_vint *)s_cd[wave][1], *cd_mul = (lds_vint *)s_cd[wave][2];
+    const ZpField F = a.F;
+    const int wslot = (int)blockIdx.x * 4 + wave;
+    const int stride = (int)gridDim.x * 4;
+    if (wslot >= a.cnt) return;
+    u64d bpos = a.wblk[2 * wslot], bend = a.wblk[2 * wslot + 1];
+    bpos = __shfl(bpos, 0);
+    bend = __shfl(bend, 0);
+    u64d c_ent = 0;
+    int c_unavail = 0, c_err = 0, c_big = 0;
+
+    // pipeline: the pivot index two rows ahead, the header one row ahead (clamped: past the end, the last row again)
+    int q_c = a.order[min(wslot, a.cnt - 1)], q_n = a.order[min(wslot + stride, a.cnt - 1)];
+    UHdr h_c = a.uhdr[q_c];
+    for (int i = wslot; i < a.cnt; i += stride) {
+        const int q_nn = a.order[min(i + 2 * stride, a.cnt - 1)];
+        const UHdr h_n = a.uhdr[q_n];
+        const int q = __builtin_amdgcn_readfirstlane(q_c);
+        const unsigned uo = (unsigned)__builtin_amdgcn_readfirstlane((int)h_c.off);
+        const int npp = __builtin_amdgcn_readfirstlane(h_c.npp), npn = __builtin_amdgcn_readfirstlane(h_c.npn);
+        unsigned out_off = 0;
+        int n_out = 0;
+        bool avail = true, deferred = false;
+        if (npp == 0) {
+            // level 0: W[q] = -U_PN[q]
+            const u64d r = wl_take(bpos, bend, npn, a.wstate + WS_CURSOR, a.wcap);
+            if (r == ~0ull) avail = false;
+            else {
+                out_off = a.wbase + (unsigned)r;
+                for (int k = lane; k < npn; k += 64) {
+                    const int2 e = a.buf[(size_t)uo + k];
+                    a.buf[(size_t)out_off + k] = make_int2(e.x, zp_neg(F, e.y));
+                }
+                n_out = npn;
+            }
+        } else {
+            bool big = npp > 64;
+            int2 dep = make_int2(0, 0), wr = make_int2(0, 0);
+            if (!big && lane < npp) {
+                dep = a.UPP[(size_t)uo + lane];
+                wr = a.wrow[dep.x];
+            }
+            if (__ballot(wr.y < 0) != 0) avail = false; // a row this one needs could not be built
+            else {
+                const int wl = wr.y, nch = (wl + 63) >> 6;
+                int tot_len, tot_ch;
+                (void)team_incl_scan<64>(wl, tot_len);
+                const int incl_ch = team_incl_scan<64>(nch, tot_ch);
+                const int bound = npn + tot_len, own_ch = (npn + 63) >> 6, C = own_ch + tot_ch;
+                big = big || bound > WL_WAVE_BOUND || C > WL_NCD;
+                if (big) {
+                    if (lane == 0) a.big_list[atomicAdd(a.big_count, 1)] = q;
+                    deferred = true;
+                    c_big++;
+                } else {
+                    // chunk descriptors: the row's own entries first (multiplier -1), then the runs of the dependencies
+                    const int nm = zp_neg(F, dep.y);
+                    const int cbase = own_ch + incl_ch - nch;
+                    for (int r = 0; r < nch; r++) {
+                        cd_off[cbase + r] = (int)((unsigned)wr.x + 64u * (unsigned)r);
+                        cd_len[cbase + r] = min(64, wl - 64 * r);
+                        cd_mul[cbase + r] = nm;
+                    }
+                    for (int r = lane; r < own_ch; r += 64) {
+                        cd_off[r] = (int)(uo + 64u * (unsigned)r);
+                        cd_len[r] = min(64, npn - 64 * r);
+                        cd_mul[r] = -1;
+                    }
+                    int logt = 7;
+                    while ((1 << logt) < 2 * bound) logt++;
+                    const int T = 1 << logt;
+                    const unsigned mask = (unsigned)T - 1u;
+                    for (int s = lane; s < T; s += 64) { key[s] = EMPTY_KEY; val[s] = 0; }
+                    __builtin_amdgcn_wave_barrier();
+                    const bool ok = wl_consume<SMALL>(cd_off, cd_len, cd_mul, C, 0, 4, a.buf, key, val, mask, 32 - logt, F);
+                    if (__ballot(!ok) != 0) c_err++;
+                    __builtin_amdgcn_wave_barrier();
+                    // sweep: count, take the space, write
+                    int tot = 0;
+                    for (int s0 = 0; s0 < T; s0 += 64) {
+                        const int k = key[s0 + lane];
+                        const int r = k == EMPTY_KEY ? 0 : acc_reduce_short<SMALL>(F, val[s0 + lane]);
+                        tot += __popcll(__ballot(r != 0));
+                    }
+                    const u64d r0 = wl_take(bpos, bend, tot, a.wstate + WS_CURSOR, a.wcap);
+                    if (r0 == ~0ull) avail = false;
+                    else {
+                        out_off = a.wbase + (unsigned)r0;
+                        int pos = 0;
+                        for (int s0 = 0; s0 < T; s0 += 64) {
+                            const int k = key[s0 + lane];
+                            const int r = k == EMPTY_KEY ? 0 : acc_reduce_short<SMALL>(F, val[s0 + lane]);
+                            const u64d mm = __ballot(r != 0);
+                            if (r != 0) a.buf[(size_t)out_off + pos + __popcll(mm & lanemask_lt())] = make_int2(k, r);
+                            pos += __popcll(mm);
+                        }
+                        n_out = tot;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (!deferred) {
+            if (lane == 0) {
+                const int len = avail ? n_out : -1;
+                a.wrow[q] = make_int2((int)out_off, len);
+                a.wcol[a.pivcol[q]] = make_int4(q, len, (int)out_off, 0);
+            }
+            if (avail) c_ent += (u64d)n_out; else c_unavail++;
+        }
+        q_c = q_n;
+        q_n = q_nn;
+        h_c = h_n;
+    }
+    if (lane == 0) {
+        a.wblk[2 * wslot] = bpos;
+        a.wblk[2 * wslot + 1] = bend;
+        if (c_ent) atomicAdd(a.wstate + WS_ENTRIES, c_ent);
+        if (c_unavail) atomicAdd(a.wstate + WS_UNAVAIL, (u64d)c_unavail);
+        if (c_err) atomicAdd(a.wstate + WS_ERROR, (u64d)c_err);
+        if (c_big) atomicAdd(a.wstate + WS_BIGROWS, (u64d)c_big);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the long rows of a level, a workgroup per row: table of up to 16384 (8192 for large primes) slots in dynamic LDS
+// ------------------------------------------------------------------------------------------------
+template <bool SMALL> constexpr int wl_wg_slots() { return SMALL ? 16384 : 8192; }
+template <bool SMALL> constexpr size_t wl_wg_lds_bytes()
+{
+    return (size_t)wl_wg_slots<SMALL>() * (sizeof(typename ZpAcc<SMALL>::type) + 4) + (size_t)3 * WL_WG_NCD * 4 + 64;
+}
+
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
+{
+    typedef typename ZpAcc<SMALL>::type Acc;
+    constexpr int TB = wl_wg_slots<SMALL>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    Acc *val = (Acc *)s_raw;
+    int *key = (int *)(s_raw + sizeof(Acc) * (size_t)TB);
+    lds_vint *cd_off = (lds_vint *)(key + TB), *cd_len = cd_off + WL_WG_NCD, *cd_mul = cd_len + WL_WG_NCD;
+    lds_vint *s_misc = cd_mul + WL_WG_NCD; // 16 words
+    const int nbig = *a.big_count;
+    if ((int)blockIdx.x >= nbig) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ZpField F = a.F;
+    for (int i = blockIdx.x; i < nbig; i += gridDim.x) {
+        const int q = a.big_list[i];
+        const UHdr h = a.uhdr[q];
+        const unsigned uo = h.off;
+        const int npp = h.npp, npn = h.npn;
+        // ---- bound of the row, and whether every row it needs is there
+        long long mylen = 0;
+        bool un = false;
+        for (int k = tid; k < npp; k += 256) {
+            const int2 d = a.UPP[(size_t)uo + k];
+            const int2 wr = a.wrow[d.x];
+            un |= wr.y < 0;
+            mylen += max(wr.y, 0);
+        }
+        for (int o = 32; o > 0; o >>= 1) mylen += __shfl_xor(mylen, o);
+        const bool wun = __ballot(un) != 0;
+        if (lane == 0) { s_misc[wave] = (int)min(mylen, (long long)INT_MAX / 8); s_misc[4 + wave] = wun ? 1 : 0; }
+        __syncthreads();
+        long long bound = npn;
+        bool unavail = false;
+        for (int w2 = 0; w2 < 4; w2++) { bound += s_misc[w2]; unavail |= s_misc[4 + w2] != 0; }
+        bool avail = !unavail && bound <= TB / 2;
+        unsigned out_off = 0;
+        int n_out = 0;
+        if (avail) { // (uniform over the workgroup)
+            int logt = 10;
+            while ((1ll << logt) < 2 * bound) logt++;
+            const int T = 1 << logt;
+            const unsigned mask = (unsigned)T - 1u;
+            const int shift = 32 - logt;
+            for (int s = tid; s < T; s += 256) { key[s] = EMPTY_KEY; val[s] = 0; }
+            __syncthreads();
+            bool ok = true;
+            // the row's own entries on non-pivot columns
+            for (int k = tid; k < npn; k += 256) {
+                const int2 e = a.buf[(size_t)uo + k];
+                const int cc[1] = {e.x};
+                const Acc vv[1] = {ZpAcc<SMALL>::mul_lazy(F, -1, e.y)};
+                ok &= wl_insert_n<SMALL, 1>(key, val, mask, shift, cc, vv, 1u);
+            }
+            // its dependencies, 256 at a time: their runs become chunks, the waves take groups of 4 chunks in turn
+            for (int b0 = 0; b0 < npp; b0 += 256) {
+                int2 d = make_int2(0, 0), wr = make_int2(0, 0);
+                if (b0 + tid < npp) {
+                    d = a.UPP[(size_t)uo + b0 + tid];
+                    wr = a.wrow[d.x];
+                }
+                const int wl = wr.y, nch = (wl + 63) >> 6;
+                int wtot;
+                const int incl = team_incl_scan<64>(nch, wtot);
+                __syncthreads(); // (the chunks of the batch before are consumed)
+                if (lane == 0) s_misc[8 + wave] = wtot;
+                __syncthreads();
+                int cbase = 0, Cb = 0;
+                for (int w2 = 0; w2 < 4; w2++) {
+                    const int cw = s_misc[8 + w2];
+                    if (w2 < wave) cbase += cw;
+                    Cb += cw;
+                }
+                const int nm = zp_neg(F, d.y);
+                const int at = cbase + incl - nch;
+                for (int r = 0; r < nch; r++) {
+                    cd_off[at + r] = (int)((unsigned)wr.x + 64u * (unsigned)r);
+                    cd_len[at + r] = min(64, wl - 64 * r);
+                    cd_mul[at + r] = nm;
+                }
+                __syncthreads();
+                ok &= wl_consume<SMALL>(cd_off, cd_len, cd_mul, Cb, wave * 4, 16, a.buf, key, val, mask, shift, F);
+            }
+            __syncthreads();
+            // sweep: wave w owns the slots it * 256 + w * 64 + lane
+            int tot = 0;
+            for (int s0 = wave * 64; s0 < T; s0 += 256) {
+                const int k = key[s0 + lane];
+                const int r = k == EMPTY_KEY ? 0 : acc_reduce_short<SMALL>(F, val[s0 + lane]);
+                tot += __popcll(__ballot(r != 0));
+            }
+            const bool wok = __ballot(!ok) == 0;
+            if (lane == 0) { s_misc[wave] = tot; if (!wok) atomicAdd(a.wstate + WS_ERROR, 1ull); }
+            __syncthreads();
+            int pre = 0;
+            for (int w2 = 0; w2 < 4; w2++) {
+                const int cw = s_misc[w2];
+                if (w2 < wave) pre += cw;
+                n_out += cw;
+            }
+            if (tid == 0) {
+                const u64d n = ((u64d)n_out + 15ull) & ~15ull;
+                const u64d b = n ? atomicAdd(a.wstate + WS_CURSOR, n) : 0;
+                const bool fits = b + n <= a.wcap;
+                s_misc[12] = fits ? 1 : 0;
+                s_misc[13] = (int)(unsigned)b;
+            }
+            __syncthreads();
+            avail = s_misc[12] != 0;
+            if (avail) {
+                out_off = a.wbase + (unsigned)s_misc[13];
+                int pos = pre;
+                for (int s0 = wave * 64; s0 < T; s0 += 256) {
+                    const int k = key[s0 + lane];
+                    const int r = k == EMPTY_KEY ? 0 : acc_reduce_short<SMALL>(F, val[s0 + lane]);
+                    const u64d mm = __ballot(r != 0);
+                    if (r != 0) a.buf[(size_t)out_off + pos + __popcll(mm & lanemask_lt())] = make_int2(k, r);
+                    pos += __popcll(mm);
+                }
+            }
+        }
+        if (tid == 0) {
+            const int len = avail ? n_out : -1;
+            a.wrow[q] = make_int2((int)out_off, len);
+            a.wcol[a.pivcol[q]] = make_int4(q, len, (int)out_off, 0);
+            if (avail) atomicAdd(a.wstate + WS_ENTRIES, (u64d)n_out);
+            else atomicAdd(a.wstate + WS_UNAVAIL, 1ull);
+        }
+        __syncthreads();
+    }
+}
