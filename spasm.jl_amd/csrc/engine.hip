@@ -224,8 +224,12 @@ struct Round {
     i64 own_total = 0;              // entries of the part of the buffer that takes the rows' own non-pivot entries
     DevBuf<u64d> own_ctr;           // its bump counters
     DevBuf<u64d> wstate, wblk;      // cursor + statistics of the build; the blocks its waves carve rows from
-    DevBuf<int> wbig_list, wbig_count;
-    std::vector<int> wbig_at;       // per level: long rows the first build of this U left to the workgroup kernel
+    DevBuf<int> wmid_list, wbig_list, wbig_count; // rows the wave kernel leaves to the workgroup kernels; counts [2 * level + {0: medium, 1: large}]
+    std::vector<int> wbig_at;       // the counts of the first build of this U: later builds skip the launches without rows
+    DevBuf<WLevRec> lev_recs;       // the pivot rows in level order, as the level kernels read them
+    DevBuf<unsigned> lev0_sz, lev0_off; // level 0: lengths rounded up to 16, and their prefix sums = the rows' places in W
+    DevBuf<u64d> lev0_ent;
+    i64 lev0_total = 0, lev0_entries = 0;
     int wave_per_cu_blocks = 0;     // resident workgroups of k_wlevel_wave per CU
     // levels of the pivot graph: level L = lev_order[lev_start[L] .. lev_start[L + 1])
     DevBuf<int> lev, lev_keys, lev_iota, lev_order, lev_start_d, lev_flag;
@@ -724,49 +728,120 @@ struct Round {
         if (deepest > WMAXLEV) return;
         depth = deepest;
         lev_start[(size_t)depth + 1] = npiv;
+        lev_recs.ensure((size_t)npiv + 1);
+        hipLaunchKernelGGL(k_lev_recs, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, lev_order.p, uhdr.p, pivcol.p, lev_recs.p);
+        HIPCHK(hipGetLastError());
+        // level 0 (rows that are copied): their places in W, once per U
+        const int cnt0 = lev_start[1];
+        lev0_sz.ensure((size_t)cnt0 + 1);
+        lev0_off.ensure((size_t)cnt0 + 1);
+        lev0_ent.ensure(1);
+        HIPCHK(hipMemsetAsync(lev0_ent.p, 0, sizeof(u64d), stream));
+        hipLaunchKernelGGL(k_lev0_sizes, dim3(cdiv((i64)cnt0 + 1, 256)), dim3(256), 0, stream, cnt0, lev_recs.p, lev0_sz.p, lev0_ent.p);
+        HIPCHK(hipGetLastError());
+        scan.exclusive(lev0_sz.p, lev0_off.p, (size_t)cnt0 + 1, stream);
+        unsigned tot0 = 0;
+        u64d ent0 = 0;
+        HIPCHK(hipMemcpyAsync(&tot0, lev0_off.p + cnt0, sizeof tot0, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&ent0, lev0_ent.p, sizeof ent0, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        lev0_total = tot0;
+        lev0_entries = (i64)ent0;
     }
 
     // ---- W, level by level (kernels only: part of every Schur step).  first: the build that follows build_U -- the workgroup kernel
     // runs behind every level and the caller then notes where it had work (wbig_at); later builds of the same U skip the others.
+    int wblk_slots() const { return num_cu * (16 * 4 + 8 + 1); } // waves of the wave kernel, workgroups of the medium and of the large table
+    // ---- W, level by level (kernels only: part of every Schur step).  Level 0 is a copy (k_wlevel0).  A level of many rows: the
+    // wave kernel, then the workgroup kernel with the medium table for the rows it left, then the one with the largest table; a level
+    // of at most 2048 rows skips the wave kernel (a launch costs ~10 us whatever it does): all its rows go to the workgroup kernel
+    // with the medium table -- with the largest one when the level has no more rows than the chip has CUs.
+    // first: the build that follows build_U, every launch is made and the caller notes the list counts (wbig_at); later builds of
+    // the same U skip the launches whose lists were empty.
     void build_w_levels(bool first)
     {
-        const int nblk_words = 2 * num_cu * 16 * 4;
-        hipLaunchKernelGGL(k_wbuild_reset, dim3(cdiv(std::max(nblk_words, WMAXLEV + 2), 256)), dim3(256), 0, stream, wstate.p, wblk.p, nblk_words, wbig_count.p,
-                           WMAXLEV + 2);
+        const int nblk_words = 2 * wblk_slots();
+        const int ncount_words = 2 * (depth + 2) * WL_NSUB * WL_SUBSTRIDE;
+        hipLaunchKernelGGL(k_wbuild_reset, dim3(cdiv(std::max(nblk_words, ncount_words), 256)), dim3(256), 0, stream, wstate.p, wblk.p, nblk_words,
+                           wbig_count.p, ncount_words, (u64d)lev0_total);
         HIPCHK(hipGetLastError());
+        const size_t lds_mid = F.small ? wl_wg_lds_bytes<true>(wl_mid_slots()) : wl_wg_lds_bytes<false>(wl_mid_slots());
+        const int big_slots = F.small ? wl_big_slots<true>() : wl_big_slots<false>();
+        const size_t lds_big = F.small ? wl_wg_lds_bytes<true>(big_slots) : wl_wg_lds_bytes<false>(big_slots);
         if (!wave_per_cu_blocks) {
             int nb = 0;
             if (F.small) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wlevel_wave<true>, 256, 0));
             else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wlevel_wave<false>, 256, 0));
             wave_per_cu_blocks = std::min(std::max(nb, 1), 16);
-            if (F.small) HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl_wg_lds_bytes<true>()));
-            else HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl_wg_lds_bytes<false>()));
+            if (F.small) HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+            else HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
         }
+        const int mid_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds_mid + 256)));
         WLevelArgs a;
-        a.uhdr = uhdr.p;
         a.UPP = UPP.p;
         a.buf = UPN.p;
         a.wrow = wrow.p;
         a.wcol = wcol.p;
-        a.pivcol = pivcol.p;
         a.wstate = wstate.p;
         a.wbase = (unsigned)wbase;
         a.wcap = (u64d)wcap;
         a.wblk = wblk.p;
-        a.big_list = wbig_list.p;
         a.F = F;
-        for (int L = 0; L <= depth; L++) {
-            a.cnt = lev_start[(size_t)L + 1] - lev_start[(size_t)L];
-            if (a.cnt <= 0) continue;
-            a.order = lev_order.p + lev_start[(size_t)L];
-            a.big_count = wbig_count.p + L;
-            const int grid = std::min(cdiv(a.cnt, 4), num_cu * wave_per_cu_blocks);
-            if (F.small) hipLaunchKernelGGL(k_wlevel_wave<true>, dim3(grid), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL(k_wlevel_wave<false>, dim3(grid), dim3(256), 0, stream, a);
-            if (L > 0 && (first || wbig_at[(size_t)L] > 0)) {
-                const int g2 = first ? num_cu : std::min(num_cu, wbig_at[(size_t)L]);
-                if (F.small) hipLaunchKernelGGL(k_wlevel_wg<true>, dim3(g2), dim3(256), wl_wg_lds_bytes<true>(), stream, a);
-                else hipLaunchKernelGGL(k_wlevel_wg<false>, dim3(g2), dim3(256), wl_wg_lds_bytes<false>(), stream, a);
+        a.stats = first ? 1 : 0;
+        a.list_stride = npiv;
+        auto launch_wg = [&](int tier, int grid) {
+            a.tslots = tier ? big_slots : wl_mid_slots();
+            a.blk_base = num_cu * 16 * 4 + (tier ? num_cu * 8 : 0);
+            const size_t lds = tier ? lds_big : lds_mid;
+            if (F.small) hipLaunchKernelGGL(k_wlevel_wg<true>, dim3(grid), dim3(256), lds, stream, a);
+            else hipLaunchKernelGGL(k_wlevel_wg<false>, dim3(grid), dim3(256), lds, stream, a);
+        };
+        {
+            const int cnt0 = lev_start[1];
+            hipLaunchKernelGGL(k_wlevel0, dim3(std::max(1, std::min(cdiv((i64)cnt0 * 16, 256), num_cu * 8))), dim3(256), 0, stream, cnt0, lev_recs.p, lev0_off.p,
+                               UPN.p, wrow.p, wcol.p, (unsigned)wbase, F);
+        }
+        for (int L = 1; L <= depth; L++) {
+            const int cnt = lev_start[(size_t)L + 1] - lev_start[(size_t)L];
+            if (cnt <= 0) continue;
+            int *const mid_count = wbig_count.p + (size_t)(2 * L) * WL_NSUB * WL_SUBSTRIDE, *const big_count = wbig_count.p + (size_t)(2 * L + 1) * WL_NSUB * WL_SUBSTRIDE;
+            const int known_mid = first ? -1 : wbig_at[(size_t)(2 * L)], known_big = first ? -1 : wbig_at[(size_t)(2 * L + 1)];
+            a.cnt = cnt;
+            a.rec_base = lev_start[(size_t)L];
+            a.mid_list = wmid_list.p;
+            a.mid_count = mid_count;
+            a.big_list = wbig_list.p;
+            a.big_count = big_count;
+            a.list = nullptr;
+            a.count = nullptr;
+            if (cnt > 2048) {
+                a.recs = lev_recs.p + lev_start[(size_t)L];
+                a.tslots = 0;
+                a.blk_base = 0;
+                const int grid = std::min(cdiv(cnt, 4), num_cu * wave_per_cu_blocks);
+                if (F.small) hipLaunchKernelGGL(k_wlevel_wave<true>, dim3(grid), dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL(k_wlevel_wave<false>, dim3(grid), dim3(256), 0, stream, a);
+                a.recs = lev_recs.p;
+                if (known_mid != 0) {
+                    a.list = wmid_list.p;
+                    a.count = mid_count;
+                    a.big_list = nullptr; // (the wave kernel sorted the rows: what is on this list fits the medium table)
+                    launch_wg(0, known_mid < 0 ? num_cu * mid_per_cu : std::min(num_cu * mid_per_cu, known_mid));
+                }
+            } else {
+                a.recs = lev_recs.p;
+                if (cnt <= num_cu) {
+                    a.big_list = nullptr; // all rows with the largest table: what does not fit is not available
+                    launch_wg(1, cnt);
+                    continue;
+                }
+                launch_wg(0, std::min(num_cu * mid_per_cu, cnt)); // rows beyond the medium table go on the list of the largest
+            }
+            if (known_big != 0) {
+                a.list = wbig_list.p;
+                a.count = big_count;
+                a.big_list = nullptr;
+                launch_wg(1, known_big < 0 ? num_cu : std::min(num_cu, known_big));
             }
         }
         HIPCHK(hipGetLastError());
@@ -799,7 +874,7 @@ struct Round {
             if (wbase + cap + 1 > room) cap = room - wbase - 1;
         }
         cap &= ~(i64)15;
-        if (cap < 4 * std::max<i64>(utotal, 1 << 12)) return;
+        if (cap < 4 * std::max<i64>(utotal, 1 << 12) || cap < 2 * lev0_total) return;
         if ((i64)UPN.n < wbase + cap + 1) {
             DevBuf<int2> both;
             both.alloc((size_t)(wbase + cap) + 1);
@@ -810,25 +885,36 @@ struct Round {
         wcap = cap;
         wrow.ensure((size_t)npiv + 1);
         wcol.ensure((size_t)m + 1);
-        wbig_list.ensure((size_t)npiv + 1);
-        wbig_count.ensure(WMAXLEV + 4);
+        wmid_list.ensure((size_t)WL_NSUB * (size_t)npiv + 1);
+        wbig_list.ensure((size_t)WL_NSUB * (size_t)npiv + 1);
+        wbig_count.ensure((size_t)2 * (WMAXLEV + 2) * WL_NSUB * WL_SUBSTRIDE);
         wstate.ensure(WS_WORDS);
-        wblk.ensure((size_t)2 * num_cu * 16 * 4);
+        wblk.ensure((size_t)2 * wblk_slots());
         own_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
         pbits.ensure((size_t)cdiv(m, 256) * 8 + 2);
         hipLaunchKernelGGL(k_pbits, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, qinv_r.p, pbits.p);
         HIPCHK(hipGetLastError());
-        wbig_at.assign((size_t)depth + 2, 0);
+        wbig_at.assign((size_t)2 * (depth + 2), 0);
         build_w_levels(true);
         u64d ws[WS_WORDS];
         HIPCHK(hipMemcpyAsync(ws, wstate.p, sizeof ws, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(wbig_at.data(), wbig_count.p, ((size_t)depth + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+        std::vector<int> parts((size_t)2 * (depth + 1) * WL_NSUB * WL_SUBSTRIDE);
+        HIPCHK(hipMemcpyAsync(parts.data(), wbig_count.p, parts.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        for (int k = 0; k < 2 * (depth + 1); k++)
+            for (int sb = 0; sb < WL_NSUB; sb++) wbig_at[(size_t)k] += parts[((size_t)k * WL_NSUB + sb) * WL_SUBSTRIDE];
         if (ws[WS_ERROR]) throw EngineError("a hash table of the W build filled up (internal bound violated)");
+        if (getenv("SPASM_AMD_WDEBUG")) {
+            fprintf(stderr, "[wlevel] npiv %d depth %d entries %llu cursor %llu unavailable %llu long rows %llu; rows per level (medium, large):", npiv, depth,
+                    (unsigned long long)ws[WS_ENTRIES], (unsigned long long)ws[WS_CURSOR], (unsigned long long)ws[WS_UNAVAIL], (unsigned long long)ws[WS_BIGROWS]);
+            for (int L = 0; L <= depth; L++)
+                fprintf(stderr, " %d (%d, %d)", lev_start[(size_t)L + 1] - lev_start[(size_t)L], wbig_at[(size_t)2 * L], wbig_at[(size_t)2 * L + 1]);
+            fprintf(stderr, "\n");
+        }
         // rows that could not be built send the rows that need them to the multiplier lists: a few are fine, many mean W does not pay
         if (ws[WS_UNAVAIL] * 64 > (u64d)npiv) return;
         wtotal = (i64)std::min<u64d>(ws[WS_CURSOR], (u64d)cap);
-        w_entries = (i64)ws[WS_ENTRIES];
+        w_entries = (i64)ws[WS_ENTRIES] + lev0_entries;
         w_long_rows = (i64)ws[WS_BIGROWS];
         own_total = own_room;
         use_w = true;

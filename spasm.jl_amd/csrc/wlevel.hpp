@@ -21,10 +21,16 @@ constexpr int WMAXLEV = 254;                    // deeper pivot graphs keep to t
 constexpr int WL_TMAX = 1024;                   // table slots of a wave
 constexpr int WL_WAVE_BOUND = WL_TMAX / 2;      // longest bound a wave takes (tables at most half full)
 constexpr int WL_NCD = 64;                      // chunk descriptors of a wave
-constexpr u64d WL_BLK = 1024;                   // entries a wave takes from the cursor at a time
+constexpr u64d WL_BLK = 4096;                   // entries a wave / workgroup takes from the cursor at a time (one returning atomic on
+                                                // one word costs ~11 ns of that word's time: 170 000 rows must not queue there)
 constexpr int WL_WG_NCD = 512;                  // chunk descriptors of a workgroup batch (256 dependencies + the longest bound / 64)
+constexpr int WL_NSUB = 64;                     // the lists of rows left to the workgroup kernels are kept in 64 parts with a counter each
+constexpr int WL_SUBSTRIDE = 32;                // (ints between two counters: a line of their own; thousands of appends to ONE word
+                                                // serialise at ~11 ns each -- they were most of the wave kernel's time on the middle levels)
 // wstate words
-constexpr int WS_CURSOR = 0, WS_UNAVAIL = 1, WS_ERROR = 2, WS_ENTRIES = 3, WS_BIGROWS = 4, WS_WORDS = 8;
+// (the cursor on a line of its own; the statistics are only kept by the first build of a U: tens of thousands of waves adding to
+// one word at the end of a kernel serialise)
+constexpr int WS_CURSOR = 0, WS_UNAVAIL = 16, WS_ERROR = 17, WS_ENTRIES = 18, WS_BIGROWS = 19, WS_WORDS = 32;
 
 // one bit per column: is it a pivot column of this round?  (blockDim.x is a multiple of 64: whole waves, whole bitmap words)
 __global__ void k_pbits(int m, const int *__restrict__ qinv_r, unsigned *__restrict__ pbits)
@@ -82,29 +88,63 @@ __global__ void k_fill_int(int n, int v, int *__restrict__ out)
 }
 
 // what a build starts from: cursor and statistics zero, every wave without a block, no long rows at any level
-__global__ void k_wbuild_reset(u64d *__restrict__ wstate, u64d *__restrict__ wblk, int nblk_words, int *__restrict__ big_count, int nlev)
+__global__ void k_wbuild_reset(u64d *__restrict__ wstate, u64d *__restrict__ wblk, int nblk_words, int *__restrict__ big_count, int nlev, u64d cursor0)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < WS_WORDS) wstate[t] = 0;
+    if (t < WS_WORDS) wstate[t] = t == WS_CURSOR ? cursor0 : 0;
     if (t < nblk_words) wblk[t] = 0;
     if (t < nlev) big_count[t] = 0;
 }
 
+// a pivot row as the level kernels want it, in level order: one 32-byte record instead of order[] -> uhdr[] -> pivcol[]
+struct __attribute__((aligned(32))) WLevRec {
+    int q;        // pivot index
+    unsigned off; // of its entries in UPP / UPN
+    int npp, npn;
+    int pivcol;
+    int pad[3];
+};
+
+__global__ void k_lev_recs(int npiv, const int *__restrict__ order, const UHdr *__restrict__ uhdr, const int *__restrict__ pivcol, WLevRec *__restrict__ recs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npiv) return;
+    const int q = order[i];
+    const UHdr h = uhdr[q];
+    WLevRec r;
+    r.q = q;
+    r.off = h.off;
+    r.npp = h.npp;
+    r.npn = h.npn;
+    r.pivcol = pivcol[q];
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    recs[i] = r;
+}
+
 struct WLevelArgs {
-    int cnt;                   // rows of this level
-    const int *order;          // their pivot indices
-    const UHdr *uhdr;
+    int cnt;                   // rows of this level (wave kernel)
+    const WLevRec *recs;       // wave kernel: the level's rows; workgroup kernel: ALL rows in level order (its lists index them)
     const int2 *UPP;           // {pivot index, value} of the entries on other pivot columns
     int2 *buf;                 // [U_PN | own entries of the plan | W]: rows of W are read and written here
     int2 *wrow;                // per pivot index: {offset in buf, length} of its row of W (length -1: not available)
     int4 *wcol;                // per pivot COLUMN: {pivot index, length, offset, 0} -- what the plan kernel reads
-    const int *pivcol;
     u64d *wstate;              // WS_* words
     unsigned wbase;            // where W starts in buf
     u64d wcap;                 // entries of W's region
     u64d *wblk;                // per wave slot of the wave kernel: {next free entry, end} of its block (relative to wbase)
-    int *big_list;             // rows of this level left to the workgroup kernel
+    int rec_base;              // index of the level's first row among all rows
+    // lists of rows (indices into all rows) left to a workgroup kernel: WL_NSUB parts of list_stride ints, part s with its counter
+    // at count[s * WL_SUBSTRIDE]; a workgroup appends to part blockIdx.x % WL_NSUB
+    int list_stride;
+    int *mid_list;             // wave kernel: rows it leaves to the workgroup kernel with the medium table ..
+    int *mid_count;
+    int *big_list;             // .. and to the one with the largest table
     int *big_count;
+    const int *list;           // workgroup kernel: its rows
+    const int *count;
+    int tslots;                // workgroup kernel: slots of its table (a power of two)
+    int blk_base;              // workgroup kernel: its first slot in wblk
+    int stats;                 // keep the statistics words (first build)
     ZpField F;
 };
 
@@ -205,7 +245,69 @@ __device__ __forceinline__ bool wl_consume(lds_vint *cd_off, lds_vint *cd_len, l
 }
 
 // ------------------------------------------------------------------------------------------------
-// one level, a wave per row
+// level 0: rows without entries on other pivot columns, W[q] = -U_PN[q].  Their places in W are a prefix sum over their lengths
+// (rounded up to 16), computed once per U (k_lev0_sizes + scan): the copy needs no allocation and no table, a team of 16 lanes
+// per row.  The cursor of a build starts behind them.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lev0_sizes(int cnt, const WLevRec *__restrict__ recs, unsigned *__restrict__ sz, u64d *__restrict__ entries)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int npn = 0;
+    if (r < cnt) { npn = recs[r].npn; sz[r] = (unsigned)((npn + 15) & ~15); }
+    if (r == cnt) sz[r] = 0;
+    for (int o = 32; o > 0; o >>= 1) npn += __shfl_xor(npn, o);
+    if ((threadIdx.x & 63) == 0 && npn) atomicAdd(entries, (u64d)npn);
+}
+
+__global__ __launch_bounds__(256) void k_wlevel0(int cnt, const WLevRec *__restrict__ recs, const unsigned *__restrict__ off0, int2 *buf, int2 *__restrict__ wrow,
+                                                 int4 *__restrict__ wcol, unsigned wbase, ZpField F)
+{
+    const int tl = threadIdx.x & 15;
+    const int team = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), nteams = (int)((gridDim.x * blockDim.x) >> 4);
+    for (int r = team; r < cnt; r += nteams) {
+        const WLevRec rc = recs[r];
+        const unsigned mine = wbase + off0[r];
+        for (int k = tl; k < rc.npn; k += 16) {
+            const int2 e = buf[(size_t)rc.off + k];
+            buf[(size_t)mine + k] = make_int2(e.x, zp_neg(F, e.y));
+        }
+        if (tl == 0) {
+            wrow[rc.q] = make_int2((int)mine, rc.npn);
+            wcol[rc.pivcol] = make_int4(rc.q, rc.npn, (int)mine, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void wl_list_append(int *list, int *count, int stride, int row)
+{
+    const int sub = (int)(blockIdx.x % WL_NSUB);
+    list[(size_t)sub * stride + atomicAdd(count + sub * WL_SUBSTRIDE, 1)] = row;
+}
+
+// a record as two 16-byte loads from one address for all lanes; unpacked to scalars where it is used
+struct WlRecRegs { int4 a; int b; };
+__device__ __forceinline__ WlRecRegs wl_rec_load(const WLevRec *p)
+{
+    WlRecRegs r;
+    r.a = *(const int4 *)p;
+    r.b = ((const int *)p)[4];
+    return r;
+}
+
+constexpr int WL_MID_BOUND = 2048;   // rows up to this bound go to the workgroup kernel with 4096 slots (four workgroups per CU)
+template <bool SMALL> constexpr int wl_big_slots() { return SMALL ? 16384 : 8192; }
+constexpr int wl_mid_slots() { return 2 * WL_MID_BOUND; }
+template <bool SMALL> constexpr size_t wl_wg_lds_bytes(int slots)
+{
+    return (size_t)slots * (sizeof(typename ZpAcc<SMALL>::type) + 4) + (size_t)3 * WL_WG_NCD * 4 + 64;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one level, a wave per row.  Rows of a level are independent, so everything a row needs before its first dependent load is
+// fetched while the rows before it are worked on: its record three rows ahead, its entries on pivot columns two rows ahead,
+// the {offset, length} of the rows of W they name and its first 64 own entries one row ahead (unconditional loads, clamped:
+// past the end of the level the last row again).  What is left on the row's own critical path is one round trip for the runs
+// of W it combines.
 // ------------------------------------------------------------------------------------------------
 template <bool SMALL>
 __global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
@@ -228,16 +330,24 @@ __global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
     bend = __shfl(bend, 0);
     u64d c_ent = 0;
     int c_unavail = 0, c_err = 0, c_big = 0;
+    const int last = a.cnt - 1;
+    auto dep_load = [&](const WlRecRegs &r) { return a.UPP[(size_t)(unsigned)r.a.y + (unsigned)min(lane, max(min(r.a.z, 64) - 1, 0))]; };
+    auto wr_load = [&](const WlRecRegs &r, const int2 &d) { return a.wrow[lane < min(r.a.z, 64) ? d.x : 0]; };
+    auto own_load = [&](const WlRecRegs &r) { return a.buf[(size_t)(unsigned)r.a.y + (unsigned)min(lane, max(min(r.a.w, 64) - 1, 0))]; };
 
-    // pipeline: the pivot index two rows ahead, the header one row ahead (clamped: past the end, the last row again)
-    int q_c = a.order[min(wslot, a.cnt - 1)], q_n = a.order[min(wslot + stride, a.cnt - 1)];
-    UHdr h_c = a.uhdr[q_c];
+    WlRecRegs R0 = wl_rec_load(a.recs + min(wslot, last)), R1 = wl_rec_load(a.recs + min(wslot + stride, last)),
+              R2 = wl_rec_load(a.recs + min(wslot + 2 * stride, last));
+    int2 D0 = dep_load(R0), D1 = dep_load(R1);
+    int2 W0 = wr_load(R0, D0), O0 = own_load(R0);
     for (int i = wslot; i < a.cnt; i += stride) {
-        const int q_nn = a.order[min(i + 2 * stride, a.cnt - 1)];
-        const UHdr h_n = a.uhdr[q_n];
-        const int q = __builtin_amdgcn_readfirstlane(q_c);
-        const unsigned uo = (unsigned)__builtin_amdgcn_readfirstlane((int)h_c.off);
-        const int npp = __builtin_amdgcn_readfirstlane(h_c.npp), npn = __builtin_amdgcn_readfirstlane(h_c.npn);
+        const WlRecRegs R3 = wl_rec_load(a.recs + min(i + 3 * stride, last));
+        const int2 D2 = dep_load(R2);
+        const int2 W1 = wr_load(R1, D1);
+        const int2 O1 = own_load(R1);
+        const int q = __builtin_amdgcn_readfirstlane(R0.a.x);
+        const unsigned uo = (unsigned)__builtin_amdgcn_readfirstlane(R0.a.y);
+        const int npp = __builtin_amdgcn_readfirstlane(R0.a.z), npn = __builtin_amdgcn_readfirstlane(R0.a.w);
+        const int pc = __builtin_amdgcn_readfirstlane(R0.b);
         unsigned out_off = 0;
         int n_out = 0;
         bool avail = true, deferred = false;
@@ -247,43 +357,45 @@ __global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
             if (r == ~0ull) avail = false;
             else {
                 out_off = a.wbase + (unsigned)r;
-                for (int k = lane; k < npn; k += 64) {
+                if (lane < npn) a.buf[(size_t)out_off + lane] = make_int2(O0.x, zp_neg(F, O0.y));
+                for (int k = 64 + lane; k < npn; k += 64) {
                     const int2 e = a.buf[(size_t)uo + k];
                     a.buf[(size_t)out_off + k] = make_int2(e.x, zp_neg(F, e.y));
                 }
                 n_out = npn;
             }
         } else {
-            bool big = npp > 64;
-            int2 dep = make_int2(0, 0), wr = make_int2(0, 0);
-            if (!big && lane < npp) {
-                dep = a.UPP[(size_t)uo + lane];
-                wr = a.wrow[dep.x];
-            }
-            if (__ballot(wr.y < 0) != 0) avail = false; // a row this one needs could not be built
+            const bool mine = lane < min(npp, 64);
+            const int wl = mine ? W0.y : 0;
+            if (__ballot(wl < 0) != 0) avail = false; // a row this one needs could not be built (the rows that need THIS one learn it the same way)
             else {
-                const int wl = wr.y, nch = (wl + 63) >> 6;
+                const int nch = (wl + 63) >> 6;
                 int tot_len, tot_ch;
                 (void)team_incl_scan<64>(wl, tot_len);
                 const int incl_ch = team_incl_scan<64>(nch, tot_ch);
-                const int bound = npn + tot_len, own_ch = (npn + 63) >> 6, C = own_ch + tot_ch;
-                big = big || bound > WL_WAVE_BOUND || C > WL_NCD;
-                if (big) {
-                    if (lane == 0) a.big_list[atomicAdd(a.big_count, 1)] = q;
+                const int bound = npn + tot_len, own_rest = max(((npn + 63) >> 6) - 1, 0), C = own_rest + tot_ch;
+                if (npp > 64 || bound > WL_WAVE_BOUND || C > WL_NCD) {
+                    // (with more than 64 dependencies the bound above is a lower bound: the large table then; its kernel checks)
+                    const bool tomid = npp <= 64 && bound <= WL_MID_BOUND;
+                    if (lane == 0) {
+                        if (tomid) wl_list_append(a.mid_list, a.mid_count, a.list_stride, a.rec_base + i);
+                        else wl_list_append(a.big_list, a.big_count, a.list_stride, a.rec_base + i);
+                    }
                     deferred = true;
                     c_big++;
                 } else {
-                    // chunk descriptors: the row's own entries first (multiplier -1), then the runs of the dependencies
-                    const int nm = zp_neg(F, dep.y);
-                    const int cbase = own_ch + incl_ch - nch;
+                    // chunk descriptors: what is left of the row's own entries (multiplier -1; the first 64 are in registers), then the
+                    // runs of the dependencies
+                    const int nm = zp_neg(F, D0.y);
+                    const int cbase = own_rest + incl_ch - nch;
                     for (int r = 0; r < nch; r++) {
-                        cd_off[cbase + r] = (int)((unsigned)wr.x + 64u * (unsigned)r);
+                        cd_off[cbase + r] = (int)((unsigned)W0.x + 64u * (unsigned)r);
                         cd_len[cbase + r] = min(64, wl - 64 * r);
                         cd_mul[cbase + r] = nm;
                     }
-                    for (int r = lane; r < own_ch; r += 64) {
-                        cd_off[r] = (int)(uo + 64u * (unsigned)r);
-                        cd_len[r] = min(64, npn - 64 * r);
+                    for (int r = lane; r < own_rest; r += 64) {
+                        cd_off[r] = (int)(uo + 64u * (unsigned)(r + 1));
+                        cd_len[r] = min(64, npn - 64 * (r + 1));
                         cd_mul[r] = -1;
                     }
                     int logt = 7;
@@ -292,7 +404,13 @@ __global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
                     const unsigned mask = (unsigned)T - 1u;
                     for (int s = lane; s < T; s += 64) { key[s] = EMPTY_KEY; val[s] = 0; }
                     __builtin_amdgcn_wave_barrier();
-                    const bool ok = wl_consume<SMALL>(cd_off, cd_len, cd_mul, C, 0, 4, a.buf, key, val, mask, 32 - logt, F);
+                    bool ok = true;
+                    {
+                        const int cc[1] = {O0.x};
+                        const Acc vv[1] = {(Acc)(-O0.y)};
+                        ok &= wl_insert_n<SMALL, 1>(key, val, mask, 32 - logt, cc, vv, lane < npn ? 1u : 0u);
+                    }
+                    ok &= wl_consume<SMALL>(cd_off, cd_len, cd_mul, C, 0, 4, a.buf, key, val, mask, 32 - logt, F);
                     if (__ballot(!ok) != 0) c_err++;
                     __builtin_amdgcn_wave_barrier();
                     // sweep: count, take the space, write
@@ -324,57 +442,90 @@ __global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
             if (lane == 0) {
                 const int len = avail ? n_out : -1;
                 a.wrow[q] = make_int2((int)out_off, len);
-                a.wcol[a.pivcol[q]] = make_int4(q, len, (int)out_off, 0);
+                a.wcol[pc] = make_int4(q, len, (int)out_off, 0);
             }
             if (avail) c_ent += (u64d)n_out; else c_unavail++;
         }
-        q_c = q_n;
-        q_n = q_nn;
-        h_c = h_n;
+        R0 = R1; R1 = R2; R2 = R3;
+        D0 = D1; D1 = D2;
+        W0 = W1;
+        O0 = O1;
     }
     if (lane == 0) {
         a.wblk[2 * wslot] = bpos;
         a.wblk[2 * wslot + 1] = bend;
-        if (c_ent) atomicAdd(a.wstate + WS_ENTRIES, c_ent);
-        if (c_unavail) atomicAdd(a.wstate + WS_UNAVAIL, (u64d)c_unavail);
+        if (a.stats) {
+            if (c_ent) atomicAdd(a.wstate + WS_ENTRIES, c_ent);
+            if (c_unavail) atomicAdd(a.wstate + WS_UNAVAIL, (u64d)c_unavail);
+            if (c_big) atomicAdd(a.wstate + WS_BIGROWS, (u64d)c_big);
+        }
         if (c_err) atomicAdd(a.wstate + WS_ERROR, (u64d)c_err);
-        if (c_big) atomicAdd(a.wstate + WS_BIGROWS, (u64d)c_big);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// the long rows of a level, a workgroup per row: table of up to 16384 (8192 for large primes) slots in dynamic LDS
+// the long rows of a level, a workgroup per row: a table of a.tslots slots in dynamic LDS (4096: four workgroups per CU; or all
+// a CU has).  The next row's record and its first 256 dependencies are fetched while this one is worked on.
 // ------------------------------------------------------------------------------------------------
-template <bool SMALL> constexpr int wl_wg_slots() { return SMALL ? 16384 : 8192; }
-template <bool SMALL> constexpr size_t wl_wg_lds_bytes()
-{
-    return (size_t)wl_wg_slots<SMALL>() * (sizeof(typename ZpAcc<SMALL>::type) + 4) + (size_t)3 * WL_WG_NCD * 4 + 64;
-}
-
 template <bool SMALL>
 __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
 {
     typedef typename ZpAcc<SMALL>::type Acc;
-    constexpr int TB = wl_wg_slots<SMALL>();
+    const int TB = a.tslots;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     Acc *val = (Acc *)s_raw;
     int *key = (int *)(s_raw + sizeof(Acc) * (size_t)TB);
     lds_vint *cd_off = (lds_vint *)(key + TB), *cd_len = cd_off + WL_WG_NCD, *cd_mul = cd_len + WL_WG_NCD;
     lds_vint *s_misc = cd_mul + WL_WG_NCD; // 16 words
-    const int nbig = *a.big_count;
-    if ((int)blockIdx.x >= nbig) return;
+    // its rows: a list the wave kernel (or this kernel with the medium table) left, or -- levels of few rows, which skip the wave
+    // kernel -- all cnt rows of the level
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ int s_pre[WL_NSUB + 1]; // list mode: rows in the parts before part s
+    int nrows = a.cnt;
+    if (a.list) {
+        if (tid < WL_NSUB) {
+            const int c = a.count[tid * WL_SUBSTRIDE];
+            int tot;
+            const int incl = team_incl_scan<64>(c, tot);
+            s_pre[tid + 1] = incl;
+            if (tid == 0) s_pre[0] = 0;
+        }
+        __syncthreads();
+        nrows = s_pre[WL_NSUB];
+    }
+    if ((int)blockIdx.x >= nrows) return;
     const ZpField F = a.F;
-    for (int i = blockIdx.x; i < nbig; i += gridDim.x) {
-        const int q = a.big_list[i];
-        const UHdr h = a.uhdr[q];
-        const unsigned uo = h.off;
-        const int npp = h.npp, npn = h.npn;
+    const int last = nrows - 1, stride = (int)gridDim.x;
+    // row i of this kernel: in list mode the (i - pre[s])-th row of the part s that holds position i
+    auto row_of = [&](int i) {
+        i = min(i, last);
+        if (!a.list) return a.rec_base + i;
+        int s0 = 0;
+#pragma unroll
+        for (int step = WL_NSUB / 2; step > 0; step >>= 1)
+            if (s_pre[s0 + step] <= i) s0 += step;
+        return a.list[(size_t)s0 * a.list_stride + (i - s_pre[s0])];
+    };
+    auto rec_of = [&](int i) { return wl_rec_load(a.recs + row_of(i)); };
+    auto dep_load = [&](const WlRecRegs &r) { return a.UPP[(size_t)(unsigned)r.a.y + (unsigned)min(tid, max(min(r.a.z, 256) - 1, 0))]; };
+    auto wr_load = [&](const WlRecRegs &r, const int2 &d) { return a.wrow[tid < min(r.a.z, 256) ? d.x : 0]; };
+    u64d bpos = a.wblk[2 * (a.blk_base + (int)blockIdx.x)], bend = a.wblk[2 * (a.blk_base + (int)blockIdx.x) + 1]; // (used by thread 0)
+    WlRecRegs R0 = rec_of(blockIdx.x), R1 = rec_of(blockIdx.x + stride);
+    int2 D0 = dep_load(R0);
+    int2 W0 = wr_load(R0, D0);
+    for (int i = blockIdx.x; i < nrows; i += stride) {
+        const WlRecRegs R2 = rec_of(i + 2 * stride);
+        const int2 D1 = dep_load(R1);
+        const int q = __builtin_amdgcn_readfirstlane(R0.a.x);
+        const unsigned uo = (unsigned)__builtin_amdgcn_readfirstlane(R0.a.y);
+        const int npp = __builtin_amdgcn_readfirstlane(R0.a.z), npn = __builtin_amdgcn_readfirstlane(R0.a.w);
+        const int pc = __builtin_amdgcn_readfirstlane(R0.b);
         // ---- bound of the row, and whether every row it needs is there
         long long mylen = 0;
         bool un = false;
-        for (int k = tid; k < npp; k += 256) {
+        if (tid < min(npp, 256)) { un = W0.y < 0; mylen = max(W0.y, 0); }
+        for (int k = 256 + tid; k < npp; k += 256) {
             const int2 d = a.UPP[(size_t)uo + k];
             const int2 wr = a.wrow[d.x];
             un |= wr.y < 0;
@@ -382,7 +533,7 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
         }
         for (int o = 32; o > 0; o >>= 1) mylen += __shfl_xor(mylen, o);
         const bool wun = __ballot(un) != 0;
-        if (lane == 0) { s_misc[wave] = (int)min(mylen, (long long)INT_MAX / 8); s_misc[4 + wave] = wun ? 1 : 0; }
+        if (lane == 0) { s_misc[wave] = (int)min(mylen, (long long)(INT_MAX / 8)); s_misc[4 + wave] = wun ? 1 : 0; }
         __syncthreads();
         long long bound = npn;
         bool unavail = false;
@@ -390,6 +541,15 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
         bool avail = !unavail && bound <= TB / 2;
         unsigned out_off = 0;
         int n_out = 0;
+        if (!avail && !unavail && !a.list && a.big_list) {
+            // range mode with the medium table: the row goes to the kernel with the largest one (which publishes it)
+            if (tid == 0) wl_list_append(a.big_list, a.big_count, a.list_stride, a.rec_base + i);
+            __syncthreads();
+            R0 = R1; R1 = R2;
+            W0 = wr_load(R0, D1);
+            D0 = D1;
+            continue;
+        }
         if (avail) { // (uniform over the workgroup)
             int logt = 10;
             while ((1ll << logt) < 2 * bound) logt++;
@@ -403,13 +563,14 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
             for (int k = tid; k < npn; k += 256) {
                 const int2 e = a.buf[(size_t)uo + k];
                 const int cc[1] = {e.x};
-                const Acc vv[1] = {ZpAcc<SMALL>::mul_lazy(F, -1, e.y)};
+                const Acc vv[1] = {(Acc)(-e.y)};
                 ok &= wl_insert_n<SMALL, 1>(key, val, mask, shift, cc, vv, 1u);
             }
             // its dependencies, 256 at a time: their runs become chunks, the waves take groups of 4 chunks in turn
             for (int b0 = 0; b0 < npp; b0 += 256) {
                 int2 d = make_int2(0, 0), wr = make_int2(0, 0);
-                if (b0 + tid < npp) {
+                if (b0 == 0) { if (tid < npp) { d = D0; wr = W0; } }
+                else if (b0 + tid < npp) {
                     d = a.UPP[(size_t)uo + b0 + tid];
                     wr = a.wrow[d.x];
                 }
@@ -453,9 +614,21 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
                 n_out += cw;
             }
             if (tid == 0) {
+                // (as wl_take, by one thread: from the workgroup's block, or from the cursor when that is used up / the row is long)
                 const u64d n = ((u64d)n_out + 15ull) & ~15ull;
-                const u64d b = n ? atomicAdd(a.wstate + WS_CURSOR, n) : 0;
-                const bool fits = b + n <= a.wcap;
+                u64d b = 0;
+                bool fits = true;
+                if (n > WL_BLK / 2) {
+                    b = atomicAdd(a.wstate + WS_CURSOR, n);
+                    fits = b + n <= a.wcap;
+                } else if (n > 0) {
+                    if (bpos + n > bend) {
+                        const u64d nb = atomicAdd(a.wstate + WS_CURSOR, WL_BLK);
+                        fits = nb + WL_BLK <= a.wcap;
+                        if (fits) { bpos = nb; bend = nb + WL_BLK; }
+                    }
+                    if (fits) { b = bpos; bpos += n; }
+                }
                 s_misc[12] = fits ? 1 : 0;
                 s_misc[13] = (int)(unsigned)b;
             }
@@ -476,10 +649,19 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
         if (tid == 0) {
             const int len = avail ? n_out : -1;
             a.wrow[q] = make_int2((int)out_off, len);
-            a.wcol[a.pivcol[q]] = make_int4(q, len, (int)out_off, 0);
-            if (avail) atomicAdd(a.wstate + WS_ENTRIES, (u64d)n_out);
-            else atomicAdd(a.wstate + WS_UNAVAIL, 1ull);
+            a.wcol[pc] = make_int4(q, len, (int)out_off, 0);
+            if (a.stats) {
+                if (avail) atomicAdd(a.wstate + WS_ENTRIES, (u64d)n_out);
+                else atomicAdd(a.wstate + WS_UNAVAIL, 1ull);
+            }
         }
         __syncthreads();
+        R0 = R1; R1 = R2;
+        W0 = wr_load(R0, D1);
+        D0 = D1;
+    }
+    if (tid == 0) {
+        a.wblk[2 * (a.blk_base + (int)blockIdx.x)] = bpos;
+        a.wblk[2 * (a.blk_base + (int)blockIdx.x) + 1] = bend;
     }
 }

@@ -20,8 +20,8 @@ G = sys.argv[1]
 f = glob.glob('gpurun_out/shard_trace/trace/**/*kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# last step: from the last k_solve_reset on
-idx = max(i for i, r in enumerate(rows) if 'k_solve_reset' in r['Kernel_Name'])
+# last step: from the last k_wbuild_reset on (the W build opens the step; plans that keep to the lists start at k_solve_reset)
+idx = max([i for i, r in enumerate(rows) if 'k_wbuild_reset' in r['Kernel_Name']] or [i for i, r in enumerate(rows) if 'k_solve_reset' in r['Kernel_Name']])
 step = rows[idx:]
 t0 = int(step[0]['Start_Timestamp'])
 out = []
