@@ -51,7 +51,7 @@ struct spasm_csr {
     spasm_field field;
 };
 
-/* struct _Triplet, src/SpaSM.jl:234-243 (72 bytes) */
+/* struct _Triplet, src/SpaSM.jl:234-243 (80 bytes) */
 struct spasm_triplet {
     i64 nzmax;
     i64 nz;
@@ -90,6 +90,37 @@ struct echelonize_opts {
     double tall_and_skinny_ratio;
     double low_rank_start_weight;
 };
+
+/* The layouts SpaSM.jl's mirrors imply (x86-64, little-endian), checked where the header is compiled: a field that
+ * moves is a build error here, not a wrong pointer in Julia. */
+#if defined(__cplusplus)
+#define SPASM_LAYOUT_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define SPASM_LAYOUT_ASSERT(cond, msg) _Static_assert(cond, msg)
+#endif
+SPASM_LAYOUT_ASSERT(sizeof(struct spasm_field_struct) == 32 && offsetof(struct spasm_field_struct, p) == 0 && offsetof(struct spasm_field_struct, halfp) == 8 &&
+                        offsetof(struct spasm_field_struct, mhalfp) == 16 && offsetof(struct spasm_field_struct, dinvp) == 24,
+                    "spasm_field: src/SpaSM.jl:51-56");
+SPASM_LAYOUT_ASSERT(sizeof(struct spasm_csr) == 72 && offsetof(struct spasm_csr, nzmax) == 0 && offsetof(struct spasm_csr, n) == 8 && offsetof(struct spasm_csr, m) == 12 &&
+                        offsetof(struct spasm_csr, p) == 16 && offsetof(struct spasm_csr, j) == 24 && offsetof(struct spasm_csr, x) == 32 &&
+                        offsetof(struct spasm_csr, field) == 40,
+                    "spasm_csr: src/SpaSM.jl:126-134");
+SPASM_LAYOUT_ASSERT(sizeof(struct spasm_triplet) == 80 && offsetof(struct spasm_triplet, nz) == 8 && offsetof(struct spasm_triplet, n) == 16 &&
+                        offsetof(struct spasm_triplet, m) == 20 && offsetof(struct spasm_triplet, i) == 24 && offsetof(struct spasm_triplet, j) == 32 &&
+                        offsetof(struct spasm_triplet, x) == 40 && offsetof(struct spasm_triplet, field) == 48,
+                    "spasm_triplet: src/SpaSM.jl:234-243");
+SPASM_LAYOUT_ASSERT(sizeof(struct spasm_lu) == 48 && offsetof(struct spasm_lu, r) == 0 && offsetof(struct spasm_lu, complete) == 4 && offsetof(struct spasm_lu, L) == 8 &&
+                        offsetof(struct spasm_lu, U) == 16 && offsetof(struct spasm_lu, qinv) == 24 && offsetof(struct spasm_lu, p) == 32 &&
+                        offsetof(struct spasm_lu, Ltmp) == 40,
+                    "spasm_lu: src/SpaSM.jl:262-270");
+SPASM_LAYOUT_ASSERT(sizeof(struct echelonize_opts) == 64 && offsetof(struct echelonize_opts, enable_greedy_pivot_search) == 0 &&
+                        offsetof(struct echelonize_opts, enable_tall_and_skinny) == 1 && offsetof(struct echelonize_opts, enable_dense) == 2 &&
+                        offsetof(struct echelonize_opts, enable_GPLU) == 3 && offsetof(struct echelonize_opts, L) == 4 && offsetof(struct echelonize_opts, complete) == 5 &&
+                        offsetof(struct echelonize_opts, min_pivot_proportion) == 8 && offsetof(struct echelonize_opts, max_round) == 16 &&
+                        offsetof(struct echelonize_opts, sparsity_threshold) == 24 && offsetof(struct echelonize_opts, dense_block_size) == 32 &&
+                        offsetof(struct echelonize_opts, low_rank_ratio) == 40 && offsetof(struct echelonize_opts, tall_and_skinny_ratio) == 48 &&
+                        offsetof(struct echelonize_opts, low_rank_start_weight) == 56,
+                    "echelonize_opts: src/SpaSM.jl:325-343");
 
 /* ---- data symbol: SpaSM.log() stores a C callback here, src/SpaSM.jl:34-46 ---- */
 extern int (*logcallback)(char *);
@@ -139,6 +170,15 @@ bool spasm_solve(const struct spasm_lu *fact, const spasm_ZZp *b, spasm_ZZp *x);
 
 /* ---- spasm_ZZp.c surface (commented-out binding at src/SpaSM.jl:65; arithmetic restated :73-88,:383-390) ---- */
 void spasm_field_init(i64 p, spasm_field F);
+
+/* ---- spasm_scatter.c / spasm_triangular.c as SpaSM.jl binds them ---- */
+void spasm_scatter(const struct spasm_csr *A, int i, spasm_ZZp beta, spasm_ZZp *x);   /* src/SpaSM.jl:620: x += beta * A[i] (host) */
+/* src/SpaSM.jl:721, semantics :694-713: solve x * U = B[k]; x (m entries, need not be initialised) receives the solution
+ * scattered over the columns, xj[top .. m) its pattern (xj has 3 m entries, zero on entry; only xj[top .. m) is written);
+ * with x_b on the pivot columns (qinv[j] >= 0) and x_a on the others, x_b * U + x_a == B[k].  Pivots of U must be 1; they need
+ * not be the first entries of their rows.  Returns top (-1 on failure).  One row through the batched device solve
+ * (spasm_amd_triangular_solve does all rows of B in one pass). */
+int spasm_sparse_triangular_solve(const struct spasm_csr *U, const struct spasm_csr *B, int k, int *xj, spasm_ZZp *x, const int *qinv);
 
 /* ---- spasm_transpose.c ---- */
 struct spasm_csr *spasm_transpose(const struct spasm_csr *A);        /* src/SpaSM.jl:589 (one-argument form) */

@@ -25,14 +25,16 @@ from .api import (
     rank,
     rref,
     save,
+    scatter,
     solve,
     sparse,
     sparse_triangular_solve,
+    sparse_triangular_solve_row,
     synth_csr,
     transpose,
 )
 
 __all__ = [
     "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "factorization_verify", "gesv", "solve", "kernel",
-    "last_rounds", "nnz", "prime0", "rank", "rref", "sparse", "sparse_triangular_solve", "synth_csr", "transpose",
+    "last_rounds", "nnz", "prime0", "rank", "rref", "sparse", "sparse_triangular_solve", "sparse_triangular_solve_row", "scatter", "synth_csr", "transpose",
 ]

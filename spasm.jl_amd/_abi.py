@@ -185,6 +185,8 @@ SIGNATURES = {
     "spasm_amd_shard_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "spasm_amd_shard_import": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "spasm_amd_triangular_solve": (_P(CsrStruct), [_P(CsrStruct), _P(C.c_int32), _P(CsrStruct), _P(C.c_ubyte)]),
+    "spasm_sparse_triangular_solve": (C.c_int32, [_P(CsrStruct), _P(CsrStruct), C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "spasm_scatter": (None, [_P(CsrStruct), C.c_int32, C.c_int32, _P(C.c_int32)]),
     "spasm_amd_kernel_strided": (_P(CsrStruct), [_P(LuStruct), C.c_int32, C.c_int32]),
     "spasm_amd_schur_plan_advance": (C.c_void_p, [C.c_void_p, _P(C.c_int32), _P(C.c_int64)]),
     "spasm_amd_shard_fetch": (_P(CsrStruct), [C.c_void_p]),

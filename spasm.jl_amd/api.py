@@ -366,6 +366,31 @@ def kernel(A, verbose=False, **kwargs):
     return CSR(ptr)
 
 
+def scatter(A, i, beta, x):
+    """scatter(A, i, beta, x): x += beta * A[i] (reference src/SpaSM.jl:619-620; i 0-based here, as on the C side).  x: int32
+    array of m balanced residues, updated in place."""
+    assert x.dtype == np.int32 and x.flags["C_CONTIGUOUS"] and len(x) >= A.m and 0 <= i < A.n
+    _abi.lib().spasm_scatter(A.data, int(i), int(beta), x.ctypes.data_as(C.POINTER(C.c_int32)))
+    return x
+
+
+def sparse_triangular_solve_row(U, B, k, xj, x, qinv, verbose=False):
+    """sparse_triangular_solve(U, B, k, xj, x, qinv) (reference src/SpaSM.jl:694-722; k 0-based): solve x * U = B[k].  xj: int32,
+    3 m entries, zero on entry; x: int32, m entries.  Returns top: the pattern of the solution is xj[top:m], its values x[xj[...]];
+    with x_b on the pivot columns and x_a on the others, x_b * U + x_a == B[k]."""
+    m = U.m
+    assert m == B.m == len(qinv) and 0 <= k < B.n                     # the reference's assertions (:715-720)
+    assert xj.dtype == np.int32 and len(xj) >= 3 * m and not xj.any()
+    assert x.dtype == np.int32 and len(x) >= m
+    q = np.ascontiguousarray(qinv, dtype=np.int32)
+    with _quiet(not verbose):
+        top = _abi.lib().spasm_sparse_triangular_solve(U.data, B.data, int(k), xj.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                        x.ctypes.data_as(C.POINTER(C.c_int32)), q.ctypes.data_as(C.POINTER(C.c_int32)))
+    if top < 0:
+        raise SpasmError("spasm_sparse_triangular_solve failed: " + _abi.last_error())
+    return int(top)
+
+
 def sparse_triangular_solve(U, B, qinv=None, verbose=False):
     """sparse_triangular_solve(LU, B) / sparse_triangular_solve(U, B, qinv) (reference src/SpaSM.jl:725-755): solve X * U == B in
     sparse matrices; returns X (rows of B x rows of U), or None if some row of B has no solution.  One device pass over all

@@ -3,6 +3,8 @@
 // Mirrors the libspasm entry points SpaSM.jl binds (reference src/SpaSM.jl, line cited per function).
 // No arithmetic of the hot path lives here: echelonize / kernel / transpose are in engine.hip.
 #include "common.hpp"
+#include <hip/hip_runtime.h>
+#include "zp.hpp"
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -343,6 +345,19 @@ SPASM_API void spasm_csr_save(const struct spasm_csr *A, void *file)
     for (int i = 0; i < A->n; i++)
         for (i64 k = A->p[i]; k < A->p[i + 1]; k++) fprintf(f, "%d %d %d\n", i + 1, A->j[k] + 1, A->x ? A->x[k] : 1);
     fprintf(f, "0 0 0\n");
+}
+
+// reference src/SpaSM.jl:619-620 (spasm_scatter.c): x += beta * A[i] on a dense vector of balanced residues.  Host-side, one row:
+// the innermost loop of libspasm's Schur complement, kept as a callable for SpaSM.jl's `scatter` (the engine's own scatter is the
+// device kernels of csrc/stream.hpp / kernels.hpp).
+SPASM_API void spasm_scatter(const struct spasm_csr *A, int i, spasm_ZZp beta, spasm_ZZp *x)
+{
+    if (!A || !x || i < 0 || i >= A->n) return;
+    const ZpField F = zp_field_make(A->field->p);
+    for (i64 k = A->p[i]; k < A->p[i + 1]; k++) {
+        const int j = A->j[k];
+        x[j] = zp_axpy(F, beta, A->x[k], x[j]);
+    }
 }
 
 SPASM_API int spasm_get_num_threads(void) { return 1; } // reference src/SpaSM.jl:470 (the engine's parallelism is on the device)

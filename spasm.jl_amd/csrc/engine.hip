@@ -2826,7 +2826,8 @@ struct spasm_csr *do_rref(const struct spasm_lu *fact, int *Rqinv)
 // "round" with U as the pivot rows and B as the rows to reduce: the multipliers ARE x_b, the Schur row IS x_a.
 // Returns X (rows of B x rows of U); ok[k] = 1 when x_a is empty, i.e. row k has a solution.  Same pivot numbering as rref.
 // ------------------------------------------------------------------------------------------------
-struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok)
+// resid (may be NULL): receives x_a, the part of B[k] - x_b * U on the columns without a pivot, one row per row of B
+struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok, struct spasm_csr **resid)
 {
     require_device();
     if (!U || !qinv || !B) throw EngineError("spasm_amd_triangular_solve: null argument");
@@ -2898,11 +2899,49 @@ struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const 
             HIPCHK(hipStreamSynchronize(s));
         }
         for (int k = 0; k <= nb; k++) X->p[k] = xp[(size_t)k];
+        if (resid) {
+            // x_a: the Schur rows of the rows of B, compacted (device) and copied out
+            DevBuf<i64d> l64, rstart2;
+            l64.alloc((size_t)nb + 1);
+            rstart2.alloc((size_t)nb + 1);
+            hipLaunchKernelGGL(k_copy_len64, dim3(cdiv((i64)nb + 1, 256)), dim3(256), 0, s, nb, R->S.len.p, l64.p);
+            HIPCHK(hipGetLastError());
+            R->scan.exclusive(l64.p, rstart2.p, (size_t)nb + 1, s);
+            std::vector<i64d> hp2((size_t)nb + 1);
+            HIPCHK(hipMemcpyAsync(hp2.data(), rstart2.p, ((size_t)nb + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const i64 rz = hp2[(size_t)nb];
+            struct spasm_csr *Rs = spasm_csr_alloc(nb, m, rz, prime, true);
+            if (!Rs) { spasm_csr_free(X); throw EngineError("out of host memory for the residual rows"); }
+            for (int k = 0; k <= nb; k++) Rs->p[k] = hp2[(size_t)k];
+            if (rz > 0) {
+                DevBuf<int> oj2, ox2;
+                oj2.alloc((size_t)rz);
+                ox2.alloc((size_t)rz);
+                constexpr int TEAM = 16;
+                hipLaunchKernelGGL((k_compact_rows<TEAM>), dim3(cdiv((i64)nb * TEAM, 256)), dim3(256), 0, s, nb, R->S.start.p, R->S.len.p, R->S.ent.p, rstart2.p, oj2.p, ox2.p);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(Rs->j, oj2.p, (size_t)rz * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(Rs->x, ox2.p, (size_t)rz * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
+            *resid = Rs;
+        }
     } else {
         X = spasm_csr_alloc(nb, r, 0, prime, true);
         if (!X) throw EngineError("out of host memory for X");
         for (int k = 0; k <= nb; k++) X->p[k] = 0;
         for (int k = 0; k < nb; k++) slen[(size_t)k] = (int)(B->p[k + 1] - B->p[k]); // without pivots a row is solvable iff it is zero
+        if (resid) {
+            // no pivots (or no rows): x_a is the row itself
+            const i64 bz = B->p[nb];
+            struct spasm_csr *Rs = spasm_csr_alloc(nb, m, bz, prime, true);
+            if (!Rs) { spasm_csr_free(X); throw EngineError("out of host memory for the residual rows"); }
+            const ZpField F = zp_field_make(prime);
+            for (int k = 0; k <= nb; k++) Rs->p[k] = B->p[k];
+            for (i64 t = 0; t < bz; t++) { Rs->j[t] = B->j[t]; Rs->x[t] = zp_reduce(F, B->x[t]); }
+            *resid = Rs;
+        }
     }
     if (ok) for (int k = 0; k < nb; k++) ok[k] = slen[(size_t)k] == 0;
     return X;
@@ -2915,7 +2954,7 @@ struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const 
 // pivots d_k = L[p[k]][k] on the diagonal (a row only holds multipliers of pivots elected before it).  Scaled to a unit diagonal
 // this is a second triangular solve of the same kind; X is zero outside the pivotal rows.  ok[b] = 1 when row b has a solution.
 // ------------------------------------------------------------------------------------------------
-struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok);
+struct spasm_csr *do_trisolve(const struct spasm_csr *U, const int *qinv, const struct spasm_csr *B, unsigned char *ok, struct spasm_csr **resid = nullptr);
 
 struct spasm_csr *do_gesv(const struct spasm_lu *fact, const struct spasm_csr *B, unsigned char *ok)
 {
@@ -3539,6 +3578,50 @@ SPASM_API struct spasm_csr *spasm_amd_kernel_strided(const struct spasm_lu *fact
     } catch (const std::exception &e) {
         spasm_set_error("spasm_amd_kernel_strided: %s", e.what());
         return nullptr;
+    }
+}
+
+// reference src/SpaSM.jl:694-722: x * U = B[k] for ONE row.  The row goes through the batched device solve (do_trisolve: the Schur
+// machinery with U as the pivot rows), then the solution is laid out as libspasm does: x scattered over the m columns (x_b on the
+// pivot columns, x_a on the others; only the entries of the pattern are written), the pattern in xj[top .. m), top returned.
+// Pattern order: the pivot columns reached, then the columns of x_a, each ascending.  xj[0 .. top) and xj[m .. 3m) (libspasm's
+// DFS stacks and marks, "it remains OK", :700) are left as they are.  -1 on failure.
+SPASM_API int spasm_sparse_triangular_solve(const struct spasm_csr *U, const struct spasm_csr *B, int k, int *xj, spasm_ZZp *x, const int *qinv)
+{
+    spasm_clear_error();
+    struct spasm_csr *X = nullptr, *Rs = nullptr;
+    struct spasm_csr one;
+    try {
+        if (!U || !B || !xj || !x || !qinv) throw EngineError("spasm_sparse_triangular_solve: null argument");
+        if (k < 0 || k >= B->n) throw EngineError("spasm_sparse_triangular_solve: row out of range");
+        const int m = U->m;
+        // row k of B as a matrix of its own (borrowed arrays)
+        i64 rp[2] = {0, B->p[k + 1] - B->p[k]};
+        one = *B;
+        one.n = 1;
+        one.nzmax = rp[1];
+        one.p = rp;
+        one.j = B->j + B->p[k];
+        one.x = B->x + B->p[k];
+        X = do_trisolve(U, qinv, &one, nullptr, &Rs);
+        std::vector<int> colof((size_t)std::max(U->n, 1), -1);
+        for (int j = 0; j < m; j++) if (qinv[j] >= 0 && qinv[j] < U->n) colof[(size_t)qinv[j]] = j;
+        std::vector<int> pat;
+        for (i64 t = X->p[0]; t < X->p[1]; t++) { const int j = colof[(size_t)X->j[t]]; x[j] = X->x[t]; pat.push_back(j); }
+        std::sort(pat.begin(), pat.end());
+        const size_t npiv_pat = pat.size();
+        for (i64 t = Rs->p[0]; t < Rs->p[1]; t++) { x[Rs->j[t]] = Rs->x[t]; pat.push_back(Rs->j[t]); }
+        std::sort(pat.begin() + (long)npiv_pat, pat.end());
+        const int top = m - (int)pat.size();
+        for (size_t t = 0; t < pat.size(); t++) xj[(size_t)top + t] = pat[t];
+        spasm_csr_free(X);
+        spasm_csr_free(Rs);
+        return top;
+    } catch (const std::exception &e) {
+        if (X) spasm_csr_free(X);
+        if (Rs) spasm_csr_free(Rs);
+        spasm_set_error("%s", e.what());
+        return -1;
     }
 }
 

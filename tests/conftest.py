@@ -13,30 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def _leftmost_by_default(fn):
-    """Most parity tests compare results (pivot columns, kernel basis, rref) that do not depend on how the rounds went only while
-    every pivot is a leftmost entry: the engine and the oracle finish differently (dense / batched rounds vs sequential GPLU).
-    They therefore run with enable_greedy_pivot_search=False unless they say otherwise; the tests of the "FL on columns" search
-    pass enable_greedy_pivot_search=True themselves, with options under which both sides go through the same rounds."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapped(A, *args, **kwargs):
-        kwargs.setdefault("enable_greedy_pivot_search", False)
-        return fn(A, *args, **kwargs)
-
-    wrapped.__wrapped_leftmost__ = True
-    return wrapped
+# Passed explicitly (`**LM`) by the tests whose comparisons hold entry for entry only while every pivot is a leftmost entry: rank,
+# pivot columns, kernel basis and rref then do not depend on how the rounds went (the engine and the oracle finish differently:
+# dense / batched rounds vs sequential GPLU).  The library's own default -- the reference's, enable_greedy_pivot_search = 1,
+# src/SpaSM.jl:326 -- is what tests/test_gpu_default_options.py runs the same groups with.
+LM = {"enable_greedy_pivot_search": False}
 
 
 @pytest.fixture(scope="session")
 def S():
     import spasm_jl_amd
-    from spasm_jl_amd import api
 
-    if not getattr(api.echelonize, "__wrapped_leftmost__", False):
-        api.echelonize = _leftmost_by_default(api.echelonize)  # (kernel(A), rank(A), blocks and sharded look it up there)
-        spasm_jl_amd.echelonize = api.echelonize
     return spasm_jl_amd
 
 
@@ -45,6 +32,4 @@ def O():
     import oracle_ffi
 
     oracle_ffi.lib()
-    if not getattr(oracle_ffi.echelonize, "__wrapped_leftmost__", False):
-        oracle_ffi.echelonize = _leftmost_by_default(oracle_ffi.echelonize)
     return oracle_ffi

@@ -45,6 +45,8 @@ def lib():
         h.orc_schur_round.argtypes = [_P(CsrStruct), _P(C.c_int64), _P(C.c_double), _P(_P(CsrStruct)), _P(C.c_int)]
         h.orc_schur_round_range.restype = _P(CsrStruct)
         h.orc_schur_round_range.argtypes = [_P(CsrStruct), C.c_int, C.c_int, _P(C.c_int64), _P(C.c_double), _P(_P(CsrStruct)), _P(C.c_int)]
+        h.orc_sparse_triangular_solve.restype = C.c_int
+        h.orc_sparse_triangular_solve.argtypes = [_P(CsrStruct), _P(CsrStruct), C.c_int, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]
         h.orc_num_threads.restype = C.c_int
         h.orc_set_threads.argtypes = [C.c_int]
         h.orc_set_threads.restype = None
@@ -126,6 +128,16 @@ def echelonize(A, **kwargs):
 
 def kernel(lu):
     return OCSR(lib().orc_kernel(lu.data))
+
+
+def sparse_triangular_solve(U, B, k, xj, x, qinv):
+    """The oracle's restatement of spasm_sparse_triangular_solve (reference src/SpaSM.jl:694-713) on row k of B: reach (DFS) + scatter.
+    xj: int32[3m] zeroed, x: int32[m]; returns top."""
+    m = U.m
+    q = np.ascontiguousarray(qinv, dtype=np.int32)
+    pstack = np.zeros(max(m, 1), dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(_P(C.c_int32))  # noqa: E731
+    return int(lib().orc_sparse_triangular_solve(U.data, B.data, int(k), ip(xj), ip(x), ip(q), ip(pstack), None))
 
 
 def transpose(A):

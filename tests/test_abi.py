@@ -6,6 +6,7 @@ import re
 
 import numpy as np
 import pytest
+from conftest import LM  # leftmost-entry pivots only: what these tests compare does not depend on how the rounds went then
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -90,6 +91,6 @@ def test_hot_path_fails_loudly_without_gpu(S):
         pytest.skip("a GPU is present")
     A = S.CSR(np.array([[1, 2], [3, 6]]))
     with pytest.raises(S.SpasmError, match="no HIP device"):
-        S.echelonize(A)
+        S.echelonize(A, **LM)
     with pytest.raises(S.SpasmError, match="no HIP device"):
         S.transpose(A)

@@ -1,6 +1,7 @@
 """Block-diagonal driver (reference src/blocks.jl)."""
 import numpy as np
 import pytest
+from conftest import LM  # leftmost-entry pivots only: what these tests compare does not depend on how the rounds went then
 
 
 def make_block_matrix(S, seed=3, p=42013):
@@ -43,14 +44,14 @@ def test_block_split_and_reassembly(S):
 def test_block_rank_and_kernel_match_the_unsplit_matrix(S, O):
     A, _ = make_block_matrix(S, seed=11)
     B = S.Block.from_csr(A)
-    E = S.blocks.echelonize(B)
-    olu = O.echelonize(A)
+    E = S.blocks.echelonize(B, **LM)
+    olu = O.echelonize(A, **LM)
     assert S.blocks.rank(E) == olu.r == S.rank(A)
     K = S.blocks.kernel(E).to_csr()
     want = O.kernel(olu).rows()
     assert K.shape == (len(want), A.m)
     assert sorted(K.rows()) == sorted(want)  # same kernel vectors, ordered block after block (src/blocks.jl:119-137)
     # owner=(rank, world): every block is echelonized by exactly one of two processes
-    parts = [S.blocks.echelonize(B, owner=(r, 2)) for r in range(2)]
+    parts = [S.blocks.echelonize(B, owner=(r, 2), **LM) for r in range(2)]
     assert all((parts[0].blocks[b] is None) != (parts[1].blocks[b] is None) for b in range(len(B)))
     assert sum(S.blocks.rank(P) for P in parts) == olu.r

@@ -4,6 +4,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+from conftest import LM  # leftmost-entry pivots only: what these tests compare does not depend on how the rounds went then
 
 
 def _copy_lu(S, olu, n, drop_row=None, poke=None):
@@ -28,7 +29,7 @@ def _copy_lu(S, olu, n, drop_row=None, poke=None):
 @pytest.mark.parametrize("n,m,k,p,seed", [(300, 340, 5, 65521, 1), (200, 150, 4, 127, 2), (250, 250, 6, 0xfffffffb, 3), (120, 400, 3, 7, 4)])
 def test_verify_accepts_correct_and_rejects_wrong(S, O, n, m, k, p, seed):
     A = S.synth_csr(1, n, m, row_nnz=k, prime=p, seed=seed)
-    olu = O.echelonize(A)
+    olu = O.echelonize(A, **LM)
     good = _copy_lu(S, olu, n)
     assert good.r == olu.r
     for sd in (0, 1, 0xDEADBEEF):
@@ -52,7 +53,7 @@ def test_verify_accepts_correct_and_rejects_wrong(S, O, n, m, k, p, seed):
 def test_verify_rejects_mismatched_matrix(S, O):
     A = S.synth_csr(1, 200, 220, row_nnz=5, prime=65521, seed=11)
     B = S.synth_csr(1, 200, 220, row_nnz=5, prime=65521, seed=12)
-    lu = _copy_lu(S, O.echelonize(A), 200)
+    lu = _copy_lu(S, O.echelonize(A, **LM), 200)
     assert S.factorization_verify(A, lu, 3)
     assert not S.factorization_verify(B, lu, 3)
 

@@ -1,0 +1,39 @@
+"""The "FL on columns" pivot search against an INDEPENDENT restatement (tests/fl_columns_ref.py, written from DESIGN.md section 2):
+here the CPU oracle (no GPU needed); tests/test_gpu_default_options.py does the same for the engine.  Before this the oracle's
+search was only ever compared with the engine's, and the engine's with the oracle's."""
+import numpy as np
+import pytest
+
+import fl_columns_ref
+
+CASES = [
+    ("fixed_nnz", 1, 600, 600, dict(row_nnz=6), 65521),
+    ("three_per_row", 1, 1500, 1500, dict(row_nnz=3), 65521),
+    ("macaulay_like", 2, 800, 320, dict(row_nnz=40), 127),
+    ("bernoulli", 0, 300, 450, dict(density=0.02), 2147483647),
+    ("wide", 1, 500, 800, dict(row_nnz=8), 0xFFFFFFFB),
+]
+
+
+def pivots_of_first_round(lu, npiv0):
+    """(column, row) of the first npiv0 rows of U: qinv gives the columns, p (pivotal rows first) the rows of the input."""
+    q = np.asarray(lu.qinv)
+    col_of = {int(q[j]): j for j in range(len(q)) if q[j] >= 0}
+    p = np.asarray(lu.p)
+    return [(col_of[k], int(p[k])) for k in range(npiv0)]
+
+
+@pytest.mark.parametrize("name,kind,n,m,kw,prime", CASES, ids=[c[0] for c in CASES])
+def test_oracle_takes_the_pivots_of_the_written_rule(S, O, name, kind, n, m, kw, prime):
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xF1C2, **kw)
+    want, nopen = fl_columns_ref.structural_pivots(A.rows(), m, on_columns=True)
+    left, _ = fl_columns_ref.structural_pivots(A.rows(), m, on_columns=False)
+    assert nopen > 0 or name == "macaulay_like", "the case must exercise the search"  # (nearly all columns of that one are closed)
+    olu = O.echelonize(A, enable_greedy_pivot_search=True, max_round=1)
+    assert pivots_of_first_round(olu, len(want)) == want
+    olu2 = O.echelonize(A, enable_greedy_pivot_search=False, max_round=1)
+    assert pivots_of_first_round(olu2, len(left)) == left
+    # every open-column pivot sits on a column that no leftmost pivot row holds, and is not the leftmost entry of its row somewhere
+    rows = A.rows()
+    closed = {c for _, i in left for c, _ in rows[i]}
+    assert all(c not in closed for c, _ in want[:nopen])

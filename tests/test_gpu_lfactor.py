@@ -2,6 +2,7 @@
 factorization_verify (:934), gesv and solve (:889-923).  A[i] == sum_k L[i][k] U[k] is checked with exact integers."""
 import numpy as np
 import pytest
+from conftest import LM  # leftmost-entry pivots only: what these tests compare does not depend on how the rounds went then
 
 pytestmark = pytest.mark.gpu
 
@@ -36,8 +37,8 @@ CASES = [
 @pytest.mark.parametrize("name,kind,n,m,kw,prime,opts", CASES, ids=[c[0] for c in CASES])
 def test_L_times_U_is_A(S, O, name, kind, n, m, kw, prime, opts):
     A = S.synth_csr(kind, n, m, prime=prime, seed=0x1FAC, **kw)
-    fact = S.echelonize(A, L=True, **opts)
-    olu = O.echelonize(A)
+    fact = S.echelonize(A, L=True, **opts, **LM)
+    olu = O.echelonize(A, **LM)
     assert fact.r == olu.r
     L, U = fact.L, fact.U
     assert L.shape == (n, fact.r)
@@ -52,16 +53,16 @@ def test_L_times_U_is_A(S, O, name, kind, n, m, kw, prime, opts):
     for sd in (0, 1, 2):
         assert S.factorization_verify(A, fact, sd)
     # the kernel does not depend on whether L was kept
-    plain = S.echelonize(A, enable_dense=False, **opts)
+    plain = S.echelonize(A, enable_dense=False, **opts, **LM)
     assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(plain.qinv >= 0).tolist()
     assert S.kernel(fact).rows() == S.kernel(plain).rows()
 
 
 def test_L_survives_rounds_in_row_batches(S, O, monkeypatch):
     A = S.synth_csr(2, 4000, 1600, row_nnz=40, prime=127, seed=0x5A5A0005)
-    ref = S.echelonize(A, L=True)
+    ref = S.echelonize(A, L=True, **LM)
     monkeypatch.setenv("SPASM_AMD_MEM_BUDGET_MB", "8")
-    got = S.echelonize(A, L=True)
+    got = S.echelonize(A, L=True, **LM)
     monkeypatch.delenv("SPASM_AMD_MEM_BUDGET_MB")
     assert got.r == ref.r and got.L.rows() == ref.L.rows() and got.U.rows() == ref.U.rows()
     assert S.factorization_verify(A, got, 5)
@@ -72,7 +73,7 @@ def test_two_sided_verify_catches_what_one_sided_misses(S, O):
     check accepts it and reports a rank that is one too high.  With L the check is two-sided and must refuse it."""
     n, m, prime = 400, 380, 65521
     A = S.synth_csr(1, n, m, row_nnz=3, prime=prime, seed=77)
-    fact = S.echelonize(A, L=True)
+    fact = S.echelonize(A, L=True, **LM)
     r = fact.r
     q = np.asarray(fact.qinv).copy()
     free = [j for j in range(m) if q[j] < 0]
@@ -102,7 +103,7 @@ def test_two_sided_verify_catches_what_one_sided_misses(S, O):
 @pytest.mark.parametrize("n,m,k,prime,seed", [(400, 500, 5, 65521, 1), (500, 300, 4, 127, 2), (300, 420, 5, 2147483647, 3)])
 def test_gesv_and_solve(S, O, n, m, k, prime, seed):
     A = S.synth_csr(1, n, m, row_nnz=k, prime=prime, seed=seed)
-    fact = S.echelonize(A, L=True)
+    fact = S.echelonize(A, L=True, **LM)
     Arows = A.rows()
     rng = np.random.default_rng(seed)
 
@@ -139,4 +140,4 @@ def test_gesv_and_solve(S, O, n, m, k, prime, seed):
             bvec2[c] = v if v <= prime // 2 else v - prime
         assert S.solve(fact, bvec2) is None
     with pytest.raises(S.SpasmError):
-        S.gesv(S.echelonize(A), B)                                  # no L: the reference errors on fact.L too (:896, :916)
+        S.gesv(S.echelonize(A, **LM), B)                                  # no L: the reference errors on fact.L too (:896, :916)

@@ -7,6 +7,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import LM  # leftmost-entry pivots only: what these tests compare does not depend on how the rounds went then
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +53,7 @@ def test_reference_known_answer_kernels(S, case):
     else:
         base = next(c for c in GOLD["cases"] if c["name"] == case["m_transposed_of"])
         sm = S.transpose(S.CSR(np.array(base["m"])))
-    fact = S.echelonize(sm)
+    fact = S.echelonize(sm, **LM)
     assert S.rank(fact) == case["rank"]
     k = S.kernel(fact)
     assert (julia_sparse_of_kernel(k, P0) == np.array(case["kernel_sparse"])).all()  # test/runtests.jl:20-23, README.md:44-47
@@ -96,9 +97,9 @@ def test_echelonize_kernel_vs_oracle_and_dense(S, O, n, m, p, density, seed, ena
     rng = np.random.default_rng(seed)
     D = random_rows(rng, n, m, p, density, rank_deficient=True)
     A = S.CSR(D.T.copy(), prime=p)
-    fact = S.echelonize(A, enable_dense=enable_dense)  # reference option, src/SpaSM.jl:329
+    fact = S.echelonize(A, enable_dense=enable_dense, **LM)  # reference option, src/SpaSM.jl:329
     K = S.kernel(fact)
-    olu = O.echelonize(A)
+    olu = O.echelonize(A, **LM)
     oK = O.kernel(olu)
     assert fact.r == olu.r
     assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()  # identical pivot columns
@@ -126,8 +127,8 @@ def test_dense_tail_multi_panel(S, O, n, m, p, density, seed):
     D[:, 5] = 0          # a zero column and a repeated column: free columns inside the panels
     D[:, 70] = D[:, 3]
     A = S.CSR(D.T.copy(), prime=p)
-    fact = S.echelonize(A)
-    olu = O.echelonize(A)
+    fact = S.echelonize(A, **LM)
+    olu = O.echelonize(A, **LM)
     assert fact.r == olu.r
     assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()
     Kd, piv = O.dense_kernel_normal_form(D, p)
@@ -147,7 +148,7 @@ def test_kernel_accepts_foreign_factorizations(S, O):
 
     D = random_rows(rng, 60, 80, 65521, 0.06, rank_deficient=True)
     A = S.CSR(D.T.copy(), prime=65521)
-    olu = O.echelonize(A)
+    olu = O.echelonize(A, **LM)
     want = O.kernel(olu).rows()
     r = olu.r
     perm = rng.permutation(r)
@@ -173,13 +174,13 @@ def test_edge_cases(S):
     # empty matrix, zero rows, zero columns, all-zero rows, single entry
     for n, m in [(0, 5), (5, 0), (3, 4)]:
         A = S.CSR.from_rows([[] for _ in range(n)], m)
-        fact = S.echelonize(A)
+        fact = S.echelonize(A, **LM)
         assert fact.r == 0
         K = S.kernel(fact)
         assert K.shape == (m, m)
         assert K.rows() == [[(j, -1)] for j in range(m)]
     A = S.CSR.from_rows([[(3, 5)]], 6)
-    fact = S.echelonize(A)
+    fact = S.echelonize(A, **LM)
     assert fact.r == 1 and fact.qinv.tolist() == [-1, -1, -1, 0, -1, -1]
     assert fact.U.rows() == [[(3, 1)]]
     assert S.kernel(fact).rows() == [[(j, -1)] for j in (0, 1, 2, 4, 5)]
@@ -192,8 +193,8 @@ def test_edge_cases(S):
 def test_config2_random_10k(S, O):
     """BASELINE config 2: random 10k x 10k, density 1e-3, p = 42013: echelonize + kernel, rank bit-exact vs CPU."""
     A = S.synth_csr(0, 10000, 10000, density=1e-3, prime=42013, seed=0x5A5A0002)
-    fact = S.echelonize(A)
-    olu = O.echelonize(A)
+    fact = S.echelonize(A, **LM)
+    olu = O.echelonize(A, **LM)
     assert fact.r == olu.r
     assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()
     assert S.factorization_verify(A, fact, 2)  # the reference's self-check (src/SpaSM.jl:934) accepts the engine's LU
@@ -223,10 +224,10 @@ def test_config2_random_10k(S, O):
 def test_config5_macaulay_style_scaled_down(S, O):
     """BASELINE config 5 at 1/250 scale: Macaulay-like 20000 x 8000, p = 127: many FL pivots, small dense tail."""
     A = S.synth_csr(2, 20000, 8000, row_nnz=40, prime=127, seed=0x5A5A0005)
-    fact = S.echelonize(A)
+    fact = S.echelonize(A, **LM)
     rounds = S.last_rounds()
     assert rounds and rounds[0]["npiv"] > 0.5 * min(A.n, A.m) * 0.5  # the first round elects most pivots
-    olu = O.echelonize(A)
+    olu = O.echelonize(A, **LM)
     assert fact.r == olu.r
     assert (np.asarray(fact.qinv) >= 0).tolist() == (olu.qinv >= 0).tolist()
     assert S.factorization_verify(A, fact, 5)
@@ -247,15 +248,15 @@ def test_rounds_in_row_batches_when_memory_is_short(S, O, monkeypatch, kind, n, 
     appended to the next round's matrix. Forced here by a 16 MB budget; U, rank and kernel must not change."""
     monkeypatch.setenv("SPASM_AMD_ROUND_STATS", "1")  # exact trip counters: the rounds keep to the multiplier lists
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xB47C4, **kw)
-    ref = S.echelonize(A, enable_dense=False)
+    ref = S.echelonize(A, enable_dense=False, **LM)
     ref_rounds = S.last_rounds()
     monkeypatch.setenv("SPASM_AMD_MEM_BUDGET_MB", "16")
     try:
-        got = S.echelonize(A, enable_dense=False)
+        got = S.echelonize(A, enable_dense=False, **LM)
         got_rounds = S.last_rounds()
     finally:
         monkeypatch.delenv("SPASM_AMD_MEM_BUDGET_MB")
-    assert got.r == ref.r == O.echelonize(A).r
+    assert got.r == ref.r == O.echelonize(A, **LM).r
     assert np.asarray(got.qinv).tolist() == np.asarray(ref.qinv).tolist()
     assert len(got_rounds) == len(ref_rounds)
     for a, b in zip(got_rounds, ref_rounds):  # same pivots, same eliminations, same Schur complements round by round
@@ -274,7 +275,7 @@ def test_rref_is_the_unique_reduced_echelon_form(S, O, n, m, p, density, seed):
     D = ((rng.random((n, m)) < density) * rng.integers(1, min(p, 1 << 31), size=(n, m))).astype(np.int64)
     D[n - 1] = (3 * D[0] + 5 * D[1]) % p  # rank deficiency
     A = S.CSR(D.T.copy(), prime=p)         # CSR(dense) stores the transpose, like the reference: rows of A = rows of D
-    fact = S.echelonize(A)
+    fact = S.echelonize(A, **LM)
     R, rq = S.rref(fact)
     want, piv = O.dense_rref(D, p)
     assert R.n == fact.r == len(piv)
@@ -294,7 +295,7 @@ def test_sparse_triangular_solve_all_rows_at_once(S, O, n, m, p, seed):
     """sparse_triangular_solve(LU, B) (reference src/SpaSM.jl:725-755, semantics :694-713): X * U == B checked exactly with
     integers; rows outside the row space are reported unsolvable; the oracle's row-by-row solve gives the same x_b."""
     A = S.synth_csr(1, n, m, row_nnz=5, prime=p, seed=seed)
-    fact = S.echelonize(A)
+    fact = S.echelonize(A, **LM)
     U, qinv = fact.U, np.asarray(fact.qinv)
     r = fact.r
     rng = np.random.default_rng(seed)
@@ -339,7 +340,7 @@ def test_sparse_triangular_solve_all_rows_at_once(S, O, n, m, p, seed):
 def test_kernel_of_a_strided_subset_of_the_free_columns(S):
     """spasm_amd_kernel_strided (the multi-GPU kernel step): vectors first, first + step, ... of the whole basis."""
     A = S.synth_csr(0, 900, 1100, density=4e-3, prime=42013, seed=0xFEED)
-    fact = S.echelonize(A)
+    fact = S.echelonize(A, **LM)
     K = S.kernel(fact).rows()
     assert len(K) == A.m - fact.r > 50
     lib = S._abi.lib()
@@ -353,7 +354,7 @@ def test_rref_of_a_multi_round_factorization(S, O):
     """U of several sparse rounds plus a dense tail (config-2 style, scaled down): R must have no entry on a foreign pivot
     column, span the same space (verify), and reproduce the kernel through the textbook formula k[piv(a)] = R[a][j]."""
     A = S.synth_csr(0, 1500, 1600, density=3e-3, prime=42013, seed=0xABCD)
-    fact = S.echelonize(A)
+    fact = S.echelonize(A, **LM)
     assert len(S.last_rounds()) >= 2
     R, rq = S.rref(fact)
     assert R.n == fact.r
@@ -571,7 +572,7 @@ def test_fuzz_small_primes_vs_dense_elimination(S, O, enable_dense):
         if m > 4 and rng.random() < 0.3:
             D[:, m - 1] = 0
         A = S.CSR(D.T.copy(), prime=p)
-        fact = S.echelonize(A, enable_dense=enable_dense)
+        fact = S.echelonize(A, enable_dense=enable_dense, **LM)
         Kd, piv = O.dense_kernel_normal_form(D, p)
         assert fact.r == len(piv), (trial, p, n, m)
         assert sorted(np.nonzero(np.asarray(fact.qinv) >= 0)[0].tolist()) == piv, (trial, p, n, m)
@@ -606,15 +607,15 @@ def test_round_loop_options_change_the_rounds_not_the_result(S, O):
     rounds run before the finish takes over; every pivot stays a leftmost entry, so rank, pivot columns and kernel do not
     move.  The round records (spasm_amd_last_rounds) must show the difference."""
     A = S.synth_csr(1, 3000, 3000, row_nnz=6, prime=65521, seed=0x0917)
-    ref = S.echelonize(A, max_round=50, min_pivot_proportion=0.0, enable_dense=False)  # sparse rounds to the end
+    ref = S.echelonize(A, max_round=50, min_pivot_proportion=0.0, enable_dense=False, **LM)  # sparse rounds to the end
     n_ref = len(S.last_rounds())
-    one = S.echelonize(A, max_round=1, min_pivot_proportion=0.0)
+    one = S.echelonize(A, max_round=1, min_pivot_proportion=0.0, **LM)
     n_one = len(S.last_rounds())
-    none = S.echelonize(A, max_round=50, min_pivot_proportion=0.9)
+    none = S.echelonize(A, max_round=50, min_pivot_proportion=0.9, **LM)
     n_none = len(S.last_rounds())
-    dflt = S.echelonize(A)
+    dflt = S.echelonize(A, **LM)
     assert n_ref > 2 and n_one == 1 and n_none == 0, (n_ref, n_one, n_none)
-    olu = O.echelonize(A)
+    olu = O.echelonize(A, **LM)
     for f in (ref, one, none, dflt):
         assert f.r == olu.r
         assert np.asarray(f.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
@@ -632,10 +633,10 @@ def test_schur_complement_straight_to_dense(S, O, kind, n, m, kw, prime):
     pivot columns and kernel must equal the oracle's, and the record of the last round must show that no sparse Schur
     complement was counted."""
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xD35E, **kw)
-    fact = S.echelonize(A, sparsity_threshold=0.1)
+    fact = S.echelonize(A, sparsity_threshold=0.1, **LM)
     rounds = S.last_rounds()
     assert len(rounds) >= 1 and rounds[-1]["nnz_out"] == -1, rounds
-    olu = O.echelonize(A)
+    olu = O.echelonize(A, **LM)
     assert fact.r == olu.r
     assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
     assert S.kernel(fact).rows() == O.kernel(olu).rows()
@@ -752,7 +753,7 @@ def test_dense_finish_variants(S, O, monkeypatch, env, kind, n, m, kw, prime):
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xD35E, **kw)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    fact = S.echelonize(A, sparsity_threshold=0.1)
+    fact = S.echelonize(A, sparsity_threshold=0.1, **LM)
     rounds = S.last_rounds()
     for k in env:
         monkeypatch.delenv(k)
@@ -760,8 +761,53 @@ def test_dense_finish_variants(S, O, monkeypatch, env, kind, n, m, kw, prime):
         assert rounds[-1]["nnz_out"] == -1, rounds   # the round went straight to the dense finish
     # (with a 4 MB budget the row sample of the p = 65521 case does not fit, so no estimate is made and the round is built sparse
     # before the finish takes it; the Macaulay-like case estimates from columns and builds its dense W in slabs)
-    olu = O.echelonize(A)
+    olu = O.echelonize(A, **LM)
     assert fact.r == olu.r
     assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
     assert S.kernel(fact).rows() == O.kernel(olu).rows()
     assert S.factorization_verify(A, fact, 9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,p,seed", [(60, 80, 65521, 1), (90, 70, 127, 2), (50, 120, 0xFFFFFFFB, 3)])
+def test_sparse_triangular_solve_one_row_as_the_reference_binds_it(S, O, n, m, p, seed):
+    """spasm_sparse_triangular_solve(U, B, k, xj, x, qinv) (reference src/SpaSM.jl:721, semantics :694-713) and spasm_scatter (:620):
+    with x_b on the pivot columns and x_a on the others, x_b * U + x_a == B[k], checked with spasm_scatter itself and exact integers;
+    the pattern is xj[top:m]; against the oracle's orc_sparse_triangular_solve value for value."""
+    rng = np.random.default_rng(seed)
+    D = ((rng.random((n, m)) < 0.08) * rng.integers(1, min(p, 1 << 31), size=(n, m))).astype(np.int64)
+    A = S.CSR(D.T.copy(), prime=p)
+    fact = S.echelonize(A, **LM)
+    U, q = fact.U, np.asarray(fact.qinv, dtype=np.int32)
+    B = S.CSR(((rng.random((7, m)) < 0.15) * rng.integers(1, min(p, 1 << 31), size=(7, m))).astype(np.int64).T.copy(), prime=p)
+    Brows = B.rows()
+    Urows = U.rows()
+    for k in range(B.n):
+        xj = np.zeros(3 * m, dtype=np.int32)
+        x = np.full(m, 12345, dtype=np.int32)  # "does not need to be initialized"
+        top = S.sparse_triangular_solve_row(U, B, k, xj, x, q)
+        pat = xj[top:m].tolist()
+        assert len(set(pat)) == len(pat) and not xj[m:].any()
+        # x_b * U + x_a == B[k]
+        acc = {}
+        for j in pat:
+            v = int(x[j])
+            if q[j] >= 0:
+                for c, u in Urows[int(q[j])]:
+                    acc[c] = (acc.get(c, 0) + v * int(u)) % p
+            else:
+                acc[j] = (acc.get(j, 0) + v) % p
+        want = {c: int(v) % p for c, v in Brows[k]}
+        assert {c: v for c, v in acc.items() if v} == {c: v for c, v in want.items() if v}
+        # the oracle's solve of the same row: same values on its pattern
+        oxj = np.zeros(3 * m, dtype=np.int32)
+        ox = np.zeros(m, dtype=np.int32)
+        otop = O.sparse_triangular_solve(U, B, k, oxj, ox, q)
+        for j in oxj[otop:m].tolist():
+            if ox[j] != 0:
+                assert j in pat and int(x[j]) == int(ox[j])
+        assert {j for j in pat if x[j] != 0} == {j for j in oxj[otop:m].tolist() if ox[j] != 0}
+    # spasm_scatter: x += beta * U[0]
+    y = np.zeros(m, dtype=np.int32)
+    S.scatter(U, 0, 3, y)
+    assert {c: int(y[c]) % p for c in np.nonzero(y)[0]} == {c: (3 * int(v)) % p for c, v in Urows[0] if (3 * int(v)) % p}

@@ -7,6 +7,7 @@ import random
 
 import numpy as np
 import pytest
+from conftest import LM  # leftmost-entry pivots only: what these tests compare does not depend on how the rounds went then
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
@@ -34,7 +35,7 @@ def test_oracle_reproduces_reference_known_answers(S, O, case):
     m, transposed = _case_matrix(case)
     A = S.CSR(m)
     src = O.transpose(A) if transposed else A
-    lu = O.echelonize(src)
+    lu = O.echelonize(src, **LM)
     assert lu.r == case["rank"]
     K = O.kernel(lu)
     assert (kernel_as_julia_sparse(K, P) == np.array(case["kernel_sparse"])).all()
@@ -92,7 +93,7 @@ def test_oracle_against_independent_dense_elimination(S, O, n, m, p, density, se
     D = random_rows(rng, n, m, p, density, rank_deficient=True)
     A = S.CSR(D.T.copy(), prime=p)  # CSR(x) stores x^T, so pass D^T to get libspasm rows = rows of D
     assert (A.todense() % p == D % p).all()
-    lu = O.echelonize(A)
+    lu = O.echelonize(A, **LM)
     K = O.kernel(lu)
     Kd, piv = O.dense_kernel_normal_form(D, p)
     assert lu.r == len(piv)

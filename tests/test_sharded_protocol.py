@@ -8,6 +8,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from conftest import LM  # leftmost-entry pivots only: what these tests compare does not depend on how the rounds went then
 
 INT64_MAX = np.iinfo(np.int64).max
 
@@ -222,7 +223,7 @@ def test_echelonize_sharded_rounds_gloo(S, O, world, finish_nnz):
         pr.join(timeout=60)
         assert pr.exitcode == 0
     A = S.synth_csr(1, n, m, row_nnz=k, prime=p, seed=seed)
-    olu = O.echelonize(A)
+    olu = O.echelonize(A, **LM)
     oK = O.kernel(olu)
     results.sort()
     for rank, r, qinv, Krows, rounds in results:
