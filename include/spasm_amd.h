@@ -158,6 +158,31 @@ void spasm_csr_save(const struct spasm_csr *A, void *file);          /* FILE*, s
  * row space of A and rank(A) == r.  Without L, (c) and (d) are skipped: a U with rows outside the row space of A passes. ---- */
 bool spasm_factorization_verify(const struct spasm_csr *A, const struct spasm_lu *fact, uint64_t seed);
 
+/* ---- spasm_certificate.c: rank certificates (src/SpaSM.jl:345-353, :928-933).  A certificate proves rank(A) >= r to somebody who
+ * only has A: r rows i[] and r columns j[] whose r x r submatrix C is non-singular, shown by a vector y with y * C == x for a
+ * challenge x the prover cannot choose -- x is drawn from SHA-256(hash, prime, r, i, j) (Fiat-Shamir; `hash` is the 32-byte digest
+ * of the matrix file as spasm_triplet_load computes it): if C were singular a random x would lie in its row space with probability
+ * <= 1/p.  Verification is host-side and O(nnz(A)); together with spasm_factorization_verify (rank(A) <= r) it pins the rank.
+ * Creation takes the pivotal rows and the pivot columns of `fact` and solves y * C == x on the device (C is echelonized with L,
+ * then spasm_solve).  libspasm's on-disk format is not in the reference tree: save/load use a text format of their own
+ * ("spasm-amd rank certificate v1", then r, prime, the hash in hex and r lines "i j x y"). ---- */
+struct spasm_rank_certificate {      /* src/SpaSM.jl:345-353 */
+    int r;
+    i64 prime;
+    uint8_t hash[32];
+    int *i;                          /* r rows of A */
+    int *j;                          /* r columns of A */
+    spasm_ZZp *x;                    /* the challenge */
+    spasm_ZZp *y;                    /* the response: y * A[i, j] == x */
+};
+struct spasm_rank_certificate *spasm_certificate_rank_create(const struct spasm_csr *A, const uint8_t *hash, const struct spasm_lu *fact); /* :928 */
+bool spasm_certificate_rank_verify(const struct spasm_csr *A, const uint8_t *hash, const struct spasm_rank_certificate *proof);           /* :930 */
+void spasm_rank_certificate_save(const struct spasm_rank_certificate *proof, void *file);  /* FILE*, :931 */
+bool spasm_rank_certificate_load(void *file, struct spasm_rank_certificate *proof);        /* FILE*, :933; fills a caller-owned struct */
+void spasm_rank_certificate_free(struct spasm_rank_certificate *proof);                    /* engine extension: the arrays and the struct */
+/* the challenge a certificate with these rows and columns must answer (r balanced residues); engine extension, for verifiers and tests */
+void spasm_amd_certificate_challenge(const uint8_t *hash, i64 prime, int r, const int *i, const int *j, spasm_ZZp *x);
+
 /* ---- spasm_solve.c (src/SpaSM.jl:895-923), for a factorization that carries L (echelonize with opts->L; the sparse rounds then
  * keep their multiplier lists and the dense finish is not used).  L is n x r with A[i] == sum_k L[i][k] U[k]; the entry of row
  * p[k] on column k is the pivot U's row k was divided by.

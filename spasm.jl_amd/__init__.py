@@ -13,7 +13,12 @@ from .api import (
     SpasmError,
     Triplet,
     ZZp,
+    RankCertificate,
     balanced,
+    certificate_rank_create,
+    certificate_rank_verify,
+    rank_certificate_load,
+    rank_certificate_save,
     echelonize,
     factorization_verify,
     gesv,
@@ -35,6 +40,6 @@ from .api import (
 )
 
 __all__ = [
-    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "echelonize", "factorization_verify", "gesv", "solve", "kernel",
+    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "RankCertificate", "certificate_rank_create", "certificate_rank_verify", "rank_certificate_save", "rank_certificate_load", "echelonize", "factorization_verify", "gesv", "solve", "kernel",
     "last_rounds", "nnz", "prime0", "rank", "rref", "sparse", "sparse_triangular_solve", "sparse_triangular_solve_row", "scatter", "synth_csr", "transpose",
 ]

@@ -70,6 +70,18 @@ class EchelonizeOptsStruct(C.Structure):  # reference src/SpaSM.jl:325-343
     ]
 
 
+class RankCertificateStruct(C.Structure):  # struct spasm_rank_certificate <-> RankCertificate{F} (reference src/SpaSM.jl:345-353)
+    _fields_ = [
+        ("r", C.c_int32),
+        ("prime", C.c_int64),
+        ("hash", C.c_uint8 * 32),
+        ("i", C.POINTER(C.c_int32)),
+        ("j", C.POINTER(C.c_int32)),
+        ("x", C.POINTER(C.c_int32)),
+        ("y", C.POINTER(C.c_int32)),
+    ]
+
+
 class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension)
     _fields_ = [
         ("round", C.c_int32),
@@ -187,6 +199,12 @@ SIGNATURES = {
     "spasm_amd_triangular_solve": (_P(CsrStruct), [_P(CsrStruct), _P(C.c_int32), _P(CsrStruct), _P(C.c_ubyte)]),
     "spasm_sparse_triangular_solve": (C.c_int32, [_P(CsrStruct), _P(CsrStruct), C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "spasm_scatter": (None, [_P(CsrStruct), C.c_int32, C.c_int32, _P(C.c_int32)]),
+    "spasm_certificate_rank_create": (_P(RankCertificateStruct), [_P(CsrStruct), _P(C.c_uint8), _P(LuStruct)]),
+    "spasm_certificate_rank_verify": (C.c_bool, [_P(CsrStruct), _P(C.c_uint8), _P(RankCertificateStruct)]),
+    "spasm_rank_certificate_save": (None, [_P(RankCertificateStruct), C.c_void_p]),
+    "spasm_rank_certificate_load": (C.c_bool, [C.c_void_p, _P(RankCertificateStruct)]),
+    "spasm_rank_certificate_free": (None, [_P(RankCertificateStruct)]),
+    "spasm_amd_certificate_challenge": (None, [_P(C.c_uint8), C.c_int64, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "spasm_amd_kernel_strided": (_P(CsrStruct), [_P(LuStruct), C.c_int32, C.c_int32]),
     "spasm_amd_schur_plan_advance": (C.c_void_p, [C.c_void_p, _P(C.c_int32), _P(C.c_int64)]),
     "spasm_amd_shard_fetch": (_P(CsrStruct), [C.c_void_p]),

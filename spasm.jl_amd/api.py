@@ -583,3 +583,87 @@ def save(path, A):
             _abi.lib().spasm_csr_save(A.data, f)
     finally:
         _libc.fclose(f)
+
+
+# ---------------------------------------------------------------------------------------------
+# Rank certificates  (reference src/SpaSM.jl:345-353, :928-933)
+# ---------------------------------------------------------------------------------------------
+class RankCertificate:
+    """RankCertificate{F}: r rows i and r columns j of A whose submatrix is shown non-singular by y * A[i, j] == x for the
+    challenge x drawn from (hash, prime, r, i, j) -- a proof that rank(A) >= r (include/spasm_amd.h)."""
+
+    def __init__(self, ptr, own=True):
+        assert ptr
+        self.data = ptr
+        self._own = own
+
+    def __del__(self):
+        if getattr(self, "data", None) and self._own:
+            try:
+                _abi.lib().spasm_rank_certificate_free(self.data)
+            except Exception:
+                pass
+            self.data = None
+
+    r = property(lambda s: int(s.data.contents.r))
+    prime = property(lambda s: int(s.data.contents.prime))
+    hash = property(lambda s: bytes(s.data.contents.hash))
+
+    def _arr(self, name):
+        r = self.r
+        return np.ctypeslib.as_array(getattr(self.data.contents, name), (max(r, 1),))[:r]
+
+    i = property(lambda s: s._arr("i"))
+    j = property(lambda s: s._arr("j"))
+    x = property(lambda s: s._arr("x"))
+    y = property(lambda s: s._arr("y"))
+
+
+def _hash_arg(h):
+    h = bytes(h)
+    assert len(h) == 32, "the hash is the 32-byte SHA-256 digest load(..., get_hash=True) returns"
+    return (C.c_uint8 * 32).from_buffer_copy(h)
+
+
+def certificate_rank_create(A, hash, fact):
+    """certificate_rank_create(A, hash, fact) (reference src/SpaSM.jl:928)."""
+    ptr = _abi.lib().spasm_certificate_rank_create(A.data, _hash_arg(hash), fact.data)
+    if not ptr:
+        raise SpasmError("spasm_certificate_rank_create failed: " + _abi.last_error())
+    return RankCertificate(ptr)
+
+
+def certificate_rank_verify(A, hash, proof):
+    """certificate_rank_verify(A, hash, proof) -> Bool (reference src/SpaSM.jl:930): host-side, O(nnz(A))."""
+    return bool(_abi.lib().spasm_certificate_rank_verify(A.data, _hash_arg(hash), proof.data))
+
+
+def rank_certificate_save(proof, path):
+    """rank_certificate_save(proof, file) (reference src/SpaSM.jl:931)."""
+    f = _libc.fopen(str(path).encode(), b"w")
+    if not f:
+        raise OSError(f"cannot open {path}")
+    try:
+        _abi.lib().spasm_rank_certificate_save(proof.data, f)
+    finally:
+        _libc.fclose(f)
+
+
+def rank_certificate_load(path):
+    """rank_certificate_load(file, proof) (reference src/SpaSM.jl:933): a RankCertificate, or None when the file does not parse."""
+    f = _libc.fopen(str(path).encode(), b"r")
+    if not f:
+        raise OSError(f"cannot open {path}")
+    libc = C.CDLL(None)
+    libc.calloc.restype = C.c_void_p
+    libc.calloc.argtypes = [C.c_size_t, C.c_size_t]
+    mem = libc.calloc(1, C.sizeof(_abi.RankCertificateStruct))
+    ptr = C.cast(mem, C.POINTER(_abi.RankCertificateStruct))
+    try:
+        ok = _abi.lib().spasm_rank_certificate_load(f, ptr)
+    finally:
+        _libc.fclose(f)
+    if not ok:
+        _abi.lib().spasm_rank_certificate_free(ptr)
+        return None
+    return RankCertificate(ptr)

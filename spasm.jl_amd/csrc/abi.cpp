@@ -293,6 +293,130 @@ struct Sha256 {
 };
 } // namespace
 
+// ---- rank certificates (reference src/SpaSM.jl:345-353, :928-933; include/spasm_amd.h) ---------------------------------------
+void spasm_cert_challenge(const uint8_t *hash, i64 prime, int r, const int *ri, const int *cj, spasm_ZZp *x)
+{
+    // seed = SHA-256(hash || prime || r || rows || columns); block k of the stream = SHA-256(seed || k), cut into 32-bit words, each
+    // masked to the bits of the prime and rejected when >= prime (uniform residues)
+    uint8_t seed[32];
+    {
+        Sha256 h;
+        h.update(hash, 32);
+        const int64_t hdr[2] = {prime, (int64_t)r};
+        h.update((const uint8_t *)hdr, sizeof hdr);
+        if (r > 0) { h.update((const uint8_t *)ri, (size_t)r * sizeof(int)); h.update((const uint8_t *)cj, (size_t)r * sizeof(int)); }
+        h.final(seed);
+    }
+    uint64_t mask = 1;
+    while (mask <= (uint64_t)prime) mask <<= 1;
+    mask -= 1;
+    const ZpField F = zp_field_make(prime);
+    uint64_t ctr = 0;
+    int have = 0;
+    uint8_t blk[32];
+    for (int k = 0; k < r;) {
+        if (have == 0) {
+            Sha256 h;
+            h.update(seed, 32);
+            h.update((const uint8_t *)&ctr, sizeof ctr);
+            h.final(blk);
+            ctr++;
+            have = 8;
+        }
+        const uint8_t *w = blk + 4 * (8 - have);
+        have--;
+        const uint64_t v = ((uint64_t)w[0] << 24 | (uint64_t)w[1] << 16 | (uint64_t)w[2] << 8 | (uint64_t)w[3]) & mask;
+        if (v >= (uint64_t)prime) continue;
+        x[k++] = zp_reduce(F, (int64_t)v);
+    }
+}
+
+extern "C" SPASM_API bool spasm_certificate_rank_verify(const struct spasm_csr *A, const uint8_t *hash, const struct spasm_rank_certificate *proof)
+{
+    spasm_clear_error();
+    if (!A || !hash || !proof) { spasm_set_error("spasm_certificate_rank_verify: null argument"); return false; }
+    const int r = proof->r, n = A->n, m = A->m;
+    if (r < 0 || r > n || r > m || proof->prime != A->field->p || memcmp(proof->hash, hash, 32) != 0) return false;
+    if (r == 0) return true;
+    if (!proof->i || !proof->j || !proof->x || !proof->y) return false;
+    const ZpField F = zp_field_make(A->field->p);
+    // the rows and the columns are distinct and in range
+    std::vector<int> pos((size_t)m, -1);
+    std::vector<char> seen((size_t)n, 0);
+    for (int k = 0; k < r; k++) {
+        const int i = proof->i[k], j = proof->j[k];
+        if (i < 0 || i >= n || j < 0 || j >= m || seen[(size_t)i] || pos[(size_t)j] >= 0) return false;
+        seen[(size_t)i] = 1;
+        pos[(size_t)j] = k;
+    }
+    // the challenge is the one the certificate's own commitment yields
+    std::vector<spasm_ZZp> x((size_t)r);
+    spasm_cert_challenge(hash, proof->prime, r, proof->i, proof->j, x.data());
+    for (int k = 0; k < r; k++) if (zp_reduce(F, (int64_t)proof->x[k]) != x[(size_t)k]) return false;
+    // y * A[i, j] == x, exactly
+    std::vector<spasm_ZZp> acc((size_t)r, 0);
+    for (int k = 0; k < r; k++) {
+        const int yk = zp_reduce(F, (int64_t)proof->y[k]);
+        if (yk == 0) continue;
+        const int i = proof->i[k];
+        for (i64 t = A->p[i]; t < A->p[i + 1]; t++) {
+            const int c = pos[(size_t)A->j[t]];
+            if (c >= 0) acc[(size_t)c] = zp_axpy(F, yk, zp_reduce(F, (int64_t)A->x[t]), acc[(size_t)c]);
+        }
+    }
+    for (int k = 0; k < r; k++) if (acc[(size_t)k] != x[(size_t)k]) return false;
+    return true;
+}
+
+extern "C" SPASM_API void spasm_amd_certificate_challenge(const uint8_t *hash, i64 prime, int r, const int *i, const int *j, spasm_ZZp *x)
+{
+    if (hash && x && r >= 0 && (r == 0 || (i && j))) spasm_cert_challenge(hash, prime, r, i, j, x);
+}
+
+extern "C" SPASM_API void spasm_rank_certificate_free(struct spasm_rank_certificate *proof)
+{
+    if (!proof) return;
+    free(proof->i); free(proof->j); free(proof->x); free(proof->y);
+    free(proof);
+}
+
+extern "C" SPASM_API void spasm_rank_certificate_save(const struct spasm_rank_certificate *proof, void *file)
+{
+    FILE *f = (FILE *)file;
+    if (!proof || !f) return;
+    fprintf(f, "spasm-amd rank certificate v1\n%d %lld\n", proof->r, (long long)proof->prime);
+    for (int k = 0; k < 32; k++) fprintf(f, "%02x", proof->hash[k]);
+    fprintf(f, "\n");
+    for (int k = 0; k < proof->r; k++) fprintf(f, "%d %d %d %d\n", proof->i[k], proof->j[k], proof->x[k], proof->y[k]);
+}
+
+extern "C" SPASM_API bool spasm_rank_certificate_load(void *file, struct spasm_rank_certificate *proof)
+{
+    FILE *f = (FILE *)file;
+    if (!proof || !f) return false;
+    char line[128];
+    if (!fgets(line, sizeof line, f) || strncmp(line, "spasm-amd rank certificate v1", 29) != 0) return false;
+    int r = 0;
+    long long prime = 0;
+    if (fscanf(f, "%d %lld", &r, &prime) != 2 || r < 0) return false;
+    char hex[80];
+    if (fscanf(f, "%79s", hex) != 1 || strlen(hex) != 64) return false;
+    for (int k = 0; k < 32; k++) {
+        unsigned v = 0;
+        if (sscanf(hex + 2 * k, "%2x", &v) != 1) return false;
+        proof->hash[k] = (uint8_t)v;
+    }
+    int *ri = (int *)malloc(sizeof(int) * (size_t)std::max(r, 1)), *cj = (int *)malloc(sizeof(int) * (size_t)std::max(r, 1));
+    spasm_ZZp *x = (spasm_ZZp *)malloc(sizeof(spasm_ZZp) * (size_t)std::max(r, 1)), *y = (spasm_ZZp *)malloc(sizeof(spasm_ZZp) * (size_t)std::max(r, 1));
+    bool ok = ri && cj && x && y;
+    for (int k = 0; ok && k < r; k++) ok = fscanf(f, "%d %d %d %d", &ri[k], &cj[k], &x[k], &y[k]) == 4;
+    if (!ok) { free(ri); free(cj); free(x); free(y); return false; }
+    proof->r = r;
+    proof->prime = prime;
+    proof->i = ri; proof->j = cj; proof->x = x; proof->y = y;
+    return true;
+}
+
 // SMS reader: header "n m M" (the letter is skipped, reference src/SpaSM.jl:1070), then "i j v" 1-based until "0 0 0"
 SPASM_API struct spasm_triplet *spasm_triplet_load(void *file, i64 prime, uint8_t *hash)
 {

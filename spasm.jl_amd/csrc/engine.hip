@@ -363,8 +363,10 @@ struct Round {
         HIPCHK(hipMemsetAsync(newpass.p, 0, ((size_t)m + 1) * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(is_piv.p, 0, ((size_t)A.n + 1) * sizeof(int), stream));
         hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, 0, 1, A.n, pivrow.p, is_piv.p);
+        HIPCHK(hipGetLastError());
         constexpr int TEAM = 8;
         hipLaunchKernelGGL((k_close_cols<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, stream, npiv, pivrow.p, A.start.p, A.len.p, A.ent.p, closed.p);
+        HIPCHK(hipGetLastError());
         int count[OPEN_PASSES + 1] = {0};
         int nnew = 0, npass = 0;
         for (int pass = 1; pass <= OPEN_PASSES; pass++) {
@@ -1433,6 +1435,7 @@ void upload_csr(const struct spasm_csr *A, int row_lo, int row_hi, DevMat &M, hi
         hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, n, row_lo, 1, dp.p, M.start.p, M.len.p, M.orig.p);
         HIPCHK(hipGetLastError());
         constexpr int TEAM = 8;
+        if (A->x) hipLaunchKernelGGL((k_drop_zeros<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p);
         hipLaunchKernelGGL((k_row_lead<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p, M.lead.p);
         HIPCHK(hipGetLastError());
     }
@@ -1478,6 +1481,7 @@ void upload_csr_strided(const struct spasm_csr *A, int row_lo, int row_hi, int s
         hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, n, row_lo, stride, dp.p, M.start.p, M.len.p, M.orig.p);
         HIPCHK(hipGetLastError());
         constexpr int TEAM = 8;
+        if (A->x) hipLaunchKernelGGL((k_drop_zeros<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p);
         hipLaunchKernelGGL((k_row_lead<TEAM>), dim3(cdiv((i64)n * TEAM, 256)), dim3(256), 0, s, n, M.start.p, M.len.p, M.ent.p, M.lead.p);
         HIPCHK(hipGetLastError());
     }
@@ -1619,11 +1623,24 @@ void append_round_U(HostU &U, const Round &R, const DevMat &A, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 // cells the dense finish may hold: a third of the free device memory in bytes (beside it: the dense W of a slab of columns, the
 // digit planes of a block, the rows of U it emits), at least 2^31 cells; elem = bytes per cell (dense_elem_bytes)
+// The hand-off to the dense finish is decided by the SHAPE: at most 2^36 bytes of dense matrix (64 GiB: a quarter of an MI355X,
+// beside the dense W of a slab of columns, the digit planes of a block and the rows of U it emits).  Free memory only vetoes
+// (a shared or smaller device): the caller then stays with sparse rounds, and the veto is logged, since with "FL on columns" the
+// pivot columns depend on where the sparse rounds stop.
 i64 dense_max_entries(int elem = 4)
 {
+    const i64 by_shape = ((i64)1 << 36) / std::max(elem, 1);
     size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (i64)1 << 31;
-    return std::max<i64>((i64)1 << 31, (i64)(fr / 3) / std::max(elem, 1));
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return by_shape;
+    const i64 by_memory = (i64)(fr / 3) / std::max(elem, 1);
+    if (by_memory < by_shape) {
+        static bool said = false;
+        if (!said) spasm_logf("[echelonize] dense finish capped by free device memory (%.1f GiB free): %lld cells instead of %lld\n", (double)fr / 1073741824.0,
+                              (long long)by_memory, (long long)by_shape);
+        said = true;
+        return by_memory;
+    }
+    return by_shape;
 }
 
 // which element type the dense matrix of a finish gets: bytes / shorts when the int8 path of dense.hpp will take it (its block
@@ -1730,7 +1747,13 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
                 unsigned long long *a_stamps = stamps.p;
                 void *args[] = {&a_Rp, &a_chunk, &a_w, &a_c0, &a_F, &a_P, &a_seq, &a_pc, &a_info, &a_sy, &a_cand, &a_st, &a_inv, &a_stamps};
                 const void *fn = inlds ? (const void *)k_panel_lu<true, 1024, DT> : (const void *)k_panel_lu<false, 1024, DT>;
-                HIPCHK(hipLaunchCooperativeKernel(fn, dim3(G), dim3(1024), args, (unsigned)lds, s));
+                // A PLAIN launch: G <= one workgroup per CU (LDS-bound), nothing else runs on the stream's device, so the grid is
+                // resident as a whole and the kernel's own barrier (dense.hpp: panel_grid_barrier, bounded spins) is enough.
+                // hipLaunchCooperativeKernel bought nothing but its launch-time size check, cost ~17 us per panel, and its dedicated
+                // HSA queue made every rocprofv3-profiled process die in exit(): libamdhip64's exit handler tears that queue down
+                // inside libhsa-runtime64 after rocprofiler-sdk has finalised its queue interception (tools/segv_probe.sh,
+                // profiles/r03_exit_sigsegv_backtrace.txt -- no frame of this library in the trace).
+                HIPCHK(hipLaunchKernel(fn, dim3(G), dim3(1024), args, (size_t)lds, s));
             }
             if (ND == 1) hipLaunchKernelGGL((k_panel_store<1, DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
             else hipLaunchKernelGGL((k_panel_store<2, DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
@@ -3472,6 +3495,7 @@ struct spasm_csr *plan_fetch_U(spasm_amd_schur_plan *P, int *pivcol_out, int *ro
     const int np = R.npiv;
     struct spasm_csr *Uc = spasm_csr_alloc(np, R.m, R.utotal, P->prime, true);
     if (!Uc) throw EngineError("out of host memory for the round's U rows");
+    std::unique_ptr<struct spasm_csr, void (*)(struct spasm_csr *)> guard(Uc, spasm_csr_free); // (a HIPCHK below may throw)
     if (np > 0) HIPCHK(hipMemcpyAsync(Uc->p, R.uoff.p, ((size_t)np + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
     else Uc->p[0] = 0;
     if (R.utotal > 0) {
@@ -3487,7 +3511,7 @@ struct spasm_csr *plan_fetch_U(spasm_amd_schur_plan *P, int *pivcol_out, int *ro
     if (np > 0 && pivcol_out) HIPCHK(hipMemcpyAsync(pivcol_out, R.pivcol.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
     if (np > 0 && row_out) HIPCHK(hipMemcpyAsync(row_out, R.pivrow.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    return Uc;
+    return guard.release();
 }
 
 struct spasm_csr *plan_fetch(spasm_amd_schur_plan *P, int *p_out)
@@ -3650,6 +3674,77 @@ SPASM_API struct spasm_csr *spasm_gesv(const struct spasm_lu *fact, const struct
 }
 
 // reference src/SpaSM.jl:895-905: x (n = rows of A entries) with x * A == b (m entries); false when there is no solution
+// reference src/SpaSM.jl:928: the certificate of rank(A) >= fact->r (include/spasm_amd.h): rows = the pivotal rows, columns = the
+// pivot columns, x = the Fiat-Shamir challenge, y with y * A[rows, columns] == x solved on the device (the r x r submatrix is
+// echelonized with L, then the two triangular solves of spasm_solve).  NULL on failure (e.g. when U is not of full rank r on A).
+SPASM_API struct spasm_rank_certificate *spasm_certificate_rank_create(const struct spasm_csr *A, const uint8_t *hash, const struct spasm_lu *fact)
+{
+    spasm_clear_error();
+    struct spasm_rank_certificate *P = nullptr;
+    struct spasm_csr *Cm = nullptr;
+    struct spasm_lu *fc = nullptr;
+    try {
+        if (!A || !hash || !fact || !fact->U || !fact->qinv || !fact->p) throw EngineError("null argument");
+        const int r = fact->r, n = A->n, m = A->m;
+        const i64 prime = A->field->p;
+        if (fact->U->m != m || r > n || r > m) throw EngineError("the factorization does not belong to this matrix");
+        P = (struct spasm_rank_certificate *)calloc(1, sizeof *P);
+        if (!P) throw EngineError("out of host memory");
+        P->r = r;
+        P->prime = prime;
+        memcpy(P->hash, hash, 32);
+        P->i = (int *)malloc(sizeof(int) * (size_t)std::max(r, 1));
+        P->j = (int *)malloc(sizeof(int) * (size_t)std::max(r, 1));
+        P->x = (spasm_ZZp *)calloc((size_t)std::max(r, 1), sizeof(spasm_ZZp));
+        P->y = (spasm_ZZp *)calloc((size_t)std::max(r, 1), sizeof(spasm_ZZp));
+        if (!P->i || !P->j || !P->x || !P->y) throw EngineError("out of host memory");
+        std::vector<int> pos((size_t)std::max(m, 1), -1);
+        for (int j = 0; j < m; j++) {
+            const int k = fact->qinv[j];
+            if (k >= 0) { if (k >= r) throw EngineError("qinv names a row beyond the rank"); P->j[k] = j; pos[(size_t)j] = k; }
+        }
+        i64 cz = 0;
+        for (int k = 0; k < r; k++) {
+            const int i = fact->p[k];
+            if (i < 0 || i >= n) throw EngineError("fact->p does not list the pivotal rows");
+            P->i[k] = i;
+            for (i64 t = A->p[i]; t < A->p[i + 1]; t++) cz += pos[(size_t)A->j[t]] >= 0;
+        }
+        spasm_cert_challenge(hash, prime, r, P->i, P->j, P->x);
+        if (r == 0) return P;
+        // C = A[rows, columns], r x r
+        Cm = spasm_csr_alloc(r, r, cz, prime, true);
+        if (!Cm) throw EngineError("out of host memory");
+        i64 w = 0;
+        for (int k = 0; k < r; k++) {
+            Cm->p[k] = w;
+            const int i = P->i[k];
+            for (i64 t = A->p[i]; t < A->p[i + 1]; t++) {
+                const int c = pos[(size_t)A->j[t]];
+                if (c >= 0) { Cm->j[w] = c; Cm->x[w] = A->x[t]; w++; }
+            }
+        }
+        Cm->p[r] = w;
+        struct echelonize_opts o;
+        spasm_echelonize_init_opts(&o);
+        o.L = true;
+        o.enable_greedy_pivot_search = false;
+        fc = do_echelonize(Cm, &o);
+        if (!fc || fc->r != r) throw EngineError("the pivotal rows and pivot columns do not span a non-singular submatrix");
+        if (!spasm_solve(fc, P->x, P->y)) throw EngineError("the challenge has no solution (singular submatrix)");
+        spasm_lu_free(fc);
+        spasm_csr_free(Cm);
+        return P;
+    } catch (const std::exception &e) {
+        std::string msg = e.what(); // (spasm_solve / spasm_lu_free below reset the error text)
+        if (fc) spasm_lu_free(fc);
+        if (Cm) spasm_csr_free(Cm);
+        spasm_rank_certificate_free(P);
+        spasm_set_error("spasm_certificate_rank_create: %s", msg.c_str());
+        return nullptr;
+    }
+}
+
 SPASM_API bool spasm_solve(const struct spasm_lu *fact, const spasm_ZZp *b, spasm_ZZp *x)
 {
     spasm_clear_error();

@@ -155,6 +155,30 @@ __global__ void k_pack_entries(i64d nnz, ZpField F, const int *__restrict__ j, c
     for (; k < nnz; k += stride) ent[k] = make_int2(j[k], x ? zp_reduce(F, (int64_t)x[k]) : 1);
 }
 
+// Explicit zeros (an entry whose value is 0 mod p; reference src/SpaSM.jl:959, :979 drops them when a CSR is built, but a C caller may
+// pass them) leave the rows at ingest, in place: "CSR with slack" lets a row shrink where it lies.  A zero that stayed could be
+// elected as a pivot (its "inverse" is 0: a silently wrong U).  One team per row, stable.
+template <int TEAM>
+__global__ void k_drop_zeros(int n, const i64d *__restrict__ start, int *__restrict__ len, int2 *__restrict__ ent)
+{
+    const int tl = threadIdx.x % TEAM;
+    const int i = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (i >= n) return;
+    const i64d st = start[i];
+    const int ln = len[i];
+    int out = 0;
+    for (int k0 = 0; k0 < ln; k0 += TEAM) {
+        const int k = k0 + tl;
+        int2 e = make_int2(0, 0);
+        if (k < ln) e = ent[st + k];
+        const bool keep = k < ln && e.y != 0;
+        const u64d mk = team_ballot<TEAM>(keep);
+        if (keep && out + __popcll(mk & ((1ull << tl) - 1ull)) != k) ent[st + out + __popcll(mk & ((1ull << tl) - 1ull))] = e; // (writes land at or before what was read)
+        out += __popcll(mk);
+    }
+    if (tl == 0 && out != ln) len[i] = out;
+}
+
 // local row i of a shard is global row row_lo + i * row_stride (stride 1: a contiguous block; stride G: every G-th row,
 // which balances the shards when the pivots concentrate at low row indices)
 __global__ void k_pack_rows(int n, int row_lo, int row_stride, const i64d *__restrict__ p, i64d *__restrict__ start, int *__restrict__ len, int *__restrict__ orig)

