@@ -339,6 +339,14 @@ spasm_amd_shard *spasm_amd_schur_plan_advance(spasm_amd_schur_plan *plan, int *r
 struct spasm_csr *spasm_amd_shard_fetch(spasm_amd_shard *sh);
 void spasm_amd_shard_free(spasm_amd_shard *sh);
 
+/* spasm_echelonize over several devices of THIS process: `nshards` row shards (shard s: rows s, s + nshards, ...; device s modulo
+ * the number of visible devices, so nshards = 8 on an 8-GPU node puts one shard on each), per round an election (per-column minimum
+ * of the shards' keys), an exchange of the elected pivot rows (peer copies over xGMI) and the local Schur complement of every shard's
+ * rows; the remainder is finished by the single-device engine.  Leftmost-entry pivots throughout, so rank, pivot columns and kernel
+ * equal those of spasm_echelonize with enable_greedy_pivot_search = 0 whatever nshards is.  What spasm.jl_amd/sharded.py does with
+ * one process per GPU and RCCL, behind one call for hosts without torch.distributed (the Julia side: one more @ccall). */
+struct spasm_lu *spasm_amd_echelonize_multi(const struct spasm_csr *A, struct echelonize_opts *opts, int nshards);
+
 /* Per-round records of the most recent spasm_echelonize call on this thread. */
 int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds);
 

@@ -20,6 +20,7 @@ from .api import (
     rank_certificate_load,
     rank_certificate_save,
     echelonize,
+    echelonize_multi,
     factorization_verify,
     gesv,
     kernel,
@@ -40,6 +41,6 @@ from .api import (
 )
 
 __all__ = [
-    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "RankCertificate", "certificate_rank_create", "certificate_rank_verify", "rank_certificate_save", "rank_certificate_load", "echelonize", "factorization_verify", "gesv", "solve", "kernel",
+    "Block", "blocks", "CSR", "LU", "Triplet", "load", "save", "EchelonizeOpts", "Field", "SpasmError", "ZZp", "balanced", "RankCertificate", "certificate_rank_create", "certificate_rank_verify", "rank_certificate_save", "rank_certificate_load", "echelonize", "echelonize_multi", "factorization_verify", "gesv", "solve", "kernel",
     "last_rounds", "nnz", "prime0", "rank", "rref", "sparse", "sparse_triangular_solve", "sparse_triangular_solve_row", "scatter", "synth_csr", "transpose",
 ]

@@ -356,6 +356,20 @@ def echelonize(A, opts=None, verbose=False, **kwargs):
     return LU(ptr)
 
 
+def echelonize_multi(A, nshards, opts=None, verbose=False, **kwargs):
+    """echelonize over `nshards` row shards on the devices of this process (spasm_amd_echelonize_multi; engine extension): the
+    LU of echelonize(A; enable_greedy_pivot_search=false) whatever nshards is -- same rank, pivot columns and kernel."""
+    if opts is None:
+        opts = EchelonizeOpts()
+    for k, v in kwargs.items():
+        if not hasattr(opts.struct, k):
+            raise AttributeError(f"type EchelonizeOpts has no field {k}")
+        setattr(opts.struct, k, v)
+    with _quiet(not verbose):
+        ptr = _abi.lib().spasm_amd_echelonize_multi(A.data, C.byref(opts.struct), int(nshards))
+    return LU(ptr)
+
+
 def kernel(A, verbose=False, **kwargs):
     """kernel(fact::LU) / kernel(A::CSR) (reference src/SpaSM.jl:876-882, :1147)."""
     fact = A if isinstance(A, LU) else echelonize(A, verbose=verbose, **kwargs)

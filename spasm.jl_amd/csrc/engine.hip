@@ -2243,6 +2243,9 @@ void collect_L_pivots(HostL &L, Round &R, const HostU &U, int ubase, hipStream_t
     }
 }
 
+struct HostL;
+struct spasm_lu *assemble_lu(HostU &U, int n, int m, i64 prime, HostL *HLp);
+
 struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
 {
     // max_round, min_pivot_proportion, enable_dense and sparsity_threshold (reference src/SpaSM.jl:329-337) decide how far the
@@ -2281,6 +2284,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     int round = 0;
     i64 cur_live = n;
     bool gplu_finish = false; // the sparse rounds are over (max_round / min_pivot_proportion) and the dense finish is not an option
+    bool partial = false;     // enable_GPLU = 0 and no dense finish: the factorization stops short (the reference's behaviour)
     while (cur->n > 0 && m > 0) {
         {
             const i64 cfree = (i64)m - (i64)U.pivcol.size();
@@ -2324,7 +2328,16 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
                     run_dense_tail(*cur, R->F, U, stream);
                     break;
                 }
-                spasm_logf("[echelonize] finishing with GPLU-style rounds%s\n", opts->enable_GPLU ? "" : " (the dense finish does not fit the device)");
+                if (!opts->enable_GPLU) {
+                    // enable_GPLU = 0 (reference src/SpaSM.jl:330) with the dense finish off, not applicable or vetoed: no method is left
+                    // to finish with.  libspasm says so and returns what the sparse rounds found ([UPSTREAM-RECALL] "Cannot finish
+                    // (no valid method; enable either GPLU or dense)"): U is then a partial echelon form and r a LOWER bound of the rank.
+                    spasm_logf("[echelonize] Cannot finish (no valid method; enable either GPLU or dense): stopping with %d pivots, a lower bound of the rank\n",
+                               (int)U.pivcol.size());
+                    partial = true;
+                    break;
+                }
+                spasm_logf("[echelonize] finishing with GPLU-style rounds\n");
                 gplu_finish = true;
             }
         }
@@ -2531,7 +2544,15 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         if (cur_nnz == 0) break;
     }
 
-    // ---- assemble the host LU (layout reference src/SpaSM.jl:262-270; ownership :273-277)
+    struct spasm_lu *N = assemble_lu(U, n, m, prime, want_L ? &HL : nullptr);
+    spasm_logf("[echelonize] Done in %.1fs. Rank %d%s, %lld nz in basis\n", spasm_wtime() - t0, N->r, partial ? " (not finished: a lower bound)" : "", (long long)U.p.back());
+    return N;
+}
+
+// ---- the host LU from the rows of U collected round by round (layout reference src/SpaSM.jl:262-270; ownership :273-277)
+struct spasm_lu *assemble_lu(HostU &U, int n, int m, i64 prime, HostL *HLp)
+{
+    const bool want_L = HLp != nullptr;
     const int r = (int)U.pivcol.size();
     struct spasm_csr *Uc = spasm_csr_alloc(r, m, 0, prime, true);
     if (!Uc) throw EngineError("out of host memory for U");
@@ -2560,6 +2581,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     struct spasm_csr *Lc = nullptr;
     if (want_L) {
         // rows of L in the order of the rows of A; inside a row the entries arrive round by round, i.e. by ascending row of U
+        HostL &HL = *HLp;
         const i64 lnz = (i64)HL.j.size();
         Lc = spasm_csr_alloc(n, r, lnz, prime, true);
         if (!Lc) throw EngineError("out of host memory for L");
@@ -2580,7 +2602,6 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     N->qinv = qinv;
     N->p = p;
     N->Ltmp = nullptr;
-    spasm_logf("[echelonize] Done in %.1fs. Rank %d, %lld nz in basis\n", spasm_wtime() - t0, r, (long long)U.p.back());
     return N;
 }
 
@@ -3550,11 +3571,254 @@ struct spasm_csr *plan_fetch(spasm_amd_schur_plan *P, int *p_out)
     return S;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The whole echelonization, row-sharded over the devices of ONE process (spasm_amd_echelonize_multi): what spasm.jl_amd/sharded.py
+// does between processes with torch.distributed, here with the shards of one host thread and peer copies over xGMI in place of the
+// collectives -- so that a Julia host reaches all GPUs of a node through one ccall.  Shard s keeps rows s, s + nshards, ... on
+// device s % (devices): with fewer devices than shards several shards share a device (how the protocol is tested on one GPU).
+// Per round: every shard proposes its election keys, device 0 takes the per-column minimum (all-reduce(MIN)), every shard numbers
+// the pivots and exports the pivot rows it owns, all shards receive the concatenation (all-gather) and build the same U, the Schur
+// rows stay where they are.  Leftmost-entry pivots only in the sharded rounds and in the finish, so the result does not depend on
+// the number of shards.  When little is left, or the remainder is dense enough for the dense finish, the rows are gathered and
+// the single-device engine finishes them on device 0.
+// ------------------------------------------------------------------------------------------------
+struct DeviceGuard {
+    int prev = 0;
+    DeviceGuard() { (void)hipGetDevice(&prev); }
+    ~DeviceGuard() { (void)hipSetDevice(prev); }
+};
+
+struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echelonize_opts *opts, int nshards)
+{
+    struct echelonize_opts dflt;
+    if (!opts) { spasm_echelonize_init_opts(&dflt); opts = &dflt; }
+    require_device();
+    check_input(A, "spasm_amd_echelonize_multi");
+    if (nshards < 1) throw EngineError("spasm_amd_echelonize_multi: at least one shard");
+    if (opts->L) throw EngineError("spasm_amd_echelonize_multi: the L factor is only kept by the single-device rounds");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    const int n = A->n, m = A->m;
+    const i64 prime = A->field->p;
+    const double t0 = spasm_wtime();
+    spasm_logf("[echelonize] Start on %d x %d matrix with %lld nnz, %d row shards on %d device(s)\n", n, m, (long long)spasm_nnz(A), nshards, std::min(ndev, nshards));
+    DeviceGuard guard;
+    auto dev_of = [&](int sh) { return sh % ndev; };
+    // the exchange copies device to device: directly over xGMI where the devices can see each other
+    for (int a = 0; a < std::min(ndev, nshards); a++) {
+        if (hipSetDevice(a) != hipSuccess) continue;
+        for (int b = 0; b < std::min(ndev, nshards); b++) {
+            int can = 0;
+            if (a != b && hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b, 0);
+        }
+    }
+    (void)hipGetLastError(); // ("already enabled" is not an error of ours)
+    struct ShardState {
+        spasm_amd_shard *sh = nullptr;
+        spasm_amd_schur_plan *plan = nullptr;
+        int rows = 0;
+        i64 nnz = 0;
+        int n_own = 0;
+        i64 nnz_own = 0;
+        DevBuf<u64d> keys;
+        DevBuf<int> hdr, ent, hdr_all, ent_all;
+    };
+    std::vector<std::unique_ptr<ShardState>> st((size_t)nshards);
+    auto cleanup = [&]() {
+        for (size_t k = 0; k < st.size(); k++) {
+            ShardState *q = st[k].get();
+            if (!q) continue;
+            (void)hipSetDevice(dev_of((int)k));
+            if (q->plan) delete q->plan;
+            if (q->sh) { delete q->sh->plan; delete q->sh; }
+            q->plan = nullptr;
+            q->sh = nullptr;
+            st[k].reset(); // (its device buffers are released on their device)
+        }
+    };
+    HostU U;
+    U.p.push_back(0);
+    try {
+        for (int k = 0; k < nshards; k++) {
+            HIPCHK(hipSetDevice(dev_of(k)));
+            st[(size_t)k].reset(new ShardState());
+            ShardState &q = *st[(size_t)k];
+            q.sh = shard_create(A, k, n, nshards);
+            for (int g = k; g < n; g += nshards) { const i64 l = A->p[g + 1] - A->p[g]; q.rows += l > 0; q.nnz += l; }
+        }
+        DevBuf<u64d> stage; // on device 0: another shard's keys, on their way into the minimum
+        int round = 0;
+        i64 last_nnz = -1;
+        const i64 finish_nnz = (i64)1 << 22;
+        for (;;) {
+            i64 rows_left = 0, nnz_left = 0;
+            for (auto &q : st) { rows_left += q->rows; nnz_left += q->nnz; }
+            if (nnz_left == 0) break;
+            const i64 free_cols = (i64)m - (i64)U.pivcol.size();
+            const double cells = (double)rows_left * (double)std::max<i64>(free_cols, 1);
+            bool dense_enough = opts->enable_dense && (double)nnz_left > opts->sparsity_threshold * cells;
+            // (one round ahead as well: when the fill keeps growing at the rate of the last round the next Schur complement would
+            // be dense -- it is then never built sparse; the single-device density estimate plays this role there)
+            if (last_nnz > 0 && nnz_left > last_nnz)
+                dense_enough = dense_enough || (opts->enable_dense && (double)nnz_left * ((double)nnz_left / (double)last_nnz) > opts->sparsity_threshold * cells);
+            if (nnz_left <= finish_nnz || round >= opts->max_round || dense_enough) {
+                // ---- hand-off: the remaining rows, under their original numbers, to the single-device engine on device 0
+                std::vector<struct spasm_csr *> parts((size_t)nshards, nullptr);
+                struct spasm_csr *rest = nullptr;
+                struct spasm_lu *fact = nullptr;
+                try {
+                    i64 tot = 0;
+                    for (int k = 0; k < nshards; k++) {
+                        HIPCHK(hipSetDevice(dev_of(k)));
+                        parts[(size_t)k] = shard_fetch(st[(size_t)k]->sh); // one row per local row: local row i = original row k + i * nshards
+                        tot += parts[(size_t)k]->p[parts[(size_t)k]->n];
+                    }
+                    rest = spasm_csr_alloc(n, m, tot, prime, true);
+                    if (!rest) throw EngineError("out of host memory for the remaining rows");
+                    i64 w = 0;
+                    for (int g = 0; g < n; g++) {
+                        const struct spasm_csr *P = parts[(size_t)(g % nshards)];
+                        const int i = g / nshards;
+                        rest->p[g] = w;
+                        const i64 lo = P->p[i], len = P->p[i + 1] - lo;
+                        if (len > 0) {
+                            memcpy(rest->j + w, P->j + lo, sizeof(int) * (size_t)len);
+                            memcpy(rest->x + w, P->x + lo, sizeof(int) * (size_t)len);
+                        }
+                        w += len;
+                    }
+                    rest->p[n] = w;
+                    for (auto &pp : parts) { spasm_csr_free(pp); pp = nullptr; }
+                    HIPCHK(hipSetDevice(dev_of(0)));
+                    struct echelonize_opts fo = *opts;
+                    fo.enable_greedy_pivot_search = false;
+                    fact = do_echelonize(rest, &fo);
+                    const int fr = fact->r;
+                    std::vector<int> colof((size_t)std::max(fr, 1), -1);
+                    for (int j = 0; j < m; j++) if (fact->qinv[j] >= 0) colof[(size_t)fact->qinv[j]] = j;
+                    const i64 base = U.p.back();
+                    for (int k = 0; k < fr; k++) {
+                        U.p.push_back(base + fact->U->p[k + 1]);
+                        U.pivcol.push_back(colof[(size_t)k]);
+                        U.orig.push_back(fact->p[k]);
+                    }
+                    const i64 uz = fact->U->p[fr];
+                    if (uz > 0) {
+                        memcpy(U.j.grow((size_t)uz), fact->U->j, sizeof(int) * (size_t)uz);
+                        memcpy(U.x.grow((size_t)uz), fact->U->x, sizeof(int) * (size_t)uz);
+                    }
+                    spasm_lu_free(fact);
+                    spasm_csr_free(rest);
+                } catch (...) {
+                    for (auto pp : parts) if (pp) spasm_csr_free(pp);
+                    if (rest) spasm_csr_free(rest);
+                    if (fact) spasm_lu_free(fact);
+                    throw;
+                }
+                break;
+            }
+            // ---- election: keys of every shard, minimum on device 0, back to every shard
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                st[(size_t)k]->keys.ensure((size_t)m + 1);
+                shard_elect(st[(size_t)k]->sh, (int64_t *)st[(size_t)k]->keys.p);
+            }
+            HIPCHK(hipSetDevice(dev_of(0)));
+            stage.ensure((size_t)m + 1);
+            for (int k = 1; k < nshards; k++) {
+                HIPCHK(hipMemcpy(stage.p, st[(size_t)k]->keys.p, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice));
+                hipLaunchKernelGGL(k_min_u64, dim3(cdiv(m, 256)), dim3(256), 0, nullptr, (i64d)m, st[0]->keys.p, stage.p);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipDeviceSynchronize());
+            }
+            int npiv = 0;
+            i64 tot_rows = 0, tot_ent = 0;
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                if (k > 0) HIPCHK(hipMemcpy(st[(size_t)k]->keys.p, st[0]->keys.p, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice));
+                ShardState &q = *st[(size_t)k];
+                npiv = shard_set_keys(q.sh, (const int64_t *)q.keys.p, &q.n_own, &q.nnz_own);
+                tot_rows += q.n_own;
+                tot_ent += q.nnz_own;
+            }
+            if (npiv == 0) break;
+            if (tot_rows != npiv) throw EngineError("spasm_amd_echelonize_multi: the shards do not own the elected pivot rows between them");
+            // ---- exchange: every shard exports what it owns; every shard receives the concatenation
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                ShardState &q = *st[(size_t)k];
+                q.hdr.ensure((size_t)2 * (size_t)std::max(q.n_own, 1));
+                q.ent.ensure((size_t)2 * (size_t)std::max<i64>(q.nnz_own, 1));
+                shard_export(q.sh, q.hdr.p, q.ent.p);
+            }
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                ShardState &q = *st[(size_t)k];
+                q.hdr_all.ensure((size_t)2 * (size_t)std::max(npiv, 1));
+                q.ent_all.ensure((size_t)2 * (size_t)std::max<i64>(tot_ent, 1));
+                i64 hr = 0, he = 0;
+                for (int src = 0; src < nshards; src++) {
+                    const ShardState &o = *st[(size_t)src];
+                    if (o.n_own > 0) HIPCHK(hipMemcpy(q.hdr_all.p + 2 * hr, o.hdr.p, (size_t)2 * (size_t)o.n_own * sizeof(int), hipMemcpyDeviceToDevice));
+                    if (o.nnz_own > 0) HIPCHK(hipMemcpy(q.ent_all.p + 2 * he, o.ent.p, (size_t)2 * (size_t)o.nnz_own * sizeof(int), hipMemcpyDeviceToDevice));
+                    hr += o.n_own;
+                    he += o.nnz_own;
+                }
+            }
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                ShardState &q = *st[(size_t)k];
+                spasm_amd_shard *sh = q.sh;
+                q.plan = shard_import(sh, npiv, tot_ent, q.hdr_all.p, q.ent_all.p); // (the shard hands its matrix to the plan)
+                q.sh = nullptr;
+                delete sh;
+            }
+            // ---- the round's rows of U, from shard 0 (identical on all)
+            {
+                HIPCHK(hipSetDevice(dev_of(0)));
+                std::vector<int> pc((size_t)npiv), ro((size_t)npiv);
+                struct spasm_csr *Uc = plan_fetch_U(st[0]->plan, pc.data(), ro.data());
+                const i64 base = U.p.back();
+                for (int k = 0; k < npiv; k++) {
+                    U.p.push_back(base + Uc->p[k + 1]);
+                    U.pivcol.push_back(pc[(size_t)k]);
+                    U.orig.push_back(ro[(size_t)k]);
+                }
+                const i64 uz = Uc->p[npiv];
+                if (uz > 0) {
+                    memcpy(U.j.grow((size_t)uz), Uc->j, sizeof(int) * (size_t)uz);
+                    memcpy(U.x.grow((size_t)uz), Uc->x, sizeof(int) * (size_t)uz);
+                }
+                spasm_csr_free(Uc);
+            }
+            // ---- the Schur complement of every shard's rows becomes its matrix of the next round, on its device
+            last_nnz = nnz_left;
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                ShardState &q = *st[(size_t)k];
+                spasm_amd_schur_plan *P = q.plan;
+                q.plan = nullptr; // consumed by the call, whatever happens
+                q.sh = plan_advance(P, &q.rows, &q.nnz);
+            }
+            spasm_logf("[echelonize] round %d (sharded): %d pivots, %lld rows / %lld entries before it\n", round, npiv, (long long)rows_left, (long long)nnz_left);
+            round++;
+        }
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+    struct spasm_lu *N = assemble_lu(U, n, m, prime, nullptr);
+    spasm_logf("[echelonize] Done in %.1fs. Rank %d, %lld nz in basis\n", spasm_wtime() - t0, N->r, (long long)U.p.back());
+    return N;
+}
+
 } // namespace
 
 // ================================================================================================
 // C ABI
 // ================================================================================================
+
 extern "C" {
 
 SPASM_API int spasm_amd_device_count(void)
@@ -3568,6 +3832,19 @@ SPASM_API int spasm_amd_set_device(int dev)
 {
     if (hipSetDevice(dev) != hipSuccess) { spasm_set_error("hipSetDevice(%d) failed", dev); return 1; }
     return 0;
+}
+
+// engine extension of spasm_echelonize (reference src/SpaSM.jl:863): the same result from `nshards` row shards on the devices of
+// this process (include/spasm_amd.h)
+SPASM_API struct spasm_lu *spasm_amd_echelonize_multi(const struct spasm_csr *A, struct echelonize_opts *opts, int nshards)
+{
+    spasm_clear_error();
+    try {
+        return do_echelonize_multi(A, opts, nshards);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_echelonize_multi: %s", e.what());
+        return nullptr;
+    }
 }
 
 // reference src/SpaSM.jl:863

@@ -219,6 +219,13 @@ __global__ void k_elect(int n, int row_base, int row_stride, const int *__restri
     atomicMin(&best[lead[i]], ((u64d)(unsigned)ln << 32) | (u64d)(unsigned)(row_base + i * row_stride));
 }
 
+// election keys of two shards merged: per column the smaller (row length << 32 | row) key wins (what all-reduce(MIN) does between processes)
+__global__ void k_min_u64(i64d n, u64d *__restrict__ dst, const u64d *__restrict__ src)
+{
+    const i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const u64d a = dst[i], b = src[i]; dst[i] = b < a ? b : a; }
+}
+
 __global__ void k_fill_u64(i64d n, u64d v, u64d *__restrict__ out)
 {
     i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x;

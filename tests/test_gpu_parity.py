@@ -839,3 +839,18 @@ def test_explicit_zero_entries_are_dropped_at_ingest(S, O):
     assert got.r == clean.r and np.asarray(got.qinv >= 0).tolist() == np.asarray(clean.qinv >= 0).tolist()
     assert S.kernel(got).rows() == Kc
     assert S.factorization_verify(A, got, 3)
+
+
+@pytest.mark.gpu
+def test_enable_gplu_off_without_a_dense_finish_stops_short(S, O):
+    """echelonize_opts.enable_GPLU = 0 (reference src/SpaSM.jl:330) with the dense finish off leaves no method to finish with: like
+    libspasm the engine returns what the sparse rounds found -- r is then a lower bound of the rank and U a partial echelon form
+    whose rows lie in the row space of A; with GPLU on (the default) the same options finish."""
+    A = S.synth_csr(1, 3000, 3000, row_nnz=6, prime=65521, seed=0x6F1)
+    full = S.echelonize(A, enable_dense=False, **LM)
+    short = S.echelonize(A, enable_dense=False, enable_GPLU=False, max_round=2, **LM)
+    assert 0 < short.r < full.r == O.echelonize(A, **LM).r
+    assert not S.factorization_verify(A, short, 1) and S.factorization_verify(A, full, 1)
+    # the rows it has are rows of a correct echelon form: the same pivot columns as the full run's first rows
+    k = short.r
+    assert short.U.rows() == full.U.rows()[:k]

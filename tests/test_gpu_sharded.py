@@ -151,3 +151,27 @@ def test_echelonize_sharded_matches_single_device(S, O, world, kind, n, m, kw, p
     assert shard_rounds == [rr["npiv"] for rr in ref_rounds[: len(shard_rounds)]]
     k = sum(shard_rounds)
     assert results[0][4][:k] == ref.U.rows()[:k]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,m,kw,prime,nshards", [
+    (1, 6000, 6000, dict(row_nnz=5), 65521, 2),
+    (1, 6000, 6000, dict(row_nnz=5), 65521, 3),
+    (0, 1500, 2000, dict(density=0.004), 0xFFFFFFFB, 4),
+    (2, 5000, 2000, dict(row_nnz=30), 127, 2),
+    (1, 300, 300, dict(row_nnz=4), 42013, 8),
+])
+def test_echelonize_multi_in_one_process_matches_the_single_device_result(S, O, kind, n, m, kw, prime, nshards):
+    """spasm_amd_echelonize_multi (the C-ABI entry a Julia host reaches all GPUs of a node through): row shards of ONE process,
+    election minimum + peer copies instead of the collectives.  On this one-GPU box the shards share the device; the protocol is
+    the same.  Leftmost pivots throughout, so rank, pivot columns and kernel equal the single-device leftmost-pivot run's."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0x3417, **kw)
+    ref = S.echelonize(A, **LM)
+    got = S.echelonize_multi(A, nshards)
+    assert got.r == ref.r
+    assert np.asarray(got.qinv >= 0).tolist() == np.asarray(ref.qinv >= 0).tolist()
+    assert S.factorization_verify(A, got, 5)
+    assert S.kernel(got).rows() == S.kernel(ref).rows()
+    # pivotal rows first in p, each once
+    p = np.asarray(got.p)[: got.r]
+    assert len(set(p.tolist())) == got.r and (p >= 0).all() and (p < n).all()
