@@ -34,7 +34,7 @@ SCATTER_KERNEL_PREFIX = ["k_scatter<8,", "k_scatter<9,", "k_scatter<10,", "k_sca
                          "k_scatter<14,", None]
 # streaming twin of class c (stats classes 8 .. 14): k_wstream<LOGT = 8 + c, ...>
 STREAM_KERNEL_PREFIX = [f"k_wstream<{8 + c}," for c in range(7)]
-TRAFFIC_FILES = ["r02_final_traffic.json", "r01_final_traffic.json"]  # newest first: PMC passes of tools/final_profile.sh
+TRAFFIC_FILES = ["r03_final_traffic.json", "r02_final_traffic.json", "r01_final_traffic.json"]  # newest first: PMC passes of tools/final_profile.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -234,12 +234,12 @@ def main():
         if traffic is not None:
             # the kernels every step launches once (streaming classes, plan, fix-ups, binning); the hash-table and combine kernels
             # only see the few rows handed back, and their per-dispatch means in the profile include the building of W
-            step_kernels = ("k_wstream<", "k_wplan<", "k_stream_fix", "k_bin")
+            step_kernels = ("k_wlevel", "k_wstream<", "k_wplan<", "k_stream_fix", "k_bin")
             try:
-                fetch = sum(v["fetch_bytes"] for k, v in prof.items() if k.startswith(step_kernels))
-                write = sum(v["write_bytes"] for k, v in prof.items() if k.startswith(step_kernels))
+                fetch = sum(v.get("fetch_bytes_per_step") or v["fetch_bytes"] for k, v in prof.items() if k.startswith(step_kernels))
+                write = sum(v.get("write_bytes_per_step") or v["write_bytes"] for k, v in prof.items() if k.startswith(step_kernels))
                 roofline["round_traffic"] = {"fetch_bytes": fetch, "write_bytes": write, "source": tf,
-                                             "kernels": "k_wstream x7 + k_wplan + k_stream_fix + k_bin (PMC, mean per dispatch)",
+                                             "kernels": "k_wlevel* (W build) + k_wplan + k_bin + k_wstream x7 + k_stream_fix (PMC, summed over the launches of one step)",
                                              "fetch_over_algorithmic_read": round(fetch / d["read_bytes"], 3) if d["read_bytes"] else None}
             except Exception:
                 pass

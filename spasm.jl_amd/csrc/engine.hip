@@ -767,16 +767,22 @@ struct Round {
         hipLaunchKernelGGL(k_wbuild_reset, dim3(cdiv(std::max(nblk_words, ncount_words), 256)), dim3(256), 0, stream, wstate.p, wblk.p, nblk_words,
                            wbig_count.p, ncount_words, (u64d)lev0_total);
         HIPCHK(hipGetLastError());
-        const size_t lds_mid = F.small ? wl_wg_lds_bytes<true>(wl_mid_slots()) : wl_wg_lds_bytes<false>(wl_mid_slots());
+        constexpr int NT_MID = 256, NT_BIG = 1024; // (512 threads for the medium table were slower: its rows wait on memory, and fewer workgroups fit a CU)
+        const size_t lds_mid = F.small ? wl_wg_lds_bytes<true>(wl_mid_slots(), NT_MID) : wl_wg_lds_bytes<false>(wl_mid_slots(), NT_MID);
         const int big_slots = F.small ? wl_big_slots<true>() : wl_big_slots<false>();
-        const size_t lds_big = F.small ? wl_wg_lds_bytes<true>(big_slots) : wl_wg_lds_bytes<false>(big_slots);
+        const size_t lds_big = F.small ? wl_wg_lds_bytes<true>(big_slots, NT_BIG) : wl_wg_lds_bytes<false>(big_slots, NT_BIG);
         if (!wave_per_cu_blocks) {
             int nb = 0;
             if (F.small) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wlevel_wave<true>, 256, 0));
             else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wlevel_wave<false>, 256, 0));
             wave_per_cu_blocks = std::min(std::max(nb, 1), 16);
-            if (F.small) HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-            else HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+            if (F.small) {
+                HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<true, NT_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+                HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<true, NT_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+            } else {
+                HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<false, NT_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+                HIPCHK(hipFuncSetAttribute((const void *)k_wlevel_wg<false, NT_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+            }
         }
         const int mid_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds_mid + 256)));
         WLevelArgs a;
@@ -794,9 +800,13 @@ struct Round {
         auto launch_wg = [&](int tier, int grid) {
             a.tslots = tier ? big_slots : wl_mid_slots();
             a.blk_base = num_cu * 16 * 4 + (tier ? num_cu * 8 : 0);
-            const size_t lds = tier ? lds_big : lds_mid;
-            if (F.small) hipLaunchKernelGGL(k_wlevel_wg<true>, dim3(grid), dim3(256), lds, stream, a);
-            else hipLaunchKernelGGL(k_wlevel_wg<false>, dim3(grid), dim3(256), lds, stream, a);
+            if (tier) {
+                if (F.small) hipLaunchKernelGGL((k_wlevel_wg<true, NT_BIG>), dim3(grid), dim3(NT_BIG), lds_big, stream, a);
+                else hipLaunchKernelGGL((k_wlevel_wg<false, NT_BIG>), dim3(grid), dim3(NT_BIG), lds_big, stream, a);
+            } else {
+                if (F.small) hipLaunchKernelGGL((k_wlevel_wg<true, NT_MID>), dim3(grid), dim3(NT_MID), lds_mid, stream, a);
+                else hipLaunchKernelGGL((k_wlevel_wg<false, NT_MID>), dim3(grid), dim3(NT_MID), lds_mid, stream, a);
+            }
         };
         {
             const int cnt0 = lev_start[1];

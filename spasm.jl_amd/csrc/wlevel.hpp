@@ -23,7 +23,6 @@ constexpr int WL_WAVE_BOUND = WL_TMAX / 2;      // longest bound a wave takes (t
 constexpr int WL_NCD = 64;                      // chunk descriptors of a wave
 constexpr u64d WL_BLK = 4096;                   // entries a wave / workgroup takes from the cursor at a time (one returning atomic on
                                                 // one word costs ~11 ns of that word's time: 170 000 rows must not queue there)
-constexpr int WL_WG_NCD = 512;                  // chunk descriptors of a workgroup batch (256 dependencies + the longest bound / 64)
 constexpr int WL_NSUB = 64;                     // the lists of rows left to the workgroup kernels are kept in 64 parts with a counter each
 constexpr int WL_SUBSTRIDE = 32;                // (ints between two counters: a line of their own; thousands of appends to ONE word
                                                 // serialise at ~11 ns each -- they were most of the wave kernel's time on the middle levels)
@@ -210,9 +209,9 @@ __device__ __forceinline__ bool wl_insert_n(int *key, typename ZpAcc<SMALL>::typ
     return pending == 0;
 }
 
-// the chunks [t0, t0 + 4), [t0 + tstep, ...) .. of a descriptor list in LDS: up to 64 consecutive entries each, multiplied and
-// accumulated; the loads of a group of 4 are in flight together
-template <bool SMALL>
+// the chunks [t0, t0 + G), [t0 + tstep, ...) .. of a descriptor list in LDS: up to 64 consecutive entries each, multiplied and
+// accumulated; the loads of a group of G = 8 are in flight together (a row of a few hundred entries costs ONE round trip here)
+template <bool SMALL, int G = 8>
 __device__ __forceinline__ bool wl_consume(lds_vint *cd_off, lds_vint *cd_len, lds_vint *cd_mul, int C, int t0, int tstep, const int2 *buf, int *key,
                                            typename ZpAcc<SMALL>::type *val, unsigned mask, int shift, const ZpField &F)
 {
@@ -220,26 +219,30 @@ __device__ __forceinline__ bool wl_consume(lds_vint *cd_off, lds_vint *cd_len, l
     const int lane = threadIdx.x & 63;
     bool ok = true;
     for (int g0 = t0; g0 < C; g0 += tstep) {
-        int2 e[4];
-        int cl[4], cm[4];
+        int2 e[G];
+        int cl[G], cm[G];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < G; u++) {
             const int t = min(g0 + u, C - 1);
             const unsigned co = (unsigned)cd_off[t];
             cl[u] = g0 + u < C ? cd_len[t] : 0;
             cm[u] = cd_mul[t];
             e[u] = buf[(size_t)co + (unsigned)min(lane, max(cl[u] - 1, 0))]; // unconditional, clamped into the chunk
         }
-        int cc[4];
-        Acc vv[4];
-        unsigned pend = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            cc[u] = e[u].x;
-            vv[u] = ZpAcc<SMALL>::mul_lazy(F, cm[u], e[u].y);
-            if (lane < cl[u]) pend |= 1u << u;
+        for (int h = 0; h < G; h += 4) {
+            if (g0 + h >= C) break; // (uniform)
+            int cc[4];
+            Acc vv[4];
+            unsigned pend = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                cc[u] = e[h + u].x;
+                vv[u] = ZpAcc<SMALL>::mul_lazy(F, cm[h + u], e[h + u].y);
+                if (lane < cl[h + u]) pend |= 1u << u;
+            }
+            ok &= wl_insert_n<SMALL, 4>(key, val, mask, shift, cc, vv, pend);
         }
-        ok &= wl_insert_n<SMALL, 4>(key, val, mask, shift, cc, vv, pend);
     }
     return ok;
 }
@@ -297,9 +300,11 @@ __device__ __forceinline__ WlRecRegs wl_rec_load(const WLevRec *p)
 constexpr int WL_MID_BOUND = 2048;   // rows up to this bound go to the workgroup kernel with 4096 slots (four workgroups per CU)
 template <bool SMALL> constexpr int wl_big_slots() { return SMALL ? 16384 : 8192; }
 constexpr int wl_mid_slots() { return 2 * WL_MID_BOUND; }
-template <bool SMALL> constexpr size_t wl_wg_lds_bytes(int slots)
+// chunk descriptors of a workgroup batch: NT dependencies at a time + the longest bound / 64
+constexpr int wl_wg_ncd(int nt) { return nt + 256; }
+template <bool SMALL> constexpr size_t wl_wg_lds_bytes(int slots, int nt)
 {
-    return (size_t)slots * (sizeof(typename ZpAcc<SMALL>::type) + 4) + (size_t)3 * WL_WG_NCD * 4 + 64;
+    return (size_t)slots * (sizeof(typename ZpAcc<SMALL>::type) + 4) + (size_t)3 * wl_wg_ncd(nt) * 4 + 256;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
                         const Acc vv[1] = {(Acc)(-O0.y)};
                         ok &= wl_insert_n<SMALL, 1>(key, val, mask, 32 - logt, cc, vv, lane < npn ? 1u : 0u);
                     }
-                    ok &= wl_consume<SMALL>(cd_off, cd_len, cd_mul, C, 0, 4, a.buf, key, val, mask, 32 - logt, F);
+                    ok &= wl_consume<SMALL>(cd_off, cd_len, cd_mul, C, 0, 8, a.buf, key, val, mask, 32 - logt, F);
                     if (__ballot(!ok) != 0) c_err++;
                     __builtin_amdgcn_wave_barrier();
                     // sweep: count, take the space, write
@@ -467,16 +472,19 @@ __global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
 // the long rows of a level, a workgroup per row: a table of a.tslots slots in dynamic LDS (4096: four workgroups per CU; or all
 // a CU has).  The next row's record and its first 256 dependencies are fetched while this one is worked on.
 // ------------------------------------------------------------------------------------------------
-template <bool SMALL>
-__global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
+// NT threads per workgroup: 1024 with the largest table (one workgroup per CU whatever its size), 512 with the medium one (four
+// per CU): clearing, filling and sweeping a table of thousands of slots is most of a long row's time, and it divides by the waves
+template <bool SMALL, int NT>
+__global__ __launch_bounds__(NT) void k_wlevel_wg(WLevelArgs a)
 {
+    constexpr int NW = NT / 64, WL_WG_NCD = wl_wg_ncd(NT);
     typedef typename ZpAcc<SMALL>::type Acc;
     const int TB = a.tslots;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     Acc *val = (Acc *)s_raw;
     int *key = (int *)(s_raw + sizeof(Acc) * (size_t)TB);
     lds_vint *cd_off = (lds_vint *)(key + TB), *cd_len = cd_off + WL_WG_NCD, *cd_mul = cd_len + WL_WG_NCD;
-    lds_vint *s_misc = cd_mul + WL_WG_NCD; // 16 words
+    lds_vint *s_misc = cd_mul + WL_WG_NCD; // 64 words: [0, 16) per-wave sums, [16, 32) per-wave flags, [32, 48) per-wave chunk counts, [48, 50) the allocation
     // its rows: a list the wave kernel (or this kernel with the medium table) left, or -- levels of few rows, which skip the wave
     // kernel -- all cnt rows of the level
     const int tid = threadIdx.x, lane = tid & 63;
@@ -508,15 +516,16 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
         return a.list[(size_t)s0 * a.list_stride + (i - s_pre[s0])];
     };
     auto rec_of = [&](int i) { return wl_rec_load(a.recs + row_of(i)); };
-    auto dep_load = [&](const WlRecRegs &r) { return a.UPP[(size_t)(unsigned)r.a.y + (unsigned)min(tid, max(min(r.a.z, 256) - 1, 0))]; };
-    auto wr_load = [&](const WlRecRegs &r, const int2 &d) { return a.wrow[tid < min(r.a.z, 256) ? d.x : 0]; };
+    auto dep_load = [&](const WlRecRegs &r) { return a.UPP[(size_t)(unsigned)r.a.y + (unsigned)min(tid, max(min(r.a.z, NT) - 1, 0))]; };
+    auto wr_load = [&](const WlRecRegs &r, const int2 &d) { return a.wrow[tid < min(r.a.z, NT) ? d.x : 0]; };
+    auto own_load = [&](const WlRecRegs &r) { return a.buf[(size_t)(unsigned)r.a.y + (unsigned)min(tid, max(min(r.a.w, NT) - 1, 0))]; };
     u64d bpos = a.wblk[2 * (a.blk_base + (int)blockIdx.x)], bend = a.wblk[2 * (a.blk_base + (int)blockIdx.x) + 1]; // (used by thread 0)
     WlRecRegs R0 = rec_of(blockIdx.x), R1 = rec_of(blockIdx.x + stride);
-    int2 D0 = dep_load(R0);
+    int2 D0 = dep_load(R0), O0 = own_load(R0);
     int2 W0 = wr_load(R0, D0);
     for (int i = blockIdx.x; i < nrows; i += stride) {
         const WlRecRegs R2 = rec_of(i + 2 * stride);
-        const int2 D1 = dep_load(R1);
+        const int2 D1 = dep_load(R1), O1 = own_load(R1);
         const int q = __builtin_amdgcn_readfirstlane(R0.a.x);
         const unsigned uo = (unsigned)__builtin_amdgcn_readfirstlane(R0.a.y);
         const int npp = __builtin_amdgcn_readfirstlane(R0.a.z), npn = __builtin_amdgcn_readfirstlane(R0.a.w);
@@ -524,8 +533,8 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
         // ---- bound of the row, and whether every row it needs is there
         long long mylen = 0;
         bool un = false;
-        if (tid < min(npp, 256)) { un = W0.y < 0; mylen = max(W0.y, 0); }
-        for (int k = 256 + tid; k < npp; k += 256) {
+        if (tid < min(npp, NT)) { un = W0.y < 0; mylen = max(W0.y, 0); }
+        for (int k = NT + tid; k < npp; k += NT) {
             const int2 d = a.UPP[(size_t)uo + k];
             const int2 wr = a.wrow[d.x];
             un |= wr.y < 0;
@@ -533,11 +542,11 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
         }
         for (int o = 32; o > 0; o >>= 1) mylen += __shfl_xor(mylen, o);
         const bool wun = __ballot(un) != 0;
-        if (lane == 0) { s_misc[wave] = (int)min(mylen, (long long)(INT_MAX / 8)); s_misc[4 + wave] = wun ? 1 : 0; }
+        if (lane == 0) { s_misc[wave] = (int)min(mylen, (long long)(INT_MAX / 32)); s_misc[16 + wave] = wun ? 1 : 0; }
         __syncthreads();
         long long bound = npn;
         bool unavail = false;
-        for (int w2 = 0; w2 < 4; w2++) { bound += s_misc[w2]; unavail |= s_misc[4 + w2] != 0; }
+        for (int w2 = 0; w2 < NW; w2++) { bound += s_misc[w2]; unavail |= s_misc[16 + w2] != 0; }
         bool avail = !unavail && bound <= TB / 2;
         unsigned out_off = 0;
         int n_out = 0;
@@ -548,6 +557,7 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
             R0 = R1; R1 = R2;
             W0 = wr_load(R0, D1);
             D0 = D1;
+            O0 = O1;
             continue;
         }
         if (avail) { // (uniform over the workgroup)
@@ -556,18 +566,18 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
             const int T = 1 << logt;
             const unsigned mask = (unsigned)T - 1u;
             const int shift = 32 - logt;
-            for (int s = tid; s < T; s += 256) { key[s] = EMPTY_KEY; val[s] = 0; }
+            for (int s = tid; s < T; s += NT) { key[s] = EMPTY_KEY; val[s] = 0; }
             __syncthreads();
             bool ok = true;
-            // the row's own entries on non-pivot columns
-            for (int k = tid; k < npn; k += 256) {
-                const int2 e = a.buf[(size_t)uo + k];
+            // the row's own entries on non-pivot columns (the first NT were fetched with the record)
+            for (int k = tid; k < npn; k += NT) {
+                const int2 e = k < NT ? O0 : a.buf[(size_t)uo + k];
                 const int cc[1] = {e.x};
                 const Acc vv[1] = {(Acc)(-e.y)};
                 ok &= wl_insert_n<SMALL, 1>(key, val, mask, shift, cc, vv, 1u);
             }
-            // its dependencies, 256 at a time: their runs become chunks, the waves take groups of 4 chunks in turn
-            for (int b0 = 0; b0 < npp; b0 += 256) {
+            // its dependencies, NT at a time: their runs become chunks, the waves take groups of 8 chunks in turn
+            for (int b0 = 0; b0 < npp; b0 += NT) {
                 int2 d = make_int2(0, 0), wr = make_int2(0, 0);
                 if (b0 == 0) { if (tid < npp) { d = D0; wr = W0; } }
                 else if (b0 + tid < npp) {
@@ -578,11 +588,11 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
                 int wtot;
                 const int incl = team_incl_scan<64>(nch, wtot);
                 __syncthreads(); // (the chunks of the batch before are consumed)
-                if (lane == 0) s_misc[8 + wave] = wtot;
+                if (lane == 0) s_misc[32 + wave] = wtot;
                 __syncthreads();
                 int cbase = 0, Cb = 0;
-                for (int w2 = 0; w2 < 4; w2++) {
-                    const int cw = s_misc[8 + w2];
+                for (int w2 = 0; w2 < NW; w2++) {
+                    const int cw = s_misc[32 + w2];
                     if (w2 < wave) cbase += cw;
                     Cb += cw;
                 }
@@ -594,12 +604,12 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
                     cd_mul[at + r] = nm;
                 }
                 __syncthreads();
-                ok &= wl_consume<SMALL>(cd_off, cd_len, cd_mul, Cb, wave * 4, 16, a.buf, key, val, mask, shift, F);
+                ok &= wl_consume<SMALL>(cd_off, cd_len, cd_mul, Cb, wave * 8, NW * 8, a.buf, key, val, mask, shift, F);
             }
             __syncthreads();
-            // sweep: wave w owns the slots it * 256 + w * 64 + lane
+            // sweep: wave w owns the slots it * NT + w * 64 + lane
             int tot = 0;
-            for (int s0 = wave * 64; s0 < T; s0 += 256) {
+            for (int s0 = wave * 64; s0 < T; s0 += NT) {
                 const int k = key[s0 + lane];
                 const int r = k == EMPTY_KEY ? 0 : acc_reduce_short<SMALL>(F, val[s0 + lane]);
                 tot += __popcll(__ballot(r != 0));
@@ -608,7 +618,7 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
             if (lane == 0) { s_misc[wave] = tot; if (!wok) atomicAdd(a.wstate + WS_ERROR, 1ull); }
             __syncthreads();
             int pre = 0;
-            for (int w2 = 0; w2 < 4; w2++) {
+            for (int w2 = 0; w2 < NW; w2++) {
                 const int cw = s_misc[w2];
                 if (w2 < wave) pre += cw;
                 n_out += cw;
@@ -629,15 +639,15 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
                     }
                     if (fits) { b = bpos; bpos += n; }
                 }
-                s_misc[12] = fits ? 1 : 0;
-                s_misc[13] = (int)(unsigned)b;
+                s_misc[48] = fits ? 1 : 0;
+                s_misc[49] = (int)(unsigned)b;
             }
             __syncthreads();
-            avail = s_misc[12] != 0;
+            avail = s_misc[48] != 0;
             if (avail) {
-                out_off = a.wbase + (unsigned)s_misc[13];
+                out_off = a.wbase + (unsigned)s_misc[49];
                 int pos = pre;
-                for (int s0 = wave * 64; s0 < T; s0 += 256) {
+                for (int s0 = wave * 64; s0 < T; s0 += NT) {
                     const int k = key[s0 + lane];
                     const int r = k == EMPTY_KEY ? 0 : acc_reduce_short<SMALL>(F, val[s0 + lane]);
                     const u64d mm = __ballot(r != 0);
@@ -659,6 +669,7 @@ __global__ __launch_bounds__(256) void k_wlevel_wg(WLevelArgs a)
         R0 = R1; R1 = R2;
         W0 = wr_load(R0, D1);
         D0 = D1;
+        O0 = O1;
     }
     if (tid == 0) {
         a.wblk[2 * (a.blk_base + (int)blockIdx.x)] = bpos;

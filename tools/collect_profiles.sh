@@ -9,5 +9,5 @@ cp "$(ls -t gpurun_out/final/calib_WRITE_SIZE/*/*_counter_collection.csv | head 
 cp gpurun_out/final/shard_time.txt profiles/${tag}_shard_time.txt
 [ -f gpurun_out/final/ablate_scatter.txt ] && cp gpurun_out/final/ablate_scatter.txt profiles/${tag}_ablations_scatter.txt
 [ -f gpurun_out/final/ablate_combine.txt ] && cp gpurun_out/final/ablate_combine.txt profiles/${tag}_ablations_combine.txt
-for k in 'k_wstream<10' 'k_wstream<11' 'k_wstream<12' 'k_wplan' 'k_scatter<13' 'k_combine<16'; do echo "== $k (mean per dispatch)"; python tools/pmc_show.py gpurun_out/pmc_final "$k"; done > profiles/${tag}_instruction_mix.txt
+for k in 'k_wstream<10' 'k_wstream<11' 'k_wstream<12' 'k_wplan' 'k_wlevel_wave' 'k_wlevel_wg' 'k_scatter<13'; do echo "== $k (mean per dispatch)"; python tools/pmc_show.py gpurun_out/pmc_final "$k"; done > profiles/${tag}_instruction_mix.txt
 ls -la profiles | grep ${tag}

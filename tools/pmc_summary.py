@@ -35,11 +35,19 @@ def main():
     mean = lambda v: sum(v) / len(v) if v else 0.0
     kernels = {}
     for k in sorted(fetch):
-        if not k.startswith(("k_scatter", "k_combine", "k_bin", "k_solve", "k_wstream", "k_wplan", "k_stream_fix")):
+        if not k.startswith(("k_scatter", "k_combine", "k_bin", "k_solve", "k_wstream", "k_wplan", "k_stream_fix", "k_wlevel", "k_wbuild")):
             continue
         hit, miss = mean(tcc.get("TCC_HIT_sum", {}).get(k, [])), mean(tcc.get("TCC_MISS_sum", {}).get(k, []))
+        # per Schur step: a kernel launched several times per step (the level kernels of the W build: one launch per level) is
+        # summed over its launches and divided by the number of steps of the run -- the builds (launches of k_wbuild_reset,
+        # the first one at plan creation); the kernels of the plan and the scatter are launched once per step: their mean per dispatch
+        multi = k.startswith(("k_wlevel", "k_wbuild"))
+        fsteps = len(fetch.get("k_wbuild_reset", [])) if multi else len(fetch[k])
+        wsteps = len(write.get("k_wbuild_reset", [])) if multi else len(write.get(k, []))
         kernels[k] = {
             "dispatches": len(fetch[k]),
+            "fetch_bytes_per_step": int(sum(fetch[k]) * 1024 / fsteps) if fsteps else None,
+            "write_bytes_per_step": int(sum(write.get(k, [])) * 1024 / wsteps) if wsteps else None,
             "fetch_bytes": int(mean(fetch[k]) * 1024),
             "write_bytes": int(mean(write.get(k, [])) * 1024),
             "l2_hit_rate": round(hit / (hit + miss), 3) if hit + miss > 0 else None,
