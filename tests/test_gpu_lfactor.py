@@ -37,7 +37,7 @@ CASES = [
 @pytest.mark.parametrize("name,kind,n,m,kw,prime,opts", CASES, ids=[c[0] for c in CASES])
 def test_L_times_U_is_A(S, O, name, kind, n, m, kw, prime, opts):
     A = S.synth_csr(kind, n, m, prime=prime, seed=0x1FAC, **kw)
-    fact = S.echelonize(A, L=True, **opts, **LM)
+    fact = S.echelonize(A, L=True, **{**LM, **opts})
     olu = O.echelonize(A, **LM)
     assert fact.r == olu.r
     L, U = fact.L, fact.U
@@ -53,7 +53,7 @@ def test_L_times_U_is_A(S, O, name, kind, n, m, kw, prime, opts):
     for sd in (0, 1, 2):
         assert S.factorization_verify(A, fact, sd)
     # the kernel does not depend on whether L was kept
-    plain = S.echelonize(A, enable_dense=False, **opts, **LM)
+    plain = S.echelonize(A, enable_dense=False, **{**LM, **opts})
     assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(plain.qinv >= 0).tolist()
     assert S.kernel(fact).rows() == S.kernel(plain).rows()
 
