@@ -854,3 +854,43 @@ def test_enable_gplu_off_without_a_dense_finish_stops_short(S, O):
     # the rows it has are rows of a correct echelon form: the same pivot columns as the full run's first rows
     k = short.r
     assert short.U.rows() == full.U.rows()[:k]
+
+
+@pytest.mark.parametrize("p", [65521, 0xFFFFFFFB], ids=["small_prime", "large_prime"])
+def test_schur_round_w_build_long_dependency_lists(S, O, p):
+    """The corners of the level-wise W build (csrc/wlevel.hpp) that random sparse matrices never reach: pivot rows with more than 64
+    entries on other pivot columns (left by the wave kernel to the workgroup kernel with the largest table), with more than 1024 of
+    them (that kernel takes its dependencies in batches), and one whose row of W exceeds the largest table -- published as not
+    available, so the rows that need it go through the multiplier lists.  Two levels, the second large enough to go through the
+    wave kernel; the Schur complement must still be the oracle's, entry for entry."""
+    rng = np.random.default_rng(11)
+    n0, n1, m = 1500, 2100, 9000        # level-0 pivots on columns n1 .. n1 + n0 - 1, level-1 pivots on columns 0 .. n1 - 1
+    val = lambda: int(rng.integers(1, min(p, 1 << 31)))  # noqa: E731
+    free = lambda k: sorted(set(int(x) for x in rng.integers(n1 + n0, m, size=k)))  # noqa: E731
+    rows = []
+    for i in range(n0):                 # level 0: the pivot, then 10 entries on columns without a pivot
+        rows.append([(n1 + i, val())] + [(c, val()) for c in free(10)])
+    for k in range(n1):                 # level 1: the pivot, level-0 pivot columns (a few, ~90, ~300, or all 1500), a few free columns
+        if k == 0:
+            deps = list(range(n1, n1 + n0))
+        else:
+            many = 1100 if p < 65536 else 350   # (12-byte slots for the large primes: the largest table holds 4096 entries, not 8192)
+            ndep = (3, 90, 300, many)[k % 4] if k % 50 else many
+            deps = sorted(set(int(x) for x in rng.integers(n1, n1 + n0, size=ndep)))
+        rows.append([(k, val())] + [(c, val()) for c in deps] + [(c, val()) for c in free(5)])
+    npiv = n0 + n1
+    for t in range(2 * npiv + 50):      # rows to reduce: longer than the pivot row of their leftmost column
+        if t % 7 == 0:                  # enters at a level-1 pivot: needs ITS row of W (pivot 0's is not available: 1500 x 10 entries)
+            c0 = (t // 7) % n1
+            cols = sorted(set([c0] + [int(x) for x in rng.integers(n1, n1 + n0, size=1200)] + free(400)))
+        else:
+            c0 = n1 + int(rng.integers(0, n0))
+            cols = sorted(set([c0] + [int(x) for x in rng.integers(c0, n1 + n0, size=3)] + free(12)))
+        rows.append([(c, val()) for c in cols])
+    A = S.CSR.from_rows(rows, m, prime=p)
+    Sc, st, p_out = run_plan(S, A)
+    So, info = O.schur_round(A)
+    assert st["npiv"] == info["npiv"] == npiv
+    assert st["w_levels"] == 2 and st["w_long_rows"] > n1 // 3, (st["w_levels"], st["w_long_rows"])
+    assert st["applications"] == info["applications"] and st["nnz_reduced"] == info["nnz_reduced"] and st["nnz_out"] == info["nnz_out"]
+    assert Sc.rows() == So.rows()
