@@ -270,6 +270,79 @@ __global__ __launch_bounds__(NT) void k_panel_lu(int Rp, int chunk, int w, int c
     }
 }
 
+// ---- tall matrices: more rows than the LDS of the chip holds (config 5 at 1/5: 666 k rows against 590 k).  The in-place variant of
+// k_panel_lu streams every row's 64 panel entries through L2 once per COLUMN (2 KB per row and panel).  Instead the pivots of a
+// panel are elected among the rows that DO fit (the first ones: the leftmost rule prefers them anyway) by the LDS-resident
+// kernel, and the rows beyond them FOLLOW: with the panel's pivots known, a row's elimination needs no election and no barrier --
+// it is loaded once, eliminated against the normalised pivot rows column by column exactly as a resident row is, stored once
+// (128 bytes per row and panel).  The one thing a follower cannot do is become a pivot: when a column that found no pivot among
+// the resident rows holds a non-zero in a follower, *flag is set and the host redoes the panel in place over all rows
+// (never seen on a matrix tall enough to have followers; tested with a planted column).
+template <int NT, typename XT>
+__global__ __launch_bounds__(NT) void k_panel_follow(int Rp, int row0, int chunk, int w, ZpField F, XT *__restrict__ P, const int *__restrict__ seq,
+                                                     const PanelInfo *__restrict__ info, int *__restrict__ flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dynf[]; // chunk * 64 residues
+    XT *X = (XT *)s_dynf;
+    __shared__ int s_T[DP_W][DP_W]; // s_T[c][j]: the normalised pivot row of column c at column j > c (0 where the column has no pivot)
+    __shared__ int s_has[DP_W];
+    const int tid = threadIdx.x;
+    const int base = row0 + blockIdx.x * chunk;
+    const int nloc = min(chunk, Rp - base);
+    if (nloc <= 0) return;
+    for (int idx = tid; idx < DP_W * DP_W; idx += NT) s_T[idx >> 6][idx & 63] = 0;
+    if (tid < DP_W) s_has[tid] = 0;
+    __syncthreads();
+    const int npp = info->npp;
+    for (int idx = tid; idx < npp * DP_W; idx += NT) {
+        const int t = idx >> 6, j = idx & 63;
+        const int c = info->col[t], p = info->row[t], inv = info->inv[t];
+        if (j > c && j < w) s_T[c][j] = zp_axpy_small(F, inv, (int)P[(i64d)j * Rp + p], 0);
+        if (j == 0) s_has[c] = 1;
+    }
+    for (int j = 0; j < DP_W; j++)
+        for (int r = tid; r < nloc; r += NT) X[j * chunk + r] = P[(i64d)j * Rp + base + r];
+    unsigned long long live = 0;
+    const int nmine = tid < nloc ? (nloc - tid + NT - 1) / NT : 0;
+    for (int k = 0; k < nmine; k++)
+        if (seq[base + tid + NT * k] < 0) live |= 1ull << k;
+    __syncthreads();
+    bool bad = false;
+    for (int c = 0; c < w; c++) {
+        const bool has = s_has[c] != 0;
+        unsigned long long m = live;
+        while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int r = tid + NT * k;
+            const int f = (int)X[c * chunk + r];
+            if (f == 0) continue;
+            if (!has) { bad = true; continue; } // the pivot of this column would have to be a follower
+            const int nf = -f;
+            for (int j = c + 1; j < w; j++) {
+                XT *x = &X[j * chunk + r];
+                *x = (XT)zp_axpy_small(F, nf, s_T[c][j], (int)*x);
+            }
+        }
+    }
+    if (bad) *flag = 1;
+    __syncthreads();
+    for (int j = 0; j < DP_W; j++)
+        for (int r = tid; r < nloc; r += NT) P[(i64d)j * Rp + base + r] = X[j * chunk + r];
+}
+
+// what k_panel_lu recorded for a panel, taken back (the host redoes the panel): its pivot rows are ordinary rows again
+__global__ void k_panel_undo(int c0, PanelInfo *__restrict__ info, int *__restrict__ seq, int *__restrict__ pivrow_of_col, DenseState *st)
+{
+    const int t = threadIdx.x;
+    const int npp = info->npp;
+    if (t < npp) {
+        seq[info->row[t]] = -1;
+        pivrow_of_col[c0 + info->col[t]] = -1;
+    }
+    if (t == 0) { st->npiv = info->gbase; st->npp = 0; }
+}
+
 // signed base-256 digits of the residue v of a prime < 2^16: a representative of v's class in [-32896, 32639]
 __device__ __forceinline__ void zp_digits(const ZpField &F, int v, int &d0, int &d1)
 {

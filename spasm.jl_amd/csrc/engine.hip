@@ -1686,6 +1686,20 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     const int lds_rows = 147456 / (DP_W * xbytes);
     const char *force_global = getenv("SPASM_AMD_PANEL_GLOBAL"); // tests: the in-place variant on small matrices
     const bool inlds = chunk <= lds_rows && !(force_global && atoi(force_global));
+    // more rows than fit: the first num_cu * res_chunk rows stay LDS-resident and elect the pivots, the others follow (dense.hpp,
+    // k_panel_follow).  SPASM_AMD_PANEL_RES_ROWS (tests): rows per workgroup that count as fitting.
+    int res_chunk = lds_rows / 64 * 64;
+    if (const char *e = getenv("SPASM_AMD_PANEL_RES_ROWS")) res_chunk = std::min(res_chunk, std::max(64, atoi(e) / 64 * 64));
+    const char *no_follow = getenv("SPASM_AMD_PANEL_NO_FOLLOW"); // A/B: the in-place variant for tall matrices, as before
+    int G_res = num_cu;
+    if (const char *e = getenv("SPASM_AMD_PANEL_RES_WGS")) G_res = std::min(num_cu, std::max(1, atoi(e))); // tests: resident workgroups
+    const i64 R_res = (i64)G_res * res_chunk; // (< Rp when tall)
+    const bool tall = R_res < (i64)R && !(force_global && atoi(force_global)) && !(no_follow && atoi(no_follow));
+    const int fol_chunk = std::min(res_chunk, (int)((147456 - (int)sizeof(int) * (DP_W * DP_W + DP_W) - 1024) / (DP_W * xbytes) / 64 * 64));
+    const int G_fol = tall ? (int)((Rp - R_res + fol_chunk - 1) / fol_chunk) : 0;
+    DevBuf<int> follow_flag;
+    if (tall) follow_flag.alloc(1);
+    int redone = 0, npanels_done = 0;
     const int Cp = (int)ldc + 128; // (the GEMM stages whole tiles of 128 columns of Ut, starting at any multiple of 64)
     DevBuf<DT> P;
     DevBuf<int> seq, candrow, invtab;
@@ -1697,7 +1711,7 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     const i64 fplane = (i64)Rp * KB, uplane = (i64)Cp * KB;
     P.alloc((size_t)DP_W * (size_t)Rp);
     seq.alloc((size_t)Rp);
-    candrow.alloc((size_t)2 * G * DP_REC);
+    candrow.alloc((size_t)2 * std::max(G, num_cu) * DP_REC);
     Fd.alloc((size_t)ND * (size_t)fplane);
     Ut.alloc((size_t)ND * (size_t)uplane);
     info.alloc((size_t)npanel);
@@ -1715,6 +1729,7 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     static bool attr_done = false;
     if (!attr_done) {
         HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
+        HIPCHK(hipFuncSetAttribute((const void *)k_panel_follow<1024, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456 - (int)sizeof(int) * (DP_W * DP_W + DP_W) - 1024));
         attr_done = true;
     }
     auto gemm = [&](int ja, int jb, int k0, int K, const int *rows, int nrows) {
@@ -1746,7 +1761,7 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
             const int c1 = std::min(c0 + DP_W, b1), w = c1 - c0;
             hipLaunchKernelGGL((k_panel_load<DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, D.p, (i64d)ldc, P.p, sync.p);
             {
-                int a_Rp = Rp, a_chunk = chunk, a_w = w, a_c0 = c0;
+                int a_Rp = Rp, a_chunk = tall ? res_chunk : chunk, a_w = w, a_c0 = c0;
                 ZpField a_F = F;
                 DT *a_P = P.p;
                 int *a_seq = seq.p, *a_pc = pivrow_of_col.p, *a_cand = candrow.p;
@@ -1756,14 +1771,35 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
                 const int *a_inv = invtab.p;
                 unsigned long long *a_stamps = stamps.p;
                 void *args[] = {&a_Rp, &a_chunk, &a_w, &a_c0, &a_F, &a_P, &a_seq, &a_pc, &a_info, &a_sy, &a_cand, &a_st, &a_inv, &a_stamps};
-                const void *fn = inlds ? (const void *)k_panel_lu<true, 1024, DT> : (const void *)k_panel_lu<false, 1024, DT>;
+                const void *fn_lds = (const void *)k_panel_lu<true, 1024, DT>, *fn_glb = (const void *)k_panel_lu<false, 1024, DT>;
                 // A PLAIN launch: G <= one workgroup per CU (LDS-bound), nothing else runs on the stream's device, so the grid is
                 // resident as a whole and the kernel's own barrier (dense.hpp: panel_grid_barrier, bounded spins) is enough.
                 // hipLaunchCooperativeKernel bought nothing but its launch-time size check, cost ~17 us per panel, and its dedicated
                 // HSA queue made every rocprofv3-profiled process die in exit(): libamdhip64's exit handler tears that queue down
                 // inside libhsa-runtime64 after rocprofiler-sdk has finalised its queue interception (tools/segv_probe.sh,
                 // profiles/r03_exit_sigsegv_backtrace.txt -- no frame of this library in the trace).
-                HIPCHK(hipLaunchKernel(fn, dim3(G), dim3(1024), args, (size_t)lds, s));
+                if (!tall) {
+                    HIPCHK(hipLaunchKernel(inlds ? fn_lds : fn_glb, dim3(G), dim3(1024), args, (size_t)lds, s));
+                } else {
+                    // the pivots among the resident rows, then the followers; a follower that should have been a pivot: redo in place
+                    HIPCHK(hipMemsetAsync(follow_flag.p, 0, sizeof(int), s));
+                    HIPCHK(hipLaunchKernel(fn_lds, dim3(G_res), dim3(1024), args, (size_t)res_chunk * DP_W * (size_t)xbytes, s));
+                    hipLaunchKernelGGL((k_panel_follow<1024, DT>), dim3(G_fol), dim3(1024), (size_t)fol_chunk * DP_W * (size_t)xbytes, s, Rp, (int)R_res, fol_chunk, w, F, P.p,
+                                       seq.p, info.p + q, follow_flag.p);
+                    HIPCHK(hipGetLastError());
+                    int fl = 0;
+                    HIPCHK(hipMemcpyAsync(&fl, follow_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                    npanels_done++;
+                    if (fl) {
+                        redone++;
+                        hipLaunchKernelGGL(k_panel_undo, dim3(1), dim3(DP_W), 0, s, c0, info.p + q, seq.p, pivrow_of_col.p, st.p);
+                        hipLaunchKernelGGL((k_panel_load<DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, D.p, (i64d)ldc, P.p, sync.p);
+                        HIPCHK(hipGetLastError());
+                        a_chunk = chunk;
+                        HIPCHK(hipLaunchKernel(fn_glb, dim3(G), dim3(1024), args, 0, s));
+                    }
+                }
             }
             if (ND == 1) hipLaunchKernelGGL((k_panel_store<1, DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
             else hipLaunchKernelGGL((k_panel_store<2, DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, F, P.p, seq.p, D.p, (i64d)ldc, info.p + q, Fd.p, (i64d)fplane, KB, q * DP_W);
@@ -1785,6 +1821,8 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     HIPCHK(hipMemcpyAsync(&hst, st.p, sizeof hst, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hst.pad) throw EngineError("dense finish: a grid barrier of the panel kernel timed out (the device is shared with another process?)");
+    if (tall) spasm_logf("[echelonize/dense] tall panels: %lld resident rows elect, %lld follow; %d of %d panels redone in place\n", (long long)R_res,
+                         (long long)R - (long long)R_res, redone, npanels_done);
     if (stamps.p) {
         std::vector<unsigned long long> h(DP_W * 8);
         HIPCHK(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

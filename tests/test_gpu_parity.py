@@ -741,14 +741,18 @@ def test_consumers_accept_pivots_that_are_not_leftmost(S, O, n, m, p, density, s
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [dict(SPASM_AMD_DENSE_KB="128"), dict(SPASM_AMD_PANEL_GLOBAL="1", SPASM_AMD_DENSE_KB="192"),
-                                 dict(SPASM_AMD_MEM_BUDGET_MB="4"), dict(SPASM_AMD_DENSE_F64="1")],
-                         ids=["several_blocks", "panel_rows_in_global_memory", "dense_W_in_column_slabs", "f64_panels"])
+                                 dict(SPASM_AMD_MEM_BUDGET_MB="4"), dict(SPASM_AMD_DENSE_F64="1"),
+                                 dict(SPASM_AMD_PANEL_RES_WGS="2", SPASM_AMD_PANEL_RES_ROWS="128", SPASM_AMD_DENSE_KB="128"),
+                                 dict(SPASM_AMD_PANEL_RES_WGS="5", SPASM_AMD_PANEL_RES_ROWS="256")],
+                         ids=["several_blocks", "panel_rows_in_global_memory", "dense_W_in_column_slabs", "f64_panels",
+                              "tall_panels_few_resident_rows_many_redone", "tall_panels_followers"])
 @pytest.mark.parametrize("kind,n,m,kw,prime", [(2, 4000, 1600, dict(row_nnz=40), 127), (1, 1500, 1200, dict(row_nnz=30), 65521)],
                          ids=["p127_one_digit", "p65521_two_digits"])
 def test_dense_finish_variants(S, O, monkeypatch, env, kind, n, m, kw, prime):
     """The code paths of the dense finish that default sizes only reach on large inputs, forced on small ones: several
     1024-column blocks (two-level updates), the panel kernel working in global memory instead of LDS, the dense W built for a
-    few columns at a time, and the f64 panels primes above 2^16 use.  Same rank, pivot columns and kernel as the oracle; the
+    few columns at a time, the f64 panels primes above 2^16 use, and the tall-matrix panels (a few LDS-resident rows elect the
+    pivots, the others follow; panels in which a follower should have been a pivot are redone in place).  Same rank, pivot columns and kernel as the oracle; the
     factorization verifies."""
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xD35E, **kw)
     for k, v in env.items():
