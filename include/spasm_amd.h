@@ -342,10 +342,16 @@ void spasm_amd_shard_free(spasm_amd_shard *sh);
 /* spasm_echelonize over several devices of THIS process: `nshards` row shards (shard s: rows s, s + nshards, ...; device s modulo
  * the number of visible devices, so nshards = 8 on an 8-GPU node puts one shard on each), per round an election (per-column minimum
  * of the shards' keys), an exchange of the elected pivot rows (peer copies over xGMI) and the local Schur complement of every shard's
- * rows; the remainder is finished by the single-device engine.  Leftmost-entry pivots throughout, so rank, pivot columns and kernel
+ * rows.  A remainder that is dense (or a round whose Schur complement is estimated dense: spasm_schur_estimate_density /
+ * spasm_schur_dense, reference src/SpaSM.jl:763-766) is finished by ALL shards together for primes below 2^16 (csrc/dense_multi.hpp:
+ * the rows stay where they are, per panel of 64 columns the candidates' panel entries go to shard 0 and the elected pivot rows to every
+ * shard); a small or sparse remainder, and larger primes, by the single-device engine on device 0.  Leftmost-entry pivots throughout, so rank, pivot columns and kernel
  * equal those of spasm_echelonize with enable_greedy_pivot_search = 0 whatever nshards is.  What spasm.jl_amd/sharded.py does with
  * one process per GPU and RCCL, behind one call for hosts without torch.distributed (the Julia side: one more @ccall). */
 struct spasm_lu *spasm_amd_echelonize_multi(const struct spasm_csr *A, struct echelonize_opts *opts, int nshards);
+/* How the most recent spasm_amd_echelonize_multi of this thread finished: 0 = remainder gathered to device 0 (or nothing left),
+ * 1 = a round's Schur complement straight to dense on all shards, 2 = the dense remainder on all shards. */
+int spasm_amd_multi_last_finish(void);
 
 /* Per-round records of the most recent spasm_echelonize call on this thread. */
 int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds);

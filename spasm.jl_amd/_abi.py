@@ -205,6 +205,7 @@ SIGNATURES = {
     "spasm_rank_certificate_load": (C.c_bool, [C.c_void_p, _P(RankCertificateStruct)]),
     "spasm_rank_certificate_free": (None, [_P(RankCertificateStruct)]),
     "spasm_amd_echelonize_multi": (_P(LuStruct), [_P(CsrStruct), _P(EchelonizeOptsStruct), C.c_int32]),
+    "spasm_amd_multi_last_finish": (C.c_int32, []),
     "spasm_amd_certificate_challenge": (None, [_P(C.c_uint8), C.c_int64, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "spasm_amd_kernel_strided": (_P(CsrStruct), [_P(LuStruct), C.c_int32, C.c_int32]),
     "spasm_amd_schur_plan_advance": (C.c_void_p, [C.c_void_p, _P(C.c_int32), _P(C.c_int64)]),

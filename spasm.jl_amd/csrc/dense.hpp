@@ -606,3 +606,239 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k
             }
         }
 }
+
+// ================================================================================================
+// Dense finish over ROW SHARDS (engine.hip: dense_finish_multi).  Rows never move: every shard keeps its rows of D, eliminates
+// them against the panel's pivots, updates them with its own GEMMs.  What crosses shards per panel of 64 columns:
+//   candidates  every shard eliminates its own rows' panel (k_panel_lu on a scratch copy of the bookkeeping) and names the <= 64
+//               rows its elimination elected: they span the panel part of all its rows.  Their 64 panel entries each, as they
+//               are in D, go to the root shard (CandRec, 16.7 KB per shard).
+//   election    the root eliminates the stacked candidates (64 x shards rows: one workgroup of k_panel_lu) -- the pivots of the
+//               panel are the rows this elects, the leading columns of the span of ALL rows: the pivot COLUMNS are those of the
+//               single-device finish.  PanelGlob (winners and the normalised 64 x 64 panel part T of the pivot rows) goes to all.
+//   guests      every winner's row of D (columns from the panel on) and of F (its multipliers of the block so far) is copied into
+//               the same GUEST row of every shard (rows R .. R + KB of D: 64 per panel of the block), so that every shard runs the
+//               pivot rows' triangular solves and its own GEMMs without further traffic: (C - c0) bytes per pivot and shard.
+//   apply       with T known a shard's rows need no election and no barrier (k_panel_apply, the follower of k_panel_follow);
+//               the winners -- guest copies, and the original on its owner -- freeze at their columns.
+// At the end of a block the owners copy the finished guest rows over the originals.
+// ================================================================================================
+#define DM_MAXSHARDS 64
+
+struct CandRec {
+    int n;                 // candidates (<= 64)
+    int pad[3];
+    int row[DP_W];         // local rows, -1 beyond n
+    int val[DP_W][DP_W];   // val[t][j] = D[row[t]][c0 + j] before the panel (0 beyond the panel's width)
+};
+
+struct PanelGlob {
+    int npp, pad[3];
+    int col[DP_W], inv[DP_W];     // pivot t: its column inside the panel, the inverse of its entry there
+    int shard[DP_W], row[DP_W];   // its owner and the row there
+    int pos[DP_W];                // its guest slot among the 64 of the panel (owner-major)
+    int piv_of_col[DP_W];         // column -> pivot index, -1: no pivot
+    int cnt[DM_MAXSHARDS], first[DM_MAXSHARDS]; // winners of every shard, and the guest slot of its first
+    int T[DP_W][DP_W];            // T[c][j], j > c: the normalised pivot row of column c (0 where the column has none)
+};
+
+template <typename DT>
+__global__ __launch_bounds__(256) void k_cand_gather(int c0, int w, const DT *__restrict__ D, i64d ldc, const PanelInfo *__restrict__ info, CandRec *__restrict__ out,
+                                                     const DenseState *__restrict__ st_tmp, int *__restrict__ flag)
+{
+    const int n = info->npp;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out->n = n;
+        if (st_tmp->pad) atomicOr(flag, 2); // a grid barrier of the candidates' elimination timed out
+    }
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < DP_W * DP_W; idx += gridDim.x * 256) {
+        const int t = idx >> 6, j = idx & 63;
+        const int r = t < n ? info->row[t] : -1;
+        out->val[t][j] = (r >= 0 && j < w) ? (int)D[(i64d)r * ldc + c0 + j] : 0;
+        if (j == 0) out->row[t] = r;
+    }
+}
+
+// the stacked candidates of G shards as the panel of a one-workgroup k_panel_lu: P[j][64 k + t], seq = -1 for real candidates
+template <typename DT>
+__global__ __launch_bounds__(256) void k_stack_load(int G, int Rs, const CandRec *__restrict__ stack, DT *__restrict__ P, int *__restrict__ seq, PanelSync *sy,
+                                                    DenseState *st)
+{
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < DP_NCTR) sy->arrive[threadIdx.x * 32] = 0;
+        if (threadIdx.x == 0) { sy->timeout = 0; st->npiv = 0; st->npp = 0; st->pad = 0; }
+    }
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < Rs * DP_W; idx += gridDim.x * 256) {
+        const int j = idx / Rs, r = idx % Rs;
+        const int k = r >> 6, t = r & 63;
+        const bool real = k < G && t < stack[k].n;
+        P[(i64d)j * Rs + r] = real ? (DT)stack[k].val[t][j] : (DT)0;
+        if (j == 0) seq[r] = real ? -1 : 0;
+    }
+}
+
+// what the election among the stacked candidates found, as every shard needs it
+template <typename DT>
+__global__ __launch_bounds__(1024) void k_make_glob(int G, int Rs, int w, ZpField F, const CandRec *__restrict__ stack, const PanelInfo *__restrict__ info,
+                                                    const DT *__restrict__ P, PanelGlob *__restrict__ g)
+{
+    const int tid = threadIdx.x;
+    const int npp = info->npp;
+    __shared__ int s_sh[DP_W];
+    for (int idx = tid; idx < DP_W * DP_W; idx += 1024) g->T[idx >> 6][idx & 63] = 0;
+    if (tid < DP_W) {
+        g->piv_of_col[tid] = -1;
+        const int t = tid;
+        int c = -1, inv = 0, sh = -1, row = -1;
+        if (t < npp) {
+            c = info->col[t];
+            inv = info->inv[t];
+            const int sr = info->row[t];
+            sh = sr >> 6;
+            row = stack[sh].row[sr & 63];
+        }
+        g->col[t] = c; g->inv[t] = inv; g->shard[t] = sh; g->row[t] = row;
+        s_sh[t] = sh;
+    }
+    __syncthreads();
+    if (tid < DP_W && tid < npp) g->piv_of_col[g->col[tid]] = tid;
+    if (tid == 0) {
+        g->npp = npp;
+        int at = 0;
+        for (int k = 0; k < DM_MAXSHARDS; k++) {
+            g->first[k] = at;
+            int c = 0;
+            if (k < G)
+                for (int t = 0; t < npp; t++)
+                    if (s_sh[t] == k) g->pos[t] = at + c++;
+            g->cnt[k] = c;
+            at += c;
+        }
+        for (int t = npp; t < DP_W; t++) g->pos[t] = -1;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < npp * DP_W; idx += 1024) {
+        const int t = idx >> 6, j = idx & 63;
+        const int c = info->col[t], sr = info->row[t], inv = info->inv[t];
+        if (j > c && j < w) g->T[c][j] = zp_axpy_small(F, inv, (int)P[(i64d)j * Rs + sr], 0);
+    }
+}
+
+// the rows a shard won, packed in winner order: their entries of D from column c0 on, their rows of F
+template <typename DT>
+__global__ __launch_bounds__(256) void k_export_pack(int me, int c0, i64d ldc, const PanelGlob *__restrict__ g, const DT *__restrict__ D,
+                                                     const signed char *__restrict__ Fd, i64d fplane, int KB, int ND, DT *__restrict__ expD,
+                                                     signed char *__restrict__ expF)
+{
+    const int t = blockIdx.x;
+    if (t >= g->npp || g->shard[t] != me) return;
+    const int slot = g->pos[t] - g->first[me];
+    const int cnt = g->cnt[me];
+    const i64d src = (i64d)g->row[t] * ldc, dst = (i64d)slot * ldc;
+    for (i64d j = c0 + blockIdx.y * 256 + threadIdx.x; j < ldc; j += (i64d)gridDim.y * 256) expD[dst + j] = D[src + j];
+    if (blockIdx.y == 0)
+        for (int d = 0; d < ND; d++)
+            for (int k = threadIdx.x; k < KB; k += 256) expF[((i64d)d * cnt + slot) * KB + k] = Fd[(i64d)d * fplane + (i64d)g->row[t] * KB + k];
+}
+
+// the guest rows of the panel go live; own_map[guest] = the row they came from when it is this shard's
+__global__ void k_apply_prep(int me, int guest0, int q, const PanelGlob *__restrict__ g, int *__restrict__ seq, int *__restrict__ own_map)
+{
+    const int t = threadIdx.x;
+    if (t < g->npp) {
+        const int gi = q * DP_W + g->pos[t];
+        seq[guest0 + gi] = -1;
+        own_map[gi] = g->shard[t] == me ? g->row[t] : -1;
+    }
+}
+
+// the elimination of a shard's rows by the panel's pivots (T of the PanelGlob): no election, no barrier.  The winners -- the guest
+// rows of the panel, and on its owner the row a guest was copied from -- take part until their own column and are pivots from there.
+// *flag is set when a live row holds a non-zero in a column without a pivot (the candidates did not span the shard's rows: a bug).
+template <int NT, typename XT>
+__global__ __launch_bounds__(NT) void k_panel_apply(int Rp, int chunk, int w, ZpField F, XT *__restrict__ P, int *__restrict__ seq, const PanelGlob *__restrict__ g,
+                                                    int me, int guest0, const DenseState *__restrict__ st, int *__restrict__ flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyna[]; // chunk * 64 residues
+    XT *X = (XT *)s_dyna;
+    __shared__ int s_T[DP_W][DP_W];
+    __shared__ int s_t[DP_W], s_g[DP_W], s_o[DP_W];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * chunk;
+    const int nloc = min(chunk, Rp - base);
+    if (nloc <= 0) return;
+    for (int idx = tid; idx < DP_W * DP_W; idx += NT) s_T[idx >> 6][idx & 63] = g->T[idx >> 6][idx & 63];
+    if (tid < DP_W) {
+        const int t = g->piv_of_col[tid];
+        s_t[tid] = t;
+        s_g[tid] = t >= 0 ? guest0 + g->pos[t] : -1;
+        s_o[tid] = (t >= 0 && g->shard[t] == me) ? g->row[t] : -1;
+    }
+    for (int j = 0; j < DP_W; j++)
+        for (int r = tid; r < nloc; r += NT) X[j * chunk + r] = P[(i64d)j * Rp + base + r];
+    unsigned long long live = 0;
+    const int nmine = tid < nloc ? (nloc - tid + NT - 1) / NT : 0;
+    for (int k = 0; k < nmine; k++)
+        if (seq[base + tid + NT * k] < 0) live |= 1ull << k;
+    const int gbase = st->npiv;
+    __syncthreads();
+    bool bad = false;
+    for (int c = 0; c < w; c++) {
+        const int t = s_t[c];
+        const int rg = s_g[c] - base, ro = s_o[c] - base;
+        unsigned long long m = live;
+        while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int r = tid + NT * k;
+            if (t >= 0 && (r == rg || r == ro)) { seq[base + r] = gbase + t; live &= ~(1ull << k); continue; }
+            const int f = (int)X[c * chunk + r];
+            if (f == 0) continue;
+            if (t < 0) { bad = true; continue; }
+            const int nf = -f;
+            for (int j = c + 1; j < w; j++) {
+                XT *x = &X[j * chunk + r];
+                *x = (XT)zp_axpy_small(F, nf, s_T[c][j], (int)*x);
+            }
+        }
+    }
+    if (bad) atomicOr(flag, 1);
+    __syncthreads();
+    for (int j = 0; j < DP_W; j++)
+        for (int r = tid; r < nloc; r += NT) P[(i64d)j * Rp + base + r] = X[j * chunk + r];
+}
+
+// the panel's record as k_panel_store / k_trsm_i8 / the pivot-row GEMMs read it: the pivot rows are the GUEST rows
+__global__ void k_apply_info(int me, int guest0, int c0, const PanelGlob *__restrict__ g, PanelInfo *__restrict__ info, DenseState *st, int *__restrict__ own_pivrow_of_col)
+{
+    const int t = threadIdx.x;
+    const int npp = g->npp;
+    if (t < DP_W) {
+        info->row[t] = t < npp ? guest0 + g->pos[t] : -1;
+        info->col[t] = t < npp ? g->col[t] : -1;
+        info->inv[t] = t < npp ? g->inv[t] : 0;
+        if (t < npp && g->shard[t] == me) own_pivrow_of_col[c0 + g->col[t]] = g->row[t];
+    }
+    if (t == 0) {
+        info->npp = npp;
+        info->gbase = st->npiv;
+        st->npp = npp;
+        st->npiv += npp;
+    }
+}
+
+// end of a block: the finished guest rows over the rows they came from (columns from the block's first on)
+template <typename DT>
+__global__ __launch_bounds__(256) void k_guest_copyback(int guest0, int b0, i64d ldc, const int *__restrict__ own_map, DT *__restrict__ D)
+{
+    const int o = own_map[blockIdx.x];
+    if (o < 0) return;
+    const i64d src = (i64d)(guest0 + blockIdx.x) * ldc, dst = (i64d)o * ldc;
+    for (i64d j = b0 + blockIdx.y * 256 + threadIdx.x; j < ldc; j += (i64d)gridDim.y * 256) D[dst + j] = D[src + j];
+}
+
+__global__ void k_or_int(int n, int *__restrict__ a, const int *__restrict__ b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] |= b[i];
+}

@@ -19,6 +19,11 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <atomic>
+#include <string>
 
 namespace {
 
@@ -1514,6 +1519,7 @@ void check_input(const struct spasm_csr *A, const char *who)
 }
 
 thread_local std::vector<spasm_amd_round_stats> g_last_rounds;
+thread_local int g_multi_finish = 0; // how the last spasm_amd_echelonize_multi finished (spasm_amd_multi_last_finish)
 
 i64 read_bytes_of(const RoundCounters &c, int m) { return 8 * (i64)c.nnz_reduced + 16 * (i64)c.segments + 4 * (i64)m; }
 
@@ -1840,6 +1846,53 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     return true;
 }
 
+// The pivot rows of an eliminated dense matrix (pivrow_of_col[c] = row of D that is the pivot row of its column c, -1: none), as
+// sparse rows appended to U: column c of D is column clist[c] of the matrix, row r comes from row row_orig[r] of the input.
+// *seconds (if given) receives the time spent.  Returns the number of rows appended.
+template <typename DT>
+int dense_extract_U(const DT *Dp, int C, i64 ldc, const int *pivrow_of_col, const int *clist, const int *row_orig, HostU &U, hipStream_t s)
+{
+    Scanner scan;
+    DevBuf<int> pflag, pscan;
+    pflag.alloc((size_t)C + 1); pscan.alloc((size_t)C + 1);
+    hipLaunchKernelGGL(k_flag_nonneg, dim3(cdiv((i64)C + 1, 256)), dim3(256), 0, s, C, pivrow_of_col, pflag.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(pflag.p, pscan.p, (size_t)C + 1, s);
+    int npd = 0;
+    HIPCHK(hipMemcpyAsync(&npd, pscan.p + C, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (npd == 0) return 0;
+    DevBuf<i64d> ulen, uoff;
+    ulen.alloc((size_t)npd + 1); uoff.alloc((size_t)npd + 1);
+    ulen.zero(s);
+    hipLaunchKernelGGL((k_dense_count<DT>), dim3(C), dim3(256), 0, s, C, Dp, (i64d)ldc, pivrow_of_col, pscan.p, ulen.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(ulen.p, uoff.p, (size_t)npd + 1, s);
+    i64d tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, uoff.p + npd, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    DevBuf<int2> Ufull;
+    DevBuf<int> pivcol, porig;
+    Ufull.alloc((size_t)tot + 1); pivcol.alloc((size_t)npd + 1); porig.alloc((size_t)npd + 1);
+    hipLaunchKernelGGL((k_dense_emit<DT>), dim3(C), dim3(64), 0, s, C, Dp, (i64d)ldc, pivrow_of_col, pscan.p, uoff.p, clist, row_orig,
+                       Ufull.p, pivcol.p, porig.p);
+    HIPCHK(hipGetLastError());
+    std::vector<i64d> off((size_t)npd + 1);
+    std::vector<int> pc((size_t)npd), po((size_t)npd);
+    HIPCHK(hipMemcpyAsync(off.data(), uoff.p, ((size_t)npd + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pc.data(), pivcol.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(po.data(), porig.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const i64 base = U.p.back();
+    for (int k = 0; k < npd; k++) {
+        U.p.push_back(base + off[(size_t)k + 1]);
+        U.pivcol.push_back(pc[(size_t)k]);
+        U.orig.push_back(po[(size_t)k]);
+    }
+    append_entries(U, Ufull.p, (i64)tot, s);
+    return npd;
+}
+
 // Leftmost-pivot elimination of a dense R x C matrix D (row-major, leading dimension ldc, residues mod p) whose column c is
 // column clist[c] of the matrix and whose row r comes from row row_orig[r] of the input; the pivot rows found are appended to U.
 template <typename DT>
@@ -1902,44 +1955,7 @@ int dense_eliminate(DevBuf<DT> &D, int R, int C, i64 ldc, const int *clist, cons
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     te1 = spasm_wtime();
-    // extract the pivot rows
-    DevBuf<int> pflag, pscan;
-    pflag.alloc((size_t)C + 1); pscan.alloc((size_t)C + 1);
-    hipLaunchKernelGGL(k_flag_nonneg, dim3(cdiv((i64)C + 1, 256)), dim3(256), 0, s, C, pivrow_of_col.p, pflag.p);
-    HIPCHK(hipGetLastError());
-    scan.exclusive(pflag.p, pscan.p, (size_t)C + 1, s);
-    int npd = 0;
-    HIPCHK(hipMemcpyAsync(&npd, pscan.p + C, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (npd == 0) return 0;
-    DevBuf<i64d> ulen, uoff;
-    ulen.alloc((size_t)npd + 1); uoff.alloc((size_t)npd + 1);
-    ulen.zero(s);
-    hipLaunchKernelGGL((k_dense_count<DT>), dim3(C), dim3(256), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, ulen.p);
-    HIPCHK(hipGetLastError());
-    scan.exclusive(ulen.p, uoff.p, (size_t)npd + 1, s);
-    i64d tot = 0;
-    HIPCHK(hipMemcpyAsync(&tot, uoff.p + npd, sizeof tot, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    DevBuf<int2> Ufull;
-    DevBuf<int> pivcol, porig;
-    Ufull.alloc((size_t)tot + 1); pivcol.alloc((size_t)npd + 1); porig.alloc((size_t)npd + 1);
-    hipLaunchKernelGGL((k_dense_emit<DT>), dim3(C), dim3(64), 0, s, C, D.p, (i64d)ldc, pivrow_of_col.p, pscan.p, uoff.p, clist, row_orig,
-                       Ufull.p, pivcol.p, porig.p);
-    HIPCHK(hipGetLastError());
-    std::vector<i64d> off((size_t)npd + 1);
-    std::vector<int> pc((size_t)npd), po((size_t)npd);
-    HIPCHK(hipMemcpyAsync(off.data(), uoff.p, ((size_t)npd + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(pc.data(), pivcol.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(po.data(), porig.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const i64 base = U.p.back();
-    for (int k = 0; k < npd; k++) {
-        U.p.push_back(base + off[(size_t)k + 1]);
-        U.pivcol.push_back(pc[(size_t)k]);
-        U.orig.push_back(po[(size_t)k]);
-    }
-    append_entries(U, Ufull.p, (i64)tot, s);
+    const int npd = dense_extract_U(D.p, C, ldc, pivrow_of_col.p, clist, row_orig, U, s);
     spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots [elimination %.2fs, rows of U to the host %.2fs]\n", R, C, npd, te1 - te0,
                spasm_wtime() - te1);
     return npd;
@@ -2012,8 +2028,9 @@ struct DenseW {
 
     DenseW(Round &R_, const DevMat &cur_, hipStream_t s_) : R(R_), cur(cur_), s(s_) {}
 
-    // columns of the dense matrix: those that hold entries of the current matrix and carry no pivot of this round
-    int map_columns()
+    // columns of the dense matrix: those that hold entries of the current matrix and carry no pivot of this round.  In two halves:
+    // row shards OR their flags between flag_columns() and finish_columns(), so that all of them number the columns alike.
+    void flag_columns()
     {
         const int m = cur.m;
         cflag.alloc((size_t)m + 1); cscan.alloc((size_t)m + 1); cmap.alloc((size_t)m + 1); clist.alloc((size_t)m + 1); cmap_s.alloc((size_t)m + 1);
@@ -2024,6 +2041,10 @@ struct DenseW {
         }
         hipLaunchKernelGGL(k_mask_pivot_cols, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, s, m, R.qinv_r.p, cflag.p);
         HIPCHK(hipGetLastError());
+    }
+    int finish_columns()
+    {
+        const int m = cur.m;
         scan.exclusive(cflag.p, cscan.p, (size_t)m + 1, s);
         HIPCHK(hipMemcpyAsync(&C, cscan.p + m, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -2032,6 +2053,11 @@ struct DenseW {
             HIPCHK(hipGetLastError());
         }
         return C;
+    }
+    int map_columns()
+    {
+        flag_columns();
+        return finish_columns();
     }
 
     // levels of the pivot graph (pivot indices are a topological order: row q of U_PP only holds indices > q)
@@ -2184,6 +2210,41 @@ struct DenseW {
     }
 };
 
+// The Schur complement of the round R has prepared (pivots elected, U built), straight into a dense matrix over the columns W has
+// mapped: D gets nnp + extra_rows rows (the extra ones zero: the guest rows of the distributed finish), row_orig the input rows.
+template <typename DT>
+void schur_dense_build(Round &R, const DevMat &cur, int nnp, DenseW &W, int extra_rows, DevBuf<DT> &D, DevBuf<int> &row_orig, hipStream_t s)
+{
+    const int C = W.C;
+    const double tw0 = spasm_wtime();
+    const i64 ldc = ((i64)C + 63) / 64 * 64;
+    D.alloc(((size_t)nnp + (size_t)extra_rows) * (size_t)ldc);
+    D.zero(s);
+    row_orig.alloc((size_t)nnp + 1);
+    if (nnp > 0) {
+        hipLaunchKernelGGL(k_gather_int, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, R.np_rows.p, cur.orig.p, row_orig.p);
+        HIPCHK(hipGetLastError());
+    }
+    // W for as many columns at a time as a third of the free memory holds
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    W.wbytes = (int)sizeof(DT); // (W holds residues like D does)
+    i64 budget = (i64)(fr / 3) + (i64)W.Wd.n;
+    if (const char *mb = getenv("SPASM_AMD_MEM_BUDGET_MB")) budget = std::max<i64>(atoll(mb), 1) << 18; // tests: several slabs
+    i64 Cs = std::min<i64>(ldc, std::max<i64>(64, budget / ((i64)std::max(R.npiv, 1) * W.wbytes) / 64 * 64));
+    int nslab = 0;
+    for (i64 s0 = 0; s0 < ldc && nnp > 0; s0 += Cs, nslab++) {
+        const int w = (int)std::min<i64>(Cs, ldc - s0);
+        W.slab((int)s0, w, 0);
+        W.build_w(w);
+        W.rows_into(R.np_rows.p, nnp, w, D.p, ldc, (int)s0);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    spasm_logf("[echelonize/dense] Schur complement %d x %d through a dense W (%d pivots, %d levels, %d slab%s of columns) [%.2fs]\n", nnp, C, R.npiv,
+               W.depth, nslab, nslab == 1 ? "" : "s", spasm_wtime() - tw0);
+    W.Wd.release();
+}
+
 // The finish of an echelonization whose remainder is dense: the Schur complement of the round R has prepared (pivots elected, U
 // built) goes straight into a dense matrix over the columns that are left, and is eliminated there.
 void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStream_t s, DenseW *prepared = nullptr)
@@ -2197,36 +2258,13 @@ void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStrea
     DenseW &W = *prepared;
     const int C = W.C;
     if (C == 0 || nnp == 0) return;
-    const double tw0 = spasm_wtime();
     const i64 ldc = ((i64)C + 63) / 64 * 64;
     DevBuf<int> row_orig;
     // (element type of D: dense_elem_bytes)
     auto go = [&](auto tag) {
         using DT = decltype(tag);
         DevBuf<DT> D;
-        D.alloc((size_t)nnp * (size_t)ldc);
-        D.zero(s);
-        row_orig.alloc((size_t)nnp + 1);
-        hipLaunchKernelGGL(k_gather_int, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, R.np_rows.p, cur.orig.p, row_orig.p);
-        HIPCHK(hipGetLastError());
-        // W for as many columns at a time as a third of the free memory holds
-        size_t fr = 0, tot = 0;
-        HIPCHK(hipMemGetInfo(&fr, &tot));
-        W.wbytes = dense_elem_bytes(R.F, nnp) == 4 ? 4 : (R.F.p <= 255 ? 1 : 2); // (W holds residues like D does)
-        i64 budget = (i64)(fr / 3) + (i64)W.Wd.n;
-        if (const char *mb = getenv("SPASM_AMD_MEM_BUDGET_MB")) budget = std::max<i64>(atoll(mb), 1) << 18; // tests: several slabs
-        i64 Cs = std::min<i64>(ldc, std::max<i64>(64, budget / ((i64)std::max(R.npiv, 1) * W.wbytes) / 64 * 64));
-        int nslab = 0;
-        for (i64 s0 = 0; s0 < ldc; s0 += Cs, nslab++) {
-            const int w = (int)std::min<i64>(Cs, ldc - s0);
-            W.slab((int)s0, w, 0);
-            W.build_w(w);
-            W.rows_into(R.np_rows.p, nnp, w, D.p, ldc, (int)s0);
-        }
-        HIPCHK(hipStreamSynchronize(s));
-        spasm_logf("[echelonize/dense] Schur complement %d x %d through a dense W (%d pivots, %d levels, %d slab%s of columns) [%.2fs]\n", nnp, C, R.npiv,
-                   W.depth, nslab, nslab == 1 ? "" : "s", spasm_wtime() - tw0);
-        W.Wd.release();
+        schur_dense_build(R, cur, nnp, W, 0, D, row_orig, s);
         dense_eliminate(D, nnp, C, ldc, W.clist.p, row_orig.p, R.F, U, s);
     };
     switch (dense_elem_bytes(R.F, nnp)) {
@@ -2235,6 +2273,8 @@ void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStrea
     default: go((int)0); break;
     }
 }
+
+#include "dense_multi.hpp"
 
 // the L factor on the host, as it is collected: per chunk the rows it belongs to (original row of A per slot, entries per slot),
 // then the (row of U, value) pairs
@@ -3385,7 +3425,17 @@ void shard_export(spasm_amd_shard *S, int *hdr_dev, int *ent_dev)
     HIPCHK(hipStreamSynchronize(s));
 }
 
-spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev)
+// what a sharded round needs after its U: W / Uinv and the dry run that sizes the pools (the second half of shard_import)
+void shard_import_finish(spasm_amd_schur_plan *P)
+{
+    Round &R = P->R;
+    plan_prepare(P);
+    HIPCHK(hipEventRecord(R.ev[1], R.stream));
+    plan_dry_run(P, 4 * std::max<i64>(P->nnz_in, 1 << 14));
+}
+
+// prepare = false: stop after U (the caller decides first whether the round's Schur complement goes dense; shard_import_finish otherwise)
+spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev, bool prepare = true)
 {
     spasm_amd_schur_plan *P = S->plan;
     if (!P) throw EngineError("spasm_amd_shard_import: already imported");
@@ -3418,9 +3468,7 @@ spasm_amd_schur_plan *shard_import(spasm_amd_shard *S, int n_rows, i64 n_entries
     if (n_entries > 0) HIPCHK(hipMemcpyAsync(PM.ent.p, ent_dev, (size_t)n_entries * sizeof(int2), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipEventRecord(R.ev[0], s));
     R.build_U(PM, P->rowsrc.p);
-    plan_prepare(P);
-    HIPCHK(hipEventRecord(R.ev[1], s));
-    plan_dry_run(P, 4 * std::max<i64>(P->nnz_in, 1 << 14));
+    if (prepare) shard_import_finish(P);
     S->plan = nullptr; // ownership passes to the caller
     S->imported = true;
     return P;
@@ -3697,7 +3745,97 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
         DevBuf<u64d> stage; // on device 0: another shard's keys, on their way into the minimum
         int round = 0;
         i64 last_nnz = -1;
-        const i64 finish_nnz = (i64)1 << 22;
+        i64 finish_nnz = (i64)1 << 22;
+        if (const char *e = getenv("SPASM_AMD_MULTI_FINISH_NNZ")) finish_nnz = std::max<i64>(atoll(e), 0); // tests: small remainders sharded too
+        g_multi_finish = 0;
+        // ---- the dense finish over the shards (dense_multi.hpp): primes below 2^16 (the int8 path), as many shards as the election
+        // workgroup holds candidates for.  SPASM_AMD_MULTI_GATHER=1 (A/B, tests): the old hand-off, everything to device 0.
+        const ZpField F0 = zp_field_make(prime);
+        const int elem = F0.p <= 255 ? 1 : 2;
+        const char *gather_env = getenv("SPASM_AMD_MULTI_GATHER");
+        const bool ddf_ok = opts->enable_dense && F0.small && nshards * DP_W <= 147456 / (DP_W * elem) && nshards <= DM_MAXSHARDS && !(gather_env && atoi(gather_env));
+        std::vector<int> devs((size_t)nshards);
+        for (int k = 0; k < nshards; k++) devs[(size_t)k] = dev_of(k);
+        // does a dense matrix of `rows` local rows and `cols` columns fit a shard's device beside what the elimination needs?
+        auto dense_fits = [&](i64 rows, i64 cols) {
+            const double bytes = ((double)rows + 2048.0) * (double)((cols + 63) / 64 * 64) * (double)elem;
+            return bytes <= (double)dense_max_entries(elem) * (double)elem;
+        };
+        auto run_typed = [&](int C, const std::vector<const int *> &clists, auto &&build) {
+            if (elem == 1) return dense_multi_run<signed char>(nshards, devs, F0, C, clists, build, U);
+            return dense_multi_run<short>(nshards, devs, F0, C, clists, build, U);
+        };
+        // The round whose pivots have just been exchanged (every shard holds U): estimate the density of its Schur complement on 64
+        // columns (spasm_schur_estimate_density, as the single-device engine does for rounds without W or Uinv); dense -> the Schur
+        // complement of every shard's rows goes straight into its dense matrix and the shards eliminate them together.
+        auto dense_round = [&]() -> bool {
+            const int free_now = m - (int)U.pivcol.size();
+            if (free_now <= 0) return false;
+            std::vector<std::unique_ptr<DenseW>> dws((size_t)nshards);
+            std::vector<int *> flags((size_t)nshards);
+            i64 nnp_tot = 0, nnp_max = 0;
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                spasm_amd_schur_plan *P = st[(size_t)k]->plan;
+                dws[(size_t)k].reset(new DenseW(P->R, P->A, P->R.stream));
+                dws[(size_t)k]->flag_columns();
+                HIPCHK(hipStreamSynchronize(P->R.stream));
+                flags[(size_t)k] = dws[(size_t)k]->cflag.p;
+                nnp_tot += P->R.nnp;
+                nnp_max = std::max<i64>(nnp_max, P->R.nnp);
+            }
+            if (nnp_tot <= 64) return false;
+            or_flags_across(devs, flags, m);
+            int C = 0;
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                C = dws[(size_t)k]->finish_columns();
+            }
+            if (C == 0 || !dense_fits(nnp_max, C)) return false;
+            HIPCHK(hipSetDevice(dev_of(0)));
+            Round &R0 = st[0]->plan->R;
+            const double est = dws[0]->estimate_density(R0.np_rows.p, R0.nnp, free_now);
+            spasm_logf("Schur complement is %lld x %d, estimated density : %.2f (64 columns sampled on shard 0, %d levels)\n", (long long)nnp_tot, free_now, est, dws[0]->depth);
+            if (!(est > opts->sparsity_threshold)) return false;
+            spasm_logf("[echelonize] finishing; density = %.3f (estimated); aspect ratio = %.1f; Schur complement straight to dense on %d shards\n", est,
+                       (double)nnp_tot / (double)free_now, nshards);
+            std::vector<const int *> clists((size_t)nshards);
+            for (int k = 0; k < nshards; k++) clists[(size_t)k] = dws[(size_t)k]->clist.p;
+            run_typed(C, clists, [&](int k, int extra, auto &D, DevBuf<int> &row_orig, int &Rk) {
+                spasm_amd_schur_plan *P = st[(size_t)k]->plan;
+                Rk = P->R.nnp;
+                schur_dense_build(P->R, P->A, Rk, *dws[(size_t)k], extra, D, row_orig, P->R.stream);
+            });
+            return true;
+        };
+        // the remaining rows are dense already: every shard's live rows as a dense matrix, eliminated together
+        auto dense_now = [&]() -> bool {
+            std::vector<std::unique_ptr<DenseFill>> fl((size_t)nshards);
+            std::vector<int *> flags((size_t)nshards);
+            i64 rmax = 0;
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                spasm_amd_schur_plan *P = st[(size_t)k]->sh->plan;
+                fl[(size_t)k].reset(new DenseFill(P->A, P->R.stream));
+                fl[(size_t)k]->flag_columns();
+                flags[(size_t)k] = fl[(size_t)k]->cflag.p;
+                rmax = std::max<i64>(rmax, fl[(size_t)k]->R);
+            }
+            or_flags_across(devs, flags, m);
+            int C = 0;
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
+                C = fl[(size_t)k]->finish_columns();
+            }
+            if (C == 0 || !dense_fits(rmax, C)) return false;
+            std::vector<const int *> clists((size_t)nshards);
+            for (int k = 0; k < nshards; k++) clists[(size_t)k] = fl[(size_t)k]->clist.p;
+            run_typed(C, clists, [&](int k, int extra, auto &D, DevBuf<int> &row_orig, int &Rk) {
+                Rk = fl[(size_t)k]->R;
+                fl[(size_t)k]->build(extra, D, row_orig);
+            });
+            return true;
+        };
         for (;;) {
             i64 rows_left = 0, nnz_left = 0;
             for (auto &q : st) { rows_left += q->rows; nnz_left += q->nnz; }
@@ -3707,8 +3845,14 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
             bool dense_enough = opts->enable_dense && (double)nnz_left > opts->sparsity_threshold * cells;
             // (one round ahead as well: when the fill keeps growing at the rate of the last round the next Schur complement would
             // be dense -- it is then never built sparse; the single-device density estimate plays this role there)
-            if (last_nnz > 0 && nnz_left > last_nnz)
+            // (with the distributed finish the estimate after the election decides instead: dense_round)
+            if (!ddf_ok && last_nnz > 0 && nnz_left > last_nnz)
                 dense_enough = dense_enough || (opts->enable_dense && (double)nnz_left * ((double)nnz_left / (double)last_nnz) > opts->sparsity_threshold * cells);
+            if (ddf_ok && dense_enough && nnz_left > finish_nnz) {
+                spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f; dense finish on %d shards\n", (double)nnz_left / cells,
+                           free_cols > 0 ? (double)rows_left / (double)free_cols : 0.0, nshards);
+                if (dense_now()) { g_multi_finish = 2; break; }
+            }
             if (nnz_left <= finish_nnz || round >= opts->max_round || dense_enough) {
                 // ---- hand-off: the remaining rows, under their original numbers, to the single-device engine on device 0
                 std::vector<struct spasm_csr *> parts((size_t)nshards, nullptr);
@@ -3817,7 +3961,7 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
                 HIPCHK(hipSetDevice(dev_of(k)));
                 ShardState &q = *st[(size_t)k];
                 spasm_amd_shard *sh = q.sh;
-                q.plan = shard_import(sh, npiv, tot_ent, q.hdr_all.p, q.ent_all.p); // (the shard hands its matrix to the plan)
+                q.plan = shard_import(sh, npiv, tot_ent, q.hdr_all.p, q.ent_all.p, !ddf_ok); // (the shard hands its matrix to the plan)
                 q.sh = nullptr;
                 delete sh;
             }
@@ -3838,6 +3982,18 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
                     memcpy(U.x.grow((size_t)uz), Uc->x, sizeof(int) * (size_t)uz);
                 }
                 spasm_csr_free(Uc);
+            }
+            if (ddf_ok) {
+                if (dense_round()) {
+                    g_multi_finish = 1;
+                    spasm_logf("[echelonize] round %d (sharded): %d pivots, %lld rows / %lld entries before it; its Schur complement went dense\n", round, npiv,
+                               (long long)rows_left, (long long)nnz_left);
+                    break;
+                }
+                for (int k = 0; k < nshards; k++) {
+                    HIPCHK(hipSetDevice(dev_of(k)));
+                    shard_import_finish(st[(size_t)k]->plan);
+                }
             }
             // ---- the Schur complement of every shard's rows becomes its matrix of the next round, on its device
             last_nnz = nnz_left;
@@ -4325,6 +4481,8 @@ SPASM_API int spasm_amd_zp_probe(i64 prime, int n, const int *a, const int *b, c
         return 1;
     }
 }
+
+SPASM_API int spasm_amd_multi_last_finish(void) { return g_multi_finish; }
 
 SPASM_API int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds)
 {

@@ -175,3 +175,62 @@ def test_echelonize_multi_in_one_process_matches_the_single_device_result(S, O, 
     # pivotal rows first in p, each once
     p = np.asarray(got.p)[: got.r]
     assert len(set(p.tolist())) == got.r and (p >= 0).all() and (p < n).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,m,kw,prime,nshards,env,finish", [
+    (2, 5000, 2000, dict(row_nnz=30), 127, 2, dict(SPASM_AMD_MULTI_FINISH_NNZ="1000"), 1),
+    (2, 6000, 2400, dict(row_nnz=30), 127, 3, dict(SPASM_AMD_MULTI_FINISH_NNZ="1000", SPASM_AMD_DENSE_KB="128"), 1),
+    (2, 5000, 2000, dict(row_nnz=30), 127, 4, dict(SPASM_AMD_MULTI_FINISH_NNZ="1000", SPASM_AMD_DENSE_KB="192", SPASM_AMD_PANEL_GLOBAL="1"), 1),
+    (1, 1500, 1200, dict(row_nnz=30), 65521, 3, dict(SPASM_AMD_MULTI_FINISH_NNZ="1000", SPASM_AMD_DENSE_KB="128"), 1),
+    (0, 900, 700, dict(density=0.3), 127, 2, dict(SPASM_AMD_MULTI_FINISH_NNZ="1000"), 2),
+    (0, 700, 900, dict(density=0.25), 65521, 5, dict(SPASM_AMD_MULTI_FINISH_NNZ="1000", SPASM_AMD_DENSE_KB="256"), 2),
+    (0, 640, 200, dict(density=0.5), 127, 8, dict(SPASM_AMD_MULTI_FINISH_NNZ="1000", SPASM_AMD_DENSE_KB="64"), 2),
+], ids=["macaulay_2_shards", "macaulay_3_shards_several_blocks", "macaulay_4_shards_panel_in_global_memory", "two_digits_3_shards",
+        "dense_input_2_shards", "dense_input_two_digits_5_shards", "tall_dense_input_8_shards_blocks_of_one_panel"])
+def test_dense_finish_over_row_shards(S, O, monkeypatch, kind, n, m, kw, prime, nshards, env, finish):
+    """The dense finish distributed over the row shards (csrc/dense_multi.hpp; VERDICT r2 missing #1, BASELINE config 5): rows stay on
+    their shard, per panel the candidates go to shard 0 and the elected pivot rows to every shard.  `finish` says which way in the
+    run must have taken (1: a round's Schur complement straight to dense, 2: the remainder was dense already).  Rank, pivot columns
+    and kernel are those of the single-device leftmost-pivot run (and of the oracle); the factorization verifies; pivotal rows are
+    distinct rows of A."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xDD5E, **kw)
+    ref = S.echelonize(A, **LM)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = S.echelonize_multi(A, nshards)
+    how = S._abi.lib().spasm_amd_multi_last_finish()
+    monkeypatch.setenv("SPASM_AMD_MULTI_GATHER", "1")
+    old = S.echelonize_multi(A, nshards)            # the hand-off to device 0, as before
+    assert S._abi.lib().spasm_amd_multi_last_finish() == 0
+    monkeypatch.delenv("SPASM_AMD_MULTI_GATHER")
+    for k in env:
+        monkeypatch.delenv(k)
+    assert how == finish
+    assert got.r == ref.r == old.r == O.echelonize(A, **LM).r
+    assert np.asarray(got.qinv >= 0).tolist() == np.asarray(ref.qinv >= 0).tolist() == np.asarray(old.qinv >= 0).tolist()
+    assert S.factorization_verify(A, got, 7)
+    assert S.kernel(got).rows() == S.kernel(ref).rows()
+    p = np.asarray(got.p)[: got.r]
+    assert len(set(p.tolist())) == got.r and (p >= 0).all() and (p < n).all()
+
+
+@pytest.mark.gpu
+def test_dense_finish_over_row_shards_rank_deficient(S, O, monkeypatch):
+    """Dependent rows and empty columns: the shards must agree on a rank below min(n, m), and columns without a pivot inside a
+    panel must not derail the candidates' election."""
+    rng = np.random.default_rng(5)
+    p = 127
+    B = (rng.integers(0, p, size=(150, 400)) * (rng.random((150, 400)) < 0.6)).astype(np.int64)
+    B[:, 100:140] = 0                                                        # a run of empty columns inside a panel
+    M = (rng.integers(0, p, size=(900, 150)).astype(np.int64).dot(B)) % p     # 900 x 400 of rank <= 150
+    A = S.CSR(M.T.copy(), prime=p)
+    ref = S.echelonize(A, **LM)
+    monkeypatch.setenv("SPASM_AMD_MULTI_FINISH_NNZ", "1000")
+    monkeypatch.setenv("SPASM_AMD_DENSE_KB", "128")
+    got = S.echelonize_multi(A, 3)
+    assert S._abi.lib().spasm_amd_multi_last_finish() == 2
+    assert got.r == ref.r <= 150
+    assert np.asarray(got.qinv >= 0).tolist() == np.asarray(ref.qinv >= 0).tolist()
+    assert S.factorization_verify(A, got, 7)
+    assert S.kernel(got).rows() == S.kernel(ref).rows()
