@@ -259,6 +259,7 @@ struct spasm_amd_round_stats {
     i64 w_levels;
     i64 w_entries;
     i64 w_long_rows;
+    i64 npiv_greedy;      /* of npiv: pivots the greedy cycle-free search added (reference README.md:23; csrc/greedy.hpp) */
 };
 
 typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;

@@ -291,9 +291,159 @@ static void emit_pivot_row(const struct spasm_csr *A, int i, int j, struct spasm
     is_piv[i] = 1;
 }
 
-static int fl_pivots_ex(const struct spasm_csr *A, struct spasm_csr *U, int *qinv, char *is_piv, int *Uorig, const int *orig,
-                        int on_columns, int *n_open)
+/* The third search of the [pivots] log, "greedy alternating cycle-free search" (README.md:23; the option is
+ * enable_greedy_pivot_search, src/SpaSM.jl:326).  As for "FL on columns", libspasm's source is not in the reference tree: its search
+ * (a breadth-first search per row, rows of different threads checking each other's new pivots in a critical section) depends on the
+ * order the rows are visited in, so this is the order-free rule of the MI355X engine (csrc/greedy.hpp), restated so that both take
+ * the SAME pivots; tests/fl_columns_ref.py states it a third time, independently, in Python.
+ *   pass (up to 3, until one accepts nothing), for every non-empty row i that is no pivot row and has at most 256 entries:
+ *     reach(i)   = pivots reachable from row i through pivot columns; more than 1024 of them: the row sits the pass out;
+ *     touched(i) = pivot-free columns held by the rows of reach(i);
+ *     proposal   = the leftmost pivot-free column of row i that is not touched; per column the smallest (length, row) wins;
+ *     a winner is accepted unless another column of (own pivot-free columns + touched) has a winner with a smaller key.
+ * pc / pr: the pivots (column, row), np of them on entry; the new ones are appended.  Returns how many were added. */
+/* breadth-first search from row i through the pivot rows: stamp[r] = mark for the rows reached (queue[0 .. *ntail) lists them).
+ * Returns 0 when more than `budget` pivots are reached. */
+static int greedy_search(const struct spasm_csr *A, int i, int mark, const int *prow_of_col, int *stamp, int *queue, int budget, int *ntail)
 {
+    int head = 0, tail = 0;
+    for (i64 k = A->p[i]; k < A->p[i + 1]; k++) {
+        int r = prow_of_col[A->j[k]];
+        if (r >= 0 && stamp[r] != mark) {
+            stamp[r] = mark;
+            if (tail >= budget) return 0;
+            queue[tail++] = r;
+        }
+    }
+    while (head < tail) {
+        int r = queue[head++];
+        for (i64 k = A->p[r]; k < A->p[r + 1]; k++) {
+            int r2 = prow_of_col[A->j[k]];
+            if (r2 >= 0 && stamp[r2] != mark) {
+                stamp[r2] = mark;
+                if (tail >= budget) return 0;
+                queue[tail++] = r2;
+            }
+        }
+    }
+    *ntail = tail;
+    return 1;
+}
+
+static int greedy_extend(const struct spasm_csr *A, int *pc, int *pr, int np)
+{
+    enum { GREEDY_PASSES = 3, GR_MAXLEN = 256, GR_BUDGET = 1024 };
+    const int n = A->n, m = A->m;
+    int *prow_of_col = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    char *taken = calloc((size_t)(n > 0 ? n : 1), 1);
+    int *stamp = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));   /* row reached by the search numbered stamp[.] */
+    int *cstamp = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));  /* column touched by the search numbered cstamp[.] */
+    int *queue = malloc(sizeof(int) * (size_t)(GR_BUDGET + 2));
+    int *prop = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    int *acc = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    i64 *winner = malloc(sizeof(i64) * (size_t)(m > 0 ? m : 1));
+    int added = 0, mark = 0;
+    for (int j = 0; j < m; j++) { prow_of_col[j] = -1; cstamp[j] = -1; }
+    for (int i = 0; i < n; i++) stamp[i] = -1;
+    for (int t = 0; t < np; t++) { prow_of_col[pc[t]] = pr[t]; taken[pr[t]] = 1; }
+    for (int pass = 1; pass <= GREEDY_PASSES; pass++) {
+        for (int j = 0; j < m; j++) winner[j] = -1;
+        for (int i = 0; i < n; i++) {
+            prop[i] = -1;
+            i64 len = A->p[i + 1] - A->p[i];
+            if (taken[i] || len == 0 || len > GR_MAXLEN) continue;
+            int tail = 0;
+            mark++;
+            if (!greedy_search(A, i, mark, prow_of_col, stamp, queue, GR_BUDGET, &tail)) continue;
+            for (int t = 0; t < tail; t++)
+                for (i64 k = A->p[queue[t]]; k < A->p[queue[t] + 1]; k++) cstamp[A->j[k]] = mark; /* (pivot columns too: harmless) */
+            int best = -1;
+            for (i64 k = A->p[i]; k < A->p[i + 1]; k++) {
+                int c = A->j[k];
+                if (prow_of_col[c] >= 0 || cstamp[c] == mark) continue;
+                if (best < 0 || c < best) best = c;
+            }
+            if (best < 0) continue;
+            prop[i] = best;
+            i64 key = (len << 32) | (i64)i;
+            if (winner[best] < 0 || key < winner[best]) winner[best] = key;
+        }
+        int nacc = 0;
+        for (int i = 0; i < n; i++) {
+            int j = prop[i];
+            if (j < 0) continue;
+            i64 len = A->p[i + 1] - A->p[i];
+            i64 key = (len << 32) | (i64)i;
+            if (winner[j] != key) continue;
+            int tail = 0;
+            mark++;
+            if (!greedy_search(A, i, mark, prow_of_col, stamp, queue, GR_BUDGET, &tail)) continue;
+            int rejected = 0;
+            /* full(i) = the pivot-free columns of row i and of the rows it reaches */
+            for (int t = -1; t < tail && !rejected; t++) {
+                int r = t < 0 ? i : queue[t];
+                for (i64 k = A->p[r]; k < A->p[r + 1]; k++) {
+                    int c = A->j[k];
+                    if (prow_of_col[c] < 0 && c != j && winner[c] >= 0 && winner[c] < key) { rejected = 1; break; }
+                }
+            }
+            if (!rejected) acc[nacc++] = i;
+        }
+        for (int t = 0; t < nacc; t++) {
+            int i = acc[t];
+            pc[np + added] = prop[i];
+            pr[np + added] = i;
+            added++;
+            prow_of_col[prop[i]] = i;
+            taken[i] = 1;
+        }
+        if (nacc == 0) break;
+    }
+    free(prow_of_col); free(taken); free(stamp); free(cstamp); free(queue); free(prop); free(acc); free(winner);
+    return added;
+}
+
+/* all pivots of a round in a topological order when the greedy search has added some: descending level (0 = the row holds no other
+ * pivot column, else 1 + the deepest level among the pivot columns it holds), ascending column inside a level */
+static void topological_numbering(const struct spasm_csr *A, int *pc, int *pr, int np)
+{
+    const int m = A->m;
+    int *idx_of_col = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    int *lev = calloc((size_t)(np > 0 ? np : 1), sizeof(int));
+    for (int j = 0; j < m; j++) idx_of_col[j] = -1;
+    for (int t = 0; t < np; t++) idx_of_col[pc[t]] = t;
+    for (int sweep = 0, changed = 1; changed; sweep++) {
+        assert(sweep <= np + 1);
+        changed = 0;
+        for (int t = 0; t < np; t++) {
+            int l = 0;
+            for (i64 k = A->p[pr[t]]; k < A->p[pr[t] + 1]; k++) {
+                int c = A->j[k];
+                if (c != pc[t] && idx_of_col[c] >= 0 && lev[idx_of_col[c]] + 1 > l) l = lev[idx_of_col[c]] + 1;
+            }
+            if (l > lev[t]) { lev[t] = l; changed = 1; }
+        }
+    }
+    /* sort by (-level, column): counting on the columns, then stable on the levels */
+    int *bycol = malloc(sizeof(int) * (size_t)(np > 0 ? np : 1));
+    int w = 0, maxlev = 0;
+    for (int j = 0; j < m; j++) if (idx_of_col[j] >= 0) bycol[w++] = idx_of_col[j];
+    for (int t = 0; t < np; t++) if (lev[t] > maxlev) maxlev = lev[t];
+    int *npc = malloc(sizeof(int) * (size_t)(np > 0 ? np : 1)), *npr = malloc(sizeof(int) * (size_t)(np > 0 ? np : 1));
+    w = 0;
+    for (int l = maxlev; l >= 0; l--)
+        for (int t = 0; t < np; t++)
+            if (lev[bycol[t]] == l) { npc[w] = pc[bycol[t]]; npr[w] = pr[bycol[t]]; w++; }
+    assert(w == np);
+    memcpy(pc, npc, sizeof(int) * (size_t)np);
+    memcpy(pr, npr, sizeof(int) * (size_t)np);
+    free(idx_of_col); free(lev); free(bycol); free(npc); free(npr);
+}
+
+static int fl_pivots_ex(const struct spasm_csr *A, struct spasm_csr *U, int *qinv, char *is_piv, int *Uorig, const int *orig,
+                        int on_columns, int *n_open, int *n_greedy)
+{
+    int emitted = 0, ngreedy = 0;
     int n = A->n, m = A->m;
     int *best = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
     for (int j = 0; j < m; j++) best[j] = -1;
@@ -359,29 +509,40 @@ static int fl_pivots_ex(const struct spasm_csr *A, struct spasm_csr *U, int *qin
                     for (i64 k = A->p[prow[t]]; k < A->p[prow[t] + 1]; k++) closed[A->j[k]] = 1;
                 }
             }
+            /* all pivots of the round in the numbering of the first two searches: later passes first, then the leftmost ones */
+            int *ac = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)), *ar = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+            int na = 0;
             for (int pass = npass; pass >= 1; pass--)
-                for (int t = pstart[pass - 1]; t < pstart[pass]; t++) {
-                    emit_pivot_row(A, prow[t], pcol[t], U, qinv, is_piv, Uorig, orig);
-                    nopen++;
-                }
+                for (int t = pstart[pass - 1]; t < pstart[pass]; t++) { ac[na] = pcol[t]; ar[na] = prow[t]; na++; nopen++; }
+            for (int j = 0; j < m; j++) if (best[j] >= 0) { ac[na] = j; ar[na] = best[j]; na++; npiv++; }
+            /* the third search (on_columns >= 2); when it finds anything all pivots are renumbered topologically */
+            if (on_columns >= 2) {
+                ngreedy = greedy_extend(A, ac, ar, na);
+                if (ngreedy > 0) { na += ngreedy; topological_numbering(A, ac, ar, na); }
+            }
+            for (int t = 0; t < na; t++) emit_pivot_row(A, ar[t], ac[t], U, qinv, is_piv, Uorig, orig);
+            free(ac); free(ar);
+            emitted = 1;
         }
         free(taken); free(closed); free(cnt); free(best2); free(pcol); free(prow);
     }
-    for (int j = 0; j < m; j++) {
-        int i = best[j];
-        if (i < 0) continue;
-        emit_pivot_row(A, i, j, U, qinv, is_piv, Uorig, orig);
-        npiv++;
-    }
+    if (!emitted)
+        for (int j = 0; j < m; j++) {
+            int i = best[j];
+            if (i < 0) continue;
+            emit_pivot_row(A, i, j, U, qinv, is_piv, Uorig, orig);
+            npiv++;
+        }
     free(best);
     if (n_open) *n_open = nopen;
-    return npiv + nopen;
+    if (n_greedy) *n_greedy = ngreedy;
+    return npiv + nopen + ngreedy;
 }
 
 static int fl_pivots(const struct spasm_csr *A, struct spasm_csr *U, int *qinv, int *Urow_of, char *is_piv, int *Uorig, const int *orig)
 {
     (void)Urow_of;
-    return fl_pivots_ex(A, U, qinv, is_piv, Uorig, orig, 0, NULL);
+    return fl_pivots_ex(A, U, qinv, is_piv, Uorig, orig, 0, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------ Schur complement, proto src/SpaSM.jl:761-762
@@ -568,7 +729,11 @@ ORC_API struct spasm_lu *orc_echelonize(const struct spasm_csr *A0, const struct
         if (orc_nnz(A) == 0 || U->n == maxr) break;
         char *is_piv = malloc((size_t)(A->n > 0 ? A->n : 1));
         int rank_before = U->n;
-        int npiv = fl_pivots_ex(A, U, qinv, is_piv, Uorig, orig, opts_in->enable_greedy_pivot_search, NULL);
+        /* enable_greedy_pivot_search: "FL on columns" and the greedy cycle-free search (SPASM_AMD_NO_CYCLE_FREE_SEARCH=1, read by
+         * the engine as well: without the third search, for A/B tests) */
+        const char *no3 = getenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH");
+        int searches = opts_in->enable_greedy_pivot_search ? ((no3 && atoi(no3)) ? 1 : 2) : 0;
+        int npiv = fl_pivots_ex(A, U, qinv, is_piv, Uorig, orig, searches, NULL, NULL);
         int avail = A->n < m - rank_before ? A->n : m - rank_before;
         int *p_out = malloc(sizeof(int) * (size_t)(A->n > 0 ? A->n : 1));
         struct spasm_csr *S = orc_schur(A, is_piv, U, qinv, p_out, stats, 0);

@@ -110,6 +110,7 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
         ("w_levels", C.c_int64),
         ("w_entries", C.c_int64),
         ("w_long_rows", C.c_int64),
+        ("npiv_greedy", C.c_int64),
     ]
 
     def as_dict(self):

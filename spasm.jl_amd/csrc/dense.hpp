@@ -842,3 +842,101 @@ __global__ void k_or_int(int n, int *__restrict__ a, const int *__restrict__ b)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] |= b[i];
 }
+
+// ================================================================================================
+// Tall-and-skinny finish (engine.hip: dense_finish_tall; libspasm's enable_tall_and_skinny / tall_and_skinny_ratio, reference
+// src/SpaSM.jl:327, :341).  A remainder with many more rows than columns has at most C pivots: eliminating ALL its rows costs
+// R C^2 / 2, although the rank is settled by few of them.  Instead
+//   1. a first slab of R1 = C + C/8 rows is eliminated as usual (R1 C^2 / 2): r1 pivots, echelon rows u_t;
+//   2. the reduced form of those rows on the f = C - r1 columns WITHOUT pivot, Z_t = u_t,N - sum_{s > t} u_t[pcol_s] Z_s (blocked back
+//      substitution on the int8 GEMM: r1^2 f / 2);
+//   3. every other row d is reduced in one step, t = d_N - d_P Z (R2 r1 f): zero on all pivot columns by construction;
+//   4. the residuals (R2 x f, small) are eliminated like any dense matrix: the pivots they still hold.
+// Exact, not probabilistic (libspasm's low-rank mode draws random combinations and stops when a batch finds nothing): every row is
+// reduced, and the pivot columns are the leading columns of the row space whatever the slab was (a basis with distinct leading
+// columns -- the u_t and the echelon form of the residuals -- shows them all).
+// ================================================================================================
+
+// F[d][i][k] = digit d of D[rowidx ? rowidx[i] : i][cols[k]], k < K; 0 for K <= k < Kpad
+template <int ND, typename DT>
+__global__ __launch_bounds__(256) void k_tall_gather_F(int nrows, const int *__restrict__ rowidx, const DT *__restrict__ D, i64d ldc, const int *__restrict__ cols, int K,
+                                                       int Kpad, ZpField F, signed char *__restrict__ Fd, i64d fplane, int KB)
+{
+    const int i = blockIdx.x;
+    if (i >= nrows) return;
+    const i64d src = (i64d)(rowidx ? rowidx[i] : i) * ldc;
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
+        int v = k < K ? (int)D[src + cols[k]] : 0;
+        int d0, d1;
+        zp_digits(F, v, d0, d1);
+        Fd[(i64d)i * KB + k] = (signed char)d0;
+        if (ND == 2) Fd[fplane + (i64d)i * KB + k] = (signed char)d1;
+    }
+}
+
+// Ut[d][j][k] = digit d of Z[k][j], k < K (rows of Z), j < ncols; 0 for K <= k < Kpad and for ncols <= j < ncols_pad
+template <int ND, typename DT>
+__global__ __launch_bounds__(256) void k_tall_Ut(const DT *__restrict__ Z, i64d ldz, int K, int Kpad, int ncols, int ncols_pad, ZpField F, signed char *__restrict__ Ut, i64d uplane,
+                                                 int KB)
+{
+    const int j = blockIdx.x;
+    if (j >= ncols_pad) return;
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
+        int v = (k < K && j < ncols) ? (int)Z[(i64d)k * ldz + j] : 0;
+        int d0, d1;
+        zp_digits(F, v, d0, d1);
+        Ut[(i64d)j * KB + k] = (signed char)d0;
+        if (ND == 2) Ut[uplane + (i64d)j * KB + k] = (signed char)d1;
+    }
+}
+
+// out[i][j] = D[rowidx ? rowidx[i] : i][cols[j]], j < ncols (0 up to ldo)
+template <typename DT>
+__global__ __launch_bounds__(256) void k_tall_gather_cols(int nrows, const int *__restrict__ rowidx, const DT *__restrict__ D, i64d ldc, const int *__restrict__ cols, int ncols,
+                                                          DT *__restrict__ out, i64d ldo)
+{
+    const int i = blockIdx.x;
+    if (i >= nrows) return;
+    const i64d src = (i64d)(rowidx ? rowidx[i] : i) * ldc;
+    for (int j = threadIdx.x; j < (int)ldo; j += 256) out[(i64d)i * ldo + j] = j < ncols ? D[src + cols[j]] : (DT)0;
+}
+
+// back substitution inside a block of nb pivots (rows t0 .. t0 + nb of Z, pivot rows prow[t], pivot columns pcol[t]):
+// z_t -= sum_{t < s < t0 + nb} D[prow[t]][pcol[s]] z_s, t descending.  One workgroup per 64 columns of Z, one lane per column; the
+// coefficients of row t are read by all lanes alike (a broadcast load).
+template <typename DT>
+__global__ __launch_bounds__(64) void k_tall_backsub(int t0, int nb, int ncols, ZpField F, const DT *__restrict__ D, i64d ldc, const int *__restrict__ prow,
+                                                     const int *__restrict__ pcol, DT *__restrict__ Z, i64d ldz)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= ncols) return;
+    for (int t = t0 + nb - 2; t >= t0; t--) {
+        const i64d urow = (i64d)prow[t] * ldc;
+        long long acc = (long long)Z[(i64d)t * ldz + j];
+        int terms = 0;
+        for (int s = t + 1; s < t0 + nb; s++) {
+            const int u = (int)D[urow + pcol[s]];
+            if (u == 0) continue;
+            acc -= (long long)u * (long long)Z[(i64d)s * ldz + j]; // |term| < 2^30 (p < 2^16)
+            if (++terms == (1 << 20)) { acc = (long long)zp_reduce(F, acc); terms = 0; }
+        }
+        Z[(i64d)t * ldz + j] = (DT)zp_reduce(F, acc);
+    }
+}
+
+// lists of the columns with and without pivot, both ascending: flag = pivrow_of_col >= 0, scans of the two flags
+__global__ void k_tall_split_cols(int C, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan, int *__restrict__ pcol, int *__restrict__ prow,
+                                  int *__restrict__ fcol)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int p = pivrow_of_col[c];
+    if (p >= 0) { pcol[pscan[c]] = c; prow[pscan[c]] = p; }
+    else fcol[c - pscan[c]] = c;
+}
+
+__global__ void k_gather_int2(int n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}

@@ -1,0 +1,190 @@
+// Tall-and-skinny dense finish -- host side (included by engine.hip inside its anonymous namespace; kernels and the algorithm:
+// dense.hpp, section "Tall-and-skinny finish").  libspasm: enable_tall_and_skinny / tall_and_skinny_ratio (reference
+// src/SpaSM.jl:327, :341; the strategies behind them, spasm_schur_dense_randomized and friends, prototypes :767-769).
+//
+// RowSource: where the dense rows come from -- fill(off, cnt, Dp) writes rows off .. off + cnt of the remainder, all C columns,
+// into Dp (cnt x ldc, zero on entry): the Schur rows of a round through the dense W (SchurRowSource) or the live rows of the
+// current matrix (FillRowSource).  Rows are only ever materialised a slab at a time.
+#pragma once
+
+struct TallStats {
+    int R1 = 0, r1 = 0, f = 0, r2 = 0;
+    double t_slab = 0, t_z = 0, t_resid = 0, t_tail = 0;
+};
+
+template <typename DT> struct TallWork {
+    const ZpField &F;
+    hipStream_t s;
+    int ND, KB = 1024;
+    DevBuf<signed char> Fd, Ut;
+    DevBuf<int> live;   // seq of the GEMM: all -1
+    i64 fplane = 0, uplane = 0;
+    int rows_cap = 0, cols_cap = 0;
+    TallWork(const ZpField &F_, hipStream_t s_) : F(F_), s(s_), ND(F_.p <= 255 ? 1 : 2) {}
+    void ensure(int rows, int ncols)
+    {
+        const int rp = (rows + 127) / 128 * 128, cp = (ncols + 63) / 64 * 64 + 128;
+        if (rp > rows_cap) {
+            rows_cap = rp;
+            fplane = (i64)rp * KB;
+            Fd.alloc((size_t)ND * (size_t)fplane);
+            live.alloc((size_t)rp);
+            HIPCHK(hipMemsetAsync(live.p, 0xff, (size_t)rp * sizeof(int), s));
+        }
+        if (cp > cols_cap) {
+            cols_cap = cp;
+            uplane = (i64)cp * KB;
+            Ut.alloc((size_t)ND * (size_t)uplane);
+        }
+    }
+    // T[i][0 .. ncols) -= sum_k Src[rowidx ? rowidx[i] : i][cols[k]] * Z[k][0 .. ncols), i < nrows, k < K (K <= KB)
+    void gemm_sub(DT *T, i64 ldt, int nrows, const DT *Src, i64 lds, const int *rowidx, const int *cols, int K, const DT *Z, i64 ldz, int ncols)
+    {
+        if (nrows <= 0 || K <= 0 || ncols <= 0) return;
+        ensure(nrows, ncols);
+        const int Kpad = (K + 63) / 64 * 64;
+        const int ncp = (ncols + 63) / 64 * 64 + 128;
+        if (ND == 1) {
+            hipLaunchKernelGGL((k_tall_gather_F<1, DT>), dim3(nrows), dim3(256), 0, s, nrows, rowidx, Src, (i64d)lds, cols, K, Kpad, F, Fd.p, (i64d)fplane, KB);
+            hipLaunchKernelGGL((k_tall_Ut<1, DT>), dim3(ncp), dim3(256), 0, s, Z, (i64d)ldz, K, Kpad, ncols, ncp, F, Ut.p, (i64d)uplane, KB);
+            const int ntm = cdiv(nrows, 128), ntn = cdiv(ncols, 128);
+            hipLaunchKernelGGL((k_gemm_i8<1, 2, 2, 2, 2, DT>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, nrows, 0, ncols, 0, Kpad, F, T, (i64d)ldt, live.p, (const int *)nullptr, 0,
+                               Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB, ntm, ntn);
+        } else {
+            hipLaunchKernelGGL((k_tall_gather_F<2, DT>), dim3(nrows), dim3(256), 0, s, nrows, rowidx, Src, (i64d)lds, cols, K, Kpad, F, Fd.p, (i64d)fplane, KB);
+            hipLaunchKernelGGL((k_tall_Ut<2, DT>), dim3(ncp), dim3(256), 0, s, Z, (i64d)ldz, K, Kpad, ncols, ncp, F, Ut.p, (i64d)uplane, KB);
+            const int ntm = cdiv(nrows, 128), ntn = cdiv(ncols, 64);
+            hipLaunchKernelGGL((k_gemm_i8<2, 4, 1, 1, 2, DT>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, nrows, 0, ncols, 0, Kpad, F, T, (i64d)ldt, live.p, (const int *)nullptr, 0,
+                               Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB, ntm, ntn);
+        }
+        HIPCHK(hipGetLastError());
+    }
+};
+
+// rows per slab that is eliminated whole: enough to carry every pivot a remainder of C columns can have, with some slack for
+// dependent rows.  SPASM_AMD_TALL_SLAB (tests): rows of the first slab.
+inline int tall_first_slab(int R, int C)
+{
+    i64 R1 = (i64)C + C / 8 + 1024;
+    if (const char *e = getenv("SPASM_AMD_TALL_SLAB")) R1 = std::max<i64>(64, atoll(e));
+    R1 = (R1 + 63) / 64 * 64;
+    return (int)std::min<i64>(R1, R);
+}
+
+// does the tall-and-skinny finish apply?  libspasm: enable_tall_and_skinny and rows / columns above tall_and_skinny_ratio
+inline bool tall_applies(const struct echelonize_opts *opts, const ZpField &F, i64 R, i64 C)
+{
+    if (!opts || !opts->enable_tall_and_skinny || !F.small || C <= 0) return false;
+    const char *e = getenv("SPASM_AMD_TALL"); // 0: never, 1: whenever there are rows beyond the first slab (tests)
+    if (e && atoi(e) == 0) return false;
+    if (tall_first_slab((int)std::min<i64>(R, INT_MAX), (int)C) >= R) return false;
+    if (e && atoi(e) == 1) return true;
+    const double ratio = opts->tall_and_skinny_ratio > 0 ? opts->tall_and_skinny_ratio : 5.0;
+    return (double)R > ratio * (double)C;
+}
+
+template <typename DT, class RowSource>
+int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, const int *row_orig, const ZpField &F, HostU &U, hipStream_t s)
+{
+    TallStats ts;
+    const double t0 = spasm_wtime();
+    const int R1 = tall_first_slab(R, C);
+    ts.R1 = R1;
+    // ---- 1. the first slab, eliminated as a whole
+    DevBuf<DT> D1;
+    DevBuf<int> pc1;
+    D1.alloc((size_t)R1 * (size_t)ldc);
+    D1.zero(s);
+    pc1.alloc((size_t)C + 1);
+    src.fill(0, R1, D1.p);
+    if (!dense_eliminate_i8(D1, R1, C, ldc, F, pc1, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
+    HIPCHK(hipStreamSynchronize(s));
+    const int r1 = dense_extract_U(D1.p, C, ldc, pc1.p, clist, row_orig, U, s);
+    ts.r1 = r1;
+    ts.t_slab = spasm_wtime() - t0;
+    const int R2 = R - R1;
+    const int f = C - r1;
+    ts.f = f;
+    if (R2 <= 0 || f <= 0) {
+        src.done();
+        spasm_logf("[echelonize/dense] tall and skinny: %d x %d, first slab of %d rows: %d pivots%s [%.2fs]\n", R, C, R1, r1,
+                   f <= 0 && R2 > 0 ? " = every column: the other rows cannot add any" : "", ts.t_slab);
+        return r1;
+    }
+    // ---- 2. columns with / without pivot; Z = the reduced form of the slab's pivot rows on the columns without
+    const double t1 = spasm_wtime();
+    Scanner scan;
+    DevBuf<int> pflag, pscan, pcol, prow, fcol, fclist;
+    pflag.alloc((size_t)C + 1); pscan.alloc((size_t)C + 1); pcol.alloc((size_t)r1 + 1); prow.alloc((size_t)r1 + 1); fcol.alloc((size_t)f + 1); fclist.alloc((size_t)f + 1);
+    hipLaunchKernelGGL(k_flag_nonneg, dim3(cdiv((i64)C + 1, 256)), dim3(256), 0, s, C, pc1.p, pflag.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(pflag.p, pscan.p, (size_t)C + 1, s);
+    hipLaunchKernelGGL(k_tall_split_cols, dim3(cdiv(C, 256)), dim3(256), 0, s, C, pc1.p, pscan.p, pcol.p, prow.p, fcol.p);
+    hipLaunchKernelGGL(k_gather_int2, dim3(cdiv(f, 256)), dim3(256), 0, s, f, fcol.p, clist, fclist.p);
+    HIPCHK(hipGetLastError());
+    const i64 ldz = ((i64)f + 63) / 64 * 64;
+    DevBuf<DT> Z;
+    Z.alloc((size_t)std::max(r1, 1) * (size_t)ldz);
+    TallWork<DT> W(F, s);
+    if (r1 > 0) {
+        hipLaunchKernelGGL((k_tall_gather_cols<DT>), dim3(r1), dim3(256), 0, s, r1, prow.p, D1.p, (i64d)ldc, fcol.p, f, Z.p, (i64d)ldz);
+        HIPCHK(hipGetLastError());
+        const int OB = W.KB, IB = 64;
+        for (int b1 = r1; b1 > 0;) {
+            const int b0 = std::max(0, (b1 - 1) / OB * OB), nb = b1 - b0;
+            // rows b0 .. b1 against everything behind the block
+            for (int s0 = b1; s0 < r1; s0 += OB)
+                W.gemm_sub(Z.p + (size_t)b0 * (size_t)ldz, ldz, nb, D1.p, ldc, prow.p + b0, pcol.p + s0, std::min(OB, r1 - s0), Z.p + (size_t)s0 * (size_t)ldz, ldz, f);
+            // inside the block: 64 pivots at a time, the later ones of the block through the GEMM, then the back substitution
+            for (int i1 = b1; i1 > b0;) {
+                const int i0 = std::max(b0, (i1 - 1) / IB * IB), ni = i1 - i0;
+                if (i1 < b1) W.gemm_sub(Z.p + (size_t)i0 * (size_t)ldz, ldz, ni, D1.p, ldc, prow.p + i0, pcol.p + i1, b1 - i1, Z.p + (size_t)i1 * (size_t)ldz, ldz, f);
+                hipLaunchKernelGGL((k_tall_backsub<DT>), dim3(cdiv(f, 64)), dim3(64), 0, s, i0, ni, f, F, D1.p, (i64d)ldc, prow.p, pcol.p, Z.p, (i64d)ldz);
+                i1 = i0;
+            }
+            HIPCHK(hipGetLastError());
+            b1 = b0;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    D1.release();
+    ts.t_z = spasm_wtime() - t1;
+    // ---- 3. every other row in one step: t = d_N - d_P Z, a batch of rows at a time
+    const double t2 = spasm_wtime();
+    DevBuf<DT> T;
+    T.alloc((size_t)R2 * (size_t)ldz);
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    i64 RB = std::max<i64>(4096, (i64)(fr / 4) / ((i64)ldc * (i64)sizeof(DT)) / 128 * 128);
+    if (const char *e = getenv("SPASM_AMD_TALL_BATCH")) RB = std::max<i64>(128, atoll(e) / 128 * 128); // tests: several batches
+    RB = std::min<i64>(RB, ((i64)R2 + 127) / 128 * 128);
+    DevBuf<DT> Db;
+    Db.alloc((size_t)RB * (size_t)ldc);
+    for (i64 off = 0; off < R2; off += RB) {
+        const int cnt = (int)std::min<i64>(RB, R2 - off);
+        HIPCHK(hipMemsetAsync(Db.p, 0, (size_t)cnt * (size_t)ldc * sizeof(DT), s));
+        src.fill(R1 + (int)off, cnt, Db.p);
+        DT *Tb = T.p + (size_t)off * (size_t)ldz;
+        hipLaunchKernelGGL((k_tall_gather_cols<DT>), dim3(cnt), dim3(256), 0, s, cnt, (const int *)nullptr, Db.p, (i64d)ldc, fcol.p, f, Tb, (i64d)ldz);
+        HIPCHK(hipGetLastError());
+        for (int s0 = 0; s0 < r1; s0 += W.KB)
+            W.gemm_sub(Tb, ldz, cnt, Db.p, ldc, nullptr, pcol.p + s0, std::min(W.KB, r1 - s0), Z.p + (size_t)s0 * (size_t)ldz, ldz, f);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    Db.release();
+    Z.release();
+    src.done();
+    ts.t_resid = spasm_wtime() - t2;
+    // ---- 4. what the residuals still hold
+    const double t3 = spasm_wtime();
+    DevBuf<int> pc2;
+    pc2.alloc((size_t)f + 1);
+    if (!dense_eliminate_i8(T, R2, f, ldz, F, pc2, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
+    HIPCHK(hipStreamSynchronize(s));
+    const int r2 = dense_extract_U(T.p, f, ldz, pc2.p, fclist.p, row_orig + R1, U, s);
+    ts.r2 = r2;
+    ts.t_tail = spasm_wtime() - t3;
+    spasm_logf("[echelonize/dense] tall and skinny: %d x %d; first slab of %d rows: %d pivots [%.2fs]; reduced form on the %d columns left [%.2fs]; %d rows reduced in one step "
+               "[%.2fs]; their residuals: %d pivots [%.2fs]\n", R, C, R1, r1, ts.t_slab, f, ts.t_z, R2, ts.t_resid, r2, ts.t_tail);
+    return r1 + r2;
+}

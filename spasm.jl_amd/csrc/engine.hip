@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 #include "stream.hpp"
 #include "wlevel.hpp"
+#include "greedy.hpp"
 #include "dense.hpp"
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
@@ -411,6 +412,93 @@ struct Round {
         HIPCHK(hipGetLastError());
         npiv += nnew;
         n_open = nnew;
+        return nnew;
+    }
+
+    // ---- (1b'') the greedy cycle-free search (greedy.hpp; reference README.md:23): after the leftmost election and "FL on columns",
+    // non-pivot rows take pivots on columns that carry none as long as the pivots stay permutable to a triangle.  Appends the new
+    // pivots, then renumbers ALL pivots of the round topologically (descending level, ascending column).  Returns how many were
+    // added.  Single device only, like "FL on columns".
+    DevBuf<int> gr_accept, gr_ascan, gr_lev, gr_iota, gr_order, gr_prow, gr_pcol, gr_flag;
+    DevBuf<u64d> gr_keys, gr_keys2;
+    int n_greedy = 0;
+    int extend_pivots_cycle_free(const DevMat &A)
+    {
+        n_greedy = 0;
+        if (npiv == 0 || A.n == 0) return 0;
+        const int n = A.n;
+        best2.ensure((size_t)m + 1);
+        prop.ensure((size_t)n + 1);
+        gr_accept.ensure((size_t)n + 1);
+        gr_ascan.ensure((size_t)n + 1);
+        is_piv.ensure((size_t)n + 1);
+        HIPCHK(hipMemsetAsync(is_piv.p, 0, ((size_t)n + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, 0, 1, n, pivrow.p, is_piv.p);
+        HIPCHK(hipGetLastError());
+        int nnew = 0;
+        for (int pass = 1; pass <= GREEDY_PASSES; pass++) {
+            hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best2.p);
+            hipLaunchKernelGGL((k_greedy<1>), dim3(cdiv(n, GR_WPB)), dim3(64 * GR_WPB), 0, stream, n, is_piv.p, A.start.p, A.len.p, A.ent.p, qinv_r.p, pivrow.p, best2.p,
+                               prop.p, gr_accept.p);
+            hipLaunchKernelGGL((k_greedy<2>), dim3(cdiv(n, GR_WPB)), dim3(64 * GR_WPB), 0, stream, n, is_piv.p, A.start.p, A.len.p, A.ent.p, qinv_r.p, pivrow.p, best2.p,
+                               prop.p, gr_accept.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(gr_accept.p + n, 0, sizeof(int), stream));
+            scan.exclusive(gr_accept.p, gr_ascan.p, (size_t)n + 1, stream);
+            int nacc = 0;
+            HIPCHK(hipMemcpyAsync(&nacc, gr_ascan.p + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (nacc == 0) break;
+            // (pivrow / pivcol grow: keep what is there)
+            if ((size_t)(npiv + nnew + nacc + 1) > pivrow.n) {
+                DevBuf<int> r2, c2;
+                r2.alloc((size_t)(npiv + nnew + nacc) + (size_t)n / 8 + 1024);
+                c2.alloc(r2.n);
+                HIPCHK(hipMemcpyAsync(r2.p, pivrow.p, (size_t)(npiv + nnew) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+                HIPCHK(hipMemcpyAsync(c2.p, pivcol.p, (size_t)(npiv + nnew) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                pivrow = std::move(r2);
+                pivcol = std::move(c2);
+            }
+            hipLaunchKernelGGL(k_greedy_record, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, npiv + nnew, gr_accept.p, gr_ascan.p, prop.p, pivrow.p, pivcol.p, qinv_r.p,
+                               is_piv.p);
+            HIPCHK(hipGetLastError());
+            nnew += nacc;
+        }
+        if (nnew == 0) return 0;
+        npiv += nnew;
+        n_greedy = nnew;
+        // ---- topological renumbering of all pivots of the round
+        gr_lev.ensure((size_t)npiv + 1); gr_iota.ensure((size_t)npiv + 1); gr_order.ensure((size_t)npiv + 1);
+        gr_prow.ensure((size_t)npiv + 1); gr_pcol.ensure((size_t)npiv + 1); gr_keys.ensure((size_t)npiv + 1); gr_keys2.ensure((size_t)npiv + 1);
+        gr_flag.ensure(4);
+        HIPCHK(hipMemsetAsync(gr_lev.p, 0, ((size_t)npiv + 1) * sizeof(int), stream));
+        constexpr int TEAM = 8;
+        for (int batch = 0;; batch++) {
+            if (batch * 8 > npiv + 8) throw EngineError("greedy pivot search: the pivots do not form an acyclic graph");
+            for (int it = 0; it < 8; it++) {
+                if (it == 7) HIPCHK(hipMemsetAsync(gr_flag.p, 0, sizeof(int), stream));
+                hipLaunchKernelGGL((k_piv_relax<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, stream, npiv, pivrow.p, pivcol.p, A.start.p, A.len.p, A.ent.p,
+                                   qinv_r.p, gr_lev.p, it == 7 ? gr_flag.p : (int *)nullptr);
+            }
+            HIPCHK(hipGetLastError());
+            int ch = 1;
+            HIPCHK(hipMemcpyAsync(&ch, gr_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (ch == 0) break;
+        }
+        hipLaunchKernelGGL(k_piv_keys, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, gr_lev.p, pivcol.p, gr_keys.p, gr_iota.p);
+        HIPCHK(hipGetLastError());
+        {
+            size_t bytes = 0;
+            HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, gr_keys.p, gr_keys2.p, gr_iota.p, gr_order.p, (size_t)npiv, 0, 64, stream));
+            sort_tmp.ensure(bytes);
+            HIPCHK(rocprim::radix_sort_pairs(sort_tmp.p, bytes, gr_keys.p, gr_keys2.p, gr_iota.p, gr_order.p, (size_t)npiv, 0, 64, stream));
+        }
+        HIPCHK(hipMemcpyAsync(gr_prow.p, pivrow.p, (size_t)npiv * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(gr_pcol.p, pivcol.p, (size_t)npiv * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_piv_permute, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, gr_order.p, gr_prow.p, gr_pcol.p, pivrow.p, pivcol.p, qinv_r.p);
+        HIPCHK(hipGetLastError());
         return nnew;
     }
 
@@ -1531,6 +1619,7 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     st.nnz_in = nnz_in;
     st.npiv = R.npiv;
     st.npiv_open = R.n_open;
+    st.npiv_greedy = R.n_greedy;
     st.rows_out = R.hctr.nonempty_out;
     st.nnz_out = (i64)R.hctr.nnz_out;
     st.nnz_reduced = (i64)R.hctr.nnz_reduced;
@@ -1962,7 +2051,24 @@ int dense_eliminate(DevBuf<DT> &D, int R, int C, i64 ldc, const int *clist, cons
 }
 
 
-int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
+#include "dense_tall.hpp"
+
+// the live rows of a sparse matrix, a range at a time, as dense rows (RowSource of dense_tall.hpp)
+template <typename DT> struct FillRowSource {
+    const DevMat &M;
+    const int *rows, *cmap;
+    i64 ldc;
+    hipStream_t s;
+    void fill(int off, int cnt, DT *Dp)
+    {
+        if (cnt <= 0) return;
+        hipLaunchKernelGGL((k_dense_fill<DT>), dim3(cdiv((i64)cnt * 64, 256)), dim3(256), 0, s, cnt, rows + off, M.start.p, M.len.p, M.ent.p, cmap, Dp, (i64d)ldc);
+        HIPCHK(hipGetLastError());
+    }
+    void done() {}
+};
+
+int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s, const struct echelonize_opts *opts = nullptr)
 {
     const int n = M.n, m = M.m;
     Scanner scan;
@@ -1995,6 +2101,12 @@ int run_dense_tail(const DevMat &M, const ZpField &F, HostU &U, hipStream_t s)
     HIPCHK(hipGetLastError());
     auto go = [&](auto tag) {
         using DT = decltype(tag);
+        if constexpr (!std::is_same<DT, int>::value) {
+            if (tall_applies(opts, F, R, C)) {
+                FillRowSource<DT> src{M, rows.p, cmap.p, ldc, s};
+                return dense_finish_tall<DT>(src, R, C, ldc, clist.p, row_orig.p, F, U, s);
+            }
+        }
         DevBuf<DT> D;
         D.alloc((size_t)R * (size_t)ldc);
         D.zero(s);
@@ -2245,9 +2357,43 @@ void schur_dense_build(Round &R, const DevMat &cur, int nnp, DenseW &W, int extr
     W.Wd.release();
 }
 
+// the Schur rows of a round, a range of the non-pivot rows at a time, through the dense W (RowSource of dense_tall.hpp)
+template <typename DT> struct SchurRowSource {
+    Round &R;
+    const DevMat &cur;
+    DenseW &W;
+    i64 ldc;
+    hipStream_t s;
+    i64 Cs = 0;
+    bool built = false;
+    SchurRowSource(Round &R_, const DevMat &cur_, DenseW &W_, i64 ldc_, hipStream_t s_) : R(R_), cur(cur_), W(W_), ldc(ldc_), s(s_)
+    {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        W.wbytes = (int)sizeof(DT);
+        i64 budget = (i64)(fr / 3) + (i64)W.Wd.n;
+        if (const char *mb = getenv("SPASM_AMD_MEM_BUDGET_MB")) budget = std::max<i64>(atoll(mb), 1) << 18;
+        Cs = std::min<i64>(ldc, std::max<i64>(64, budget / ((i64)std::max(R.npiv, 1) * W.wbytes) / 64 * 64));
+    }
+    void fill(int off, int cnt, DT *Dp)
+    {
+        const bool one = Cs >= ldc; // W for all columns at once: built once, kept until done()
+        for (i64 s0 = 0; s0 < ldc && cnt > 0; s0 += Cs) {
+            const int w = (int)std::min<i64>(Cs, ldc - s0);
+            if (!(one && built)) {
+                W.slab((int)s0, w, 0);
+                W.build_w(w);
+                built = true;
+            }
+            W.rows_into(R.np_rows.p + off, cnt, w, Dp, ldc, (int)s0);
+        }
+    }
+    void done() { W.Wd.release(); built = false; }
+};
+
 // The finish of an echelonization whose remainder is dense: the Schur complement of the round R has prepared (pivots elected, U
 // built) goes straight into a dense matrix over the columns that are left, and is eliminated there.
-void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStream_t s, DenseW *prepared = nullptr)
+void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStream_t s, DenseW *prepared = nullptr, const struct echelonize_opts *opts = nullptr)
 {
     std::unique_ptr<DenseW> own;
     if (!prepared) {
@@ -2263,6 +2409,17 @@ void schur_dense_finish(Round &R, const DevMat &cur, int nnp, HostU &U, hipStrea
     // (element type of D: dense_elem_bytes)
     auto go = [&](auto tag) {
         using DT = decltype(tag);
+        if constexpr (!std::is_same<DT, int>::value) {
+            if (tall_applies(opts, R.F, nnp, C)) {
+                // many more rows than columns: one slab carries the pivots, the other rows are reduced in one step (dense_tall.hpp)
+                row_orig.alloc((size_t)nnp + 1);
+                hipLaunchKernelGGL(k_gather_int, dim3(cdiv(nnp, 256)), dim3(256), 0, s, nnp, R.np_rows.p, cur.orig.p, row_orig.p);
+                HIPCHK(hipGetLastError());
+                SchurRowSource<DT> src(R, cur, W, ldc, s);
+                dense_finish_tall<DT>(src, nnp, C, ldc, W.clist.p, row_orig.p, R.F, U, s);
+                return;
+            }
+        }
         DevBuf<DT> D;
         schur_dense_build(R, cur, nnp, W, 0, D, row_orig, s);
         dense_eliminate(D, nnp, C, ldc, W.clist.p, row_orig.p, R.F, U, s);
@@ -2381,7 +2538,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
                 (double)cur_nnz > opts->sparsity_threshold * cells) {
                 spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                            cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
-                run_dense_tail(*cur, R->F, U, stream);
+                run_dense_tail(*cur, R->F, U, stream, opts);
                 break;
             }
         }
@@ -2394,7 +2551,12 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         // finish keep to leftmost entries, like the reference's GPLU and dense finishes.
         R->n_leftmost = R->npiv;
         R->n_open = 0;
-        if (opts->enable_greedy_pivot_search && !gplu_finish && round < opts->max_round) R->extend_pivots_on_open_columns(*cur);
+        R->n_greedy = 0;
+        if (opts->enable_greedy_pivot_search && !gplu_finish && round < opts->max_round) {
+            R->extend_pivots_on_open_columns(*cur);
+            const char *no_third = getenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH"); // A/B: the round without the third search
+            if (!(no_third && atoi(no_third))) R->extend_pivots_cycle_free(*cur);
+        }
         if (!gplu_finish) {
             // The reference's round loop (tunables src/SpaSM.jl:333-337): at most max_round sparse rounds, and none that finds
             // fewer than min_pivot_proportion * min(rows, free columns) pivots ("not enough pivots found; stopping", README.md:32).
@@ -2413,7 +2575,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
                 if (use_dense && cells > 0 && cells <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) && worth) {
                     spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                                cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
-                    run_dense_tail(*cur, R->F, U, stream);
+                    run_dense_tail(*cur, R->F, U, stream, opts);
                     break;
                 }
                 if (!opts->enable_GPLU) {
@@ -2511,10 +2673,11 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         if (dense_possible && est_density > opts->sparsity_threshold) {
             spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found\n", round, R->n_leftmost);
             if (R->n_open) spasm_logf("[pivots] ``Faugère-Lachartre on columns'': %d pivots found\n", R->n_open);
+            if (R->n_greedy) spasm_logf("[pivots] greedy alternating cycle-free search: %d pivots found\n", R->n_greedy);
             spasm_logf("[echelonize] finishing; density = %.3f (estimated); aspect ratio = %.1f; Schur complement straight to dense\n", est_density,
                        free_now > 0 ? (double)nnp / (double)free_now : 0.0);
             append_round_U(U, *R, *cur, stream);
-            schur_dense_finish(*R, *cur, nnp, U, stream, dw.get());
+            schur_dense_finish(*R, *cur, nnp, U, stream, dw.get(), opts);
             spasm_amd_round_stats st;
             fill_stats(st, *R, round, cur->n, cur_nnz);
             st.nnz_out = -1; // (never counted: the rows went dense)
@@ -2620,6 +2783,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         g_last_rounds.push_back(st);
         spasm_logf("[echelonize] round %d\n[pivots] Faugère-Lachartre: %d pivots found [%.1fs]\n", round, R->n_leftmost, st.ms_pivots * 1e-3);
         if (R->n_open) spasm_logf("[pivots] ``Faugère-Lachartre on columns'': %d pivots found\n", R->n_open);
+        if (R->n_greedy) spasm_logf("[pivots] greedy alternating cycle-free search: %d pivots found\n", R->n_greedy);
         spasm_logf("Schur complement: %d * %d [%lld nz / density= %.3f], %.1fs%s\n", nnp, m - (int)U.pivcol.size(),
                    (long long)st.nnz_out, nnp > 0 && m > 0 ? (double)st.nnz_out / ((double)nnp * (double)m) : 0.0,
                    (st.ms_solve + st.ms_scatter) * 1e-3, nbatch > 1 ? " (in batches of rows)" : "");
@@ -3744,6 +3908,7 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
         }
         DevBuf<u64d> stage; // on device 0: another shard's keys, on their way into the minimum
         int round = 0;
+        bool extra_round_done = false;
         i64 last_nnz = -1;
         i64 finish_nnz = (i64)1 << 22;
         if (const char *e = getenv("SPASM_AMD_MULTI_FINISH_NNZ")) finish_nnz = std::max<i64>(atoll(e), 0); // tests: small remainders sharded too
@@ -3757,9 +3922,13 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
         std::vector<int> devs((size_t)nshards);
         for (int k = 0; k < nshards; k++) devs[(size_t)k] = dev_of(k);
         // does a dense matrix of `rows` local rows and `cols` columns fit a shard's device beside what the elimination needs?
+        // (no cap by shape here: the shards finish together BECAUSE one device does not hold the remainder -- config 3 / 4 leave
+        // 95k x 760k shorts = 144 GB per device of an 8-GPU node; 60 % of the free memory, beside the digit planes and the dense W)
         auto dense_fits = [&](i64 rows, i64 cols) {
             const double bytes = ((double)rows + 2048.0) * (double)((cols + 63) / 64 * 64) * (double)elem;
-            return bytes <= (double)dense_max_entries(elem) * (double)elem;
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+            return bytes <= 0.6 * (double)fr;
         };
         auto run_typed = [&](int C, const std::vector<const int *> &clists, auto &&build) {
             if (elem == 1) return dense_multi_run<signed char>(nshards, devs, F0, C, clists, build, U);
@@ -3853,7 +4022,12 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
                            free_cols > 0 ? (double)rows_left / (double)free_cols : 0.0, nshards);
                 if (dense_now()) { g_multi_finish = 2; break; }
             }
-            if (nnz_left <= finish_nnz || round >= opts->max_round || dense_enough) {
+            // max_round sparse rounds are over and the remainder is still sparse: the single-device engine would elect once more and
+            // estimate the density of that Schur complement before choosing its finish -- so do the shards, once
+            const bool spent = round >= opts->max_round;
+            const bool one_more = ddf_ok && spent && !extra_round_done && !dense_enough && nnz_left > finish_nnz;
+            if (one_more) extra_round_done = true;
+            if (!one_more && (nnz_left <= finish_nnz || spent || dense_enough)) {
                 // ---- hand-off: the remaining rows, under their original numbers, to the single-device engine on device 0
                 std::vector<struct spasm_csr *> parts((size_t)nshards, nullptr);
                 struct spasm_csr *rest = nullptr;

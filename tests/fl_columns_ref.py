@@ -83,3 +83,106 @@ def structural_pivots(rows, m, on_columns=True):
     nopen = len(out)
     out.extend(leftmost)
     return out, nopen
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The third search -- "greedy alternating cycle-free search" (reference README.md:23) -- as DESIGN.md section 2 words it:
+#   a pass (up to three, until one accepts nothing), for every non-empty row that is no pivot row and has at most 256 entries:
+#     reach     the pivots reachable from the row: those on the pivot columns it holds, then those on the pivot columns THEIR rows
+#               hold, and so on; a row that reaches more than 1024 pivots sits the pass out;
+#     touched   the columns without pivot that the rows of the reach hold;
+#     the row proposes the leftmost of its columns that carries no pivot and is not touched;
+#     per proposed column the smallest (row length, row number) wins;
+#     a winner is accepted unless some OTHER column of (its own pivot-free columns + touched) has a winner with a smaller key.
+#   Accepted rows are pivot rows from the next pass on.
+#   When the search found anything, all pivots of the round are numbered by descending level (0: the row holds no other pivot column;
+#   else 1 + the deepest level among the pivot columns it holds), ascending column inside a level.
+# ---------------------------------------------------------------------------------------------------------------------------
+GREEDY_PASSES = 3
+GR_MAXLEN = 256
+GR_BUDGET = 1024
+
+
+def greedy_extend(rows, m, pivots):
+    """pivots: [(column, row)] found so far (any numbering).  Returns (all pivots renumbered -- or `pivots` unchanged when the search
+    finds nothing --, number of pivots the search added)."""
+    cols = [[c for c, _ in r] for r in rows]
+    n = len(rows)
+    prow_of_col = {c: i for c, i in pivots}
+    is_piv = [False] * n
+    for _, i in pivots:
+        is_piv[i] = True
+    added = 0
+    for _ in range(GREEDY_PASSES):
+        proposal, full, winner = {}, {}, {}
+        for i, cs in enumerate(cols):
+            if is_piv[i] or not cs or len(cs) > GR_MAXLEN:
+                continue
+            reach, todo = set(), [prow_of_col[c] for c in cs if c in prow_of_col]
+            reach.update(todo)
+            while todo and len(reach) <= GR_BUDGET:
+                r = todo.pop()
+                for c in cols[r]:
+                    r2 = prow_of_col.get(c)
+                    if r2 is not None and r2 not in reach:
+                        reach.add(r2)
+                        todo.append(r2)
+            if len(reach) > GR_BUDGET:
+                continue
+            touched = {c for r in reach for c in cols[r] if c not in prow_of_col}
+            cand = [c for c in cs if c not in prow_of_col and c not in touched]
+            if not cand:
+                continue
+            j = min(cand)
+            proposal[i] = j
+            full[i] = touched | {c for c in cs if c not in prow_of_col}
+            key = (len(cs), i)
+            if j not in winner or key < winner[j]:
+                winner[j] = key
+        accepted = []
+        for i, j in proposal.items():
+            key = (len(cols[i]), i)
+            if winner[j] != key:
+                continue
+            if any(c != j and c in winner and winner[c] < key for c in full[i]):
+                continue
+            accepted.append((j, i))
+        if not accepted:
+            break
+        for j, i in accepted:
+            prow_of_col[j] = i
+            is_piv[i] = True
+        added += len(accepted)
+    if added == 0:
+        return list(pivots), 0
+    # levels (the pivot graph is acyclic: that is what the search guarantees)
+    level = {}
+
+    def lev(c):
+        stack = [c]
+        while stack:
+            x = stack[-1]
+            if x in level:
+                stack.pop()
+                continue
+            deps = [c2 for c2 in cols[prow_of_col[x]] if c2 != x and c2 in prow_of_col]
+            missing = [d for d in deps if d not in level]
+            if missing:
+                assert len(stack) <= len(prow_of_col), "cycle among the pivots"
+                stack.extend(missing)
+                continue
+            level[x] = 1 + max((level[d] for d in deps), default=-1)
+            stack.pop()
+        return level[c]
+
+    for c in prow_of_col:
+        lev(c)
+    order = sorted(prow_of_col, key=lambda c: (-level[c], c))
+    return [(c, prow_of_col[c]) for c in order], added
+
+
+def structural_pivots3(rows, m):
+    """All three searches of a sparse round: [(column, row)] in U's numbering, open-column pivots, greedy pivots."""
+    piv, nopen = structural_pivots(rows, m, on_columns=True)
+    out, ngreedy = greedy_extend(rows, m, piv)
+    return out, nopen, ngreedy

@@ -24,12 +24,14 @@ def pivots_of_first_round(lu, npiv0):
 
 
 @pytest.mark.parametrize("name,kind,n,m,kw,prime", CASES, ids=[c[0] for c in CASES])
-def test_oracle_takes_the_pivots_of_the_written_rule(S, O, name, kind, n, m, kw, prime):
+def test_oracle_takes_the_pivots_of_the_written_rule(S, O, monkeypatch, name, kind, n, m, kw, prime):
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xF1C2, **kw)
     want, nopen = fl_columns_ref.structural_pivots(A.rows(), m, on_columns=True)
     left, _ = fl_columns_ref.structural_pivots(A.rows(), m, on_columns=False)
     assert nopen > 0 or name == "macaulay_like", "the case must exercise the search"  # (nearly all columns of that one are closed)
+    monkeypatch.setenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH", "1")                         # the first two searches alone
     olu = O.echelonize(A, enable_greedy_pivot_search=True, max_round=1)
+    monkeypatch.delenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH")
     assert pivots_of_first_round(olu, len(want)) == want
     olu2 = O.echelonize(A, enable_greedy_pivot_search=False, max_round=1)
     assert pivots_of_first_round(olu2, len(left)) == left
@@ -37,3 +39,22 @@ def test_oracle_takes_the_pivots_of_the_written_rule(S, O, name, kind, n, m, kw,
     rows = A.rows()
     closed = {c for _, i in left for c, _ in rows[i]}
     assert all(c not in closed for c, _ in want[:nopen])
+
+
+@pytest.mark.parametrize("name,kind,n,m,kw,prime", CASES, ids=[c[0] for c in CASES])
+def test_oracle_takes_the_pivots_of_the_written_rule_with_the_cycle_free_search(S, O, name, kind, n, m, kw, prime):
+    """All three searches (leftmost, on columns, greedy cycle-free: tests/fl_columns_ref.py structural_pivots3) against the oracle's
+    round 0, pair for pair in U's numbering; and what the third search promises: the pivots are permutable to a triangle in the
+    order given (a pivot row only holds pivot columns of LATER pivots), every new pivot sits on a non-zero of its row."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xF1C2, **kw)
+    rows = A.rows()
+    want, nopen, ngreedy = fl_columns_ref.structural_pivots3(rows, m)
+    assert ngreedy > 0 or name == "macaulay_like", "the case must exercise the search"
+    olu = O.echelonize(A, enable_greedy_pivot_search=True, max_round=1)
+    assert pivots_of_first_round(olu, len(want)) == want
+    idx = {c: k for k, (c, _) in enumerate(want)}
+    assert len({i for _, i in want}) == len(want) == len(idx)
+    for k, (c, i) in enumerate(want):
+        cs = [c2 for c2, _ in rows[i]]
+        assert c in cs
+        assert all(idx[c2] > k for c2 in cs if c2 != c and c2 in idx)

@@ -171,10 +171,27 @@ def test_round0_pivots_match_the_independent_restatement(S, O, name, kind, n, m,
     """Un-circles the parity of the "FL on columns" search: the engine's round 0 and the oracle's are each compared with the
     plain-Python rule written from DESIGN.md section 2 -- same (column, row) pairs in the same numbering."""
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xF1C0, **kw)
-    want, nopen = fl_columns_ref.structural_pivots(A.rows(), m, on_columns=True)
+    want, nopen, ngreedy = fl_columns_ref.structural_pivots3(A.rows(), m)
     fact = S.echelonize(A, enable_greedy_pivot_search=True, enable_dense=False)
     r0 = S.last_rounds()[0]
-    assert (r0["npiv"], r0["npiv_open"]) == (len(want), nopen)
+    assert (r0["npiv"], r0["npiv_open"], r0["npiv_greedy"]) == (len(want), nopen, ngreedy)
     assert pivots_of_first_round(fact, len(want)) == want
     olu = O.echelonize(A, enable_greedy_pivot_search=True)
+    assert pivots_of_first_round(olu, len(want)) == want
+    assert S.factorization_verify(A, fact, 5)
+
+
+@pytest.mark.parametrize("name,kind,n,m,kw,prime", GREEDY_CASES, ids=[c[0] for c in GREEDY_CASES])
+def test_round0_pivots_without_the_cycle_free_search(S, O, monkeypatch, name, kind, n, m, kw, prime):
+    """The first two searches alone (SPASM_AMD_NO_CYCLE_FREE_SEARCH=1, read by engine and oracle): the numbering of round 2's tests --
+    open-column pivots first, then the leftmost ones by column -- is what a round keeps when the third search adds nothing."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xF1C0, **kw)
+    want, nopen = fl_columns_ref.structural_pivots(A.rows(), m, on_columns=True)
+    monkeypatch.setenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH", "1")
+    fact = S.echelonize(A, enable_greedy_pivot_search=True, enable_dense=False)
+    r0 = S.last_rounds()[0]
+    olu = O.echelonize(A, enable_greedy_pivot_search=True)
+    monkeypatch.delenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH")
+    assert (r0["npiv"], r0["npiv_open"], r0["npiv_greedy"]) == (len(want), nopen, 0)
+    assert pivots_of_first_round(fact, len(want)) == want
     assert pivots_of_first_round(olu, len(want)) == want

@@ -670,8 +670,8 @@ def test_fl_on_columns_takes_the_oracles_pivots(S, O, name, kind, n, m, kw, prim
     assert fact.r == olu.r == plain.r
     assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
     sparse_rounds = [r for r in rounds if r["round"] < 3]
-    assert sum(r["npiv_open"] for r in sparse_rounds) > 0, rounds            # the search found something
-    assert all(r["npiv_open"] == 0 for r in rounds if r["round"] >= 3)       # the finish keeps to leftmost entries
+    assert sum(r["npiv_open"] + r["npiv_greedy"] for r in sparse_rounds) > 0, rounds               # the searches found something
+    assert all(r["npiv_open"] + r["npiv_greedy"] == 0 for r in rounds if r["round"] >= 3)          # the finish keeps to leftmost entries
     k = sum(r["npiv"] for r in sparse_rounds)
     assert fact.U.rows()[:k] == olu.U.rows()[:k]                             # same pivot rows, same order, same values
     assert S.kernel(fact).rows() == O.kernel(olu).rows()
@@ -693,7 +693,8 @@ def test_fl_on_columns_finds_more_pivots_per_round(S, O):
     l = S.echelonize(A, enable_greedy_pivot_search=False)
     rl = S.last_rounds()
     assert g.r == l.r
-    assert rg[0]["npiv"] - rg[0]["npiv_open"] == rl[0]["npiv"]               # the leftmost election is the same
+    assert rg[0]["npiv"] - rg[0]["npiv_open"] - rg[0]["npiv_greedy"] == rl[0]["npiv"]   # the leftmost election is the same
+    assert rg[0]["npiv_greedy"] > 0.05 * rl[0]["npiv"], (rg[0], rl[0])                   # the third search adds its share
     assert rg[0]["npiv_open"] > 0.05 * rl[0]["npiv"], (rg[0], rl[0])
     assert len(rg) <= len(rl)
     assert S.factorization_verify(A, g, 3) and S.factorization_verify(A, l, 3)
@@ -898,3 +899,71 @@ def test_schur_round_w_build_long_dependency_lists(S, O, p):
     assert st["w_levels"] == 2 and st["w_long_rows"] > n1 // 3, (st["w_levels"], st["w_long_rows"])
     assert st["applications"] == info["applications"] and st["nnz_reduced"] == info["nnz_reduced"] and st["nnz_out"] == info["nnz_out"]
     assert Sc.rows() == So.rows()
+
+
+# ---- tall-and-skinny finish (enable_tall_and_skinny / tall_and_skinny_ratio, reference src/SpaSM.jl:327, :341; csrc/dense_tall.hpp) ------
+
+def _low_rank_rows(rng, rows, rank, m, p):
+    return (rng.integers(0, p, size=(rows, rank)).astype(np.int64).dot(rng.integers(0, p, size=(rank, m)).astype(np.int64))) % p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [127, 65521], ids=["one_digit", "two_digits"])
+@pytest.mark.parametrize("shape", ["slab_short_of_the_rank", "rank_below_the_columns", "slab_finds_every_column"])
+def test_tall_and_skinny_finish_dense_input(S, O, monkeypatch, p, shape):
+    """A dense remainder with many more rows than columns: a first slab of rows is eliminated, the others are reduced against its
+    reduced form in one step and only their residuals eliminated (dense_tall.hpp).  The three shapes: the slab's rows span only part
+    of the row space (the residuals carry pivots, also LEFT of pivots the slab found -- the pivot columns must still be the leading
+    columns of the whole row space); the whole matrix is rank deficient (columns without pivot at the end); the slab has full column
+    rank (the other rows are never looked at).  Rank, pivot columns and kernel of the oracle; several row batches; verified."""
+    rng = np.random.default_rng(11)
+    m = 400
+    if shape == "slab_short_of_the_rank":
+        M = np.vstack([_low_rank_rows(rng, 320, 100, m, p), rng.integers(0, p, size=(900, m))])
+        M[:, 37] = 0
+        M[400:, 37] = rng.integers(1, p, size=M.shape[0] - 400)          # a column the slab cannot see
+    elif shape == "rank_below_the_columns":
+        M = np.vstack([_low_rank_rows(rng, 320, 90, m, p), _low_rank_rows(rng, 900, 150, m, p)])
+    else:
+        M = rng.integers(0, p, size=(1500, m))
+    A = S.CSR(M.astype(np.int64).T.copy(), prime=p)
+    olu = O.echelonize(A, **LM)
+    monkeypatch.setenv("SPASM_AMD_TALL_SLAB", "320" if shape != "slab_finds_every_column" else "448")
+    monkeypatch.setenv("SPASM_AMD_TALL_BATCH", "256")
+    fact = S.echelonize(A, verbose=False, **LM)
+    monkeypatch.setenv("SPASM_AMD_TALL", "0")
+    plain = S.echelonize(A, **LM)                                       # the same without the strategy
+    for k in ("SPASM_AMD_TALL_SLAB", "SPASM_AMD_TALL_BATCH", "SPASM_AMD_TALL"):
+        monkeypatch.delenv(k)
+    assert fact.r == olu.r == plain.r
+    assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist() == np.asarray(plain.qinv >= 0).tolist()
+    assert S.kernel(fact).rows() == O.kernel(olu).rows()
+    assert S.factorization_verify(A, fact, 9)
+    pr = np.asarray(fact.p)[: fact.r]
+    assert len(set(pr.tolist())) == fact.r
+    # enable_tall_and_skinny = 0 switches the strategy off like the reference's option
+    off = S.echelonize(A, enable_tall_and_skinny=False, **LM)
+    assert off.U.rows() == plain.U.rows()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(), dict(SPASM_AMD_MEM_BUDGET_MB="4")], ids=["W_whole", "W_in_column_slabs"])
+def test_tall_and_skinny_finish_of_a_schur_complement(S, O, monkeypatch, env):
+    """The same strategy fed by the Schur rows of a round through the dense W (Macaulay-like: config 5's shape), rows materialised a
+    slab / a batch at a time."""
+    A = S.synth_csr(2, 6000, 1500, row_nnz=40, prime=127, seed=0x7A11)
+    olu = O.echelonize(A, **LM)
+    monkeypatch.setenv("SPASM_AMD_TALL", "1")
+    monkeypatch.setenv("SPASM_AMD_TALL_SLAB", "256")
+    monkeypatch.setenv("SPASM_AMD_TALL_BATCH", "512")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fact = S.echelonize(A, sparsity_threshold=0.1, **LM)
+    rounds = S.last_rounds()
+    for k in ["SPASM_AMD_TALL", "SPASM_AMD_TALL_SLAB", "SPASM_AMD_TALL_BATCH"] + list(env):
+        monkeypatch.delenv(k)
+    assert rounds[-1]["nnz_out"] == -1, rounds                          # the round went straight to the dense finish
+    assert fact.r == olu.r
+    assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
+    assert S.kernel(fact).rows() == O.kernel(olu).rows()
+    assert S.factorization_verify(A, fact, 9)
