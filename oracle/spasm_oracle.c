@@ -302,6 +302,9 @@ static void emit_pivot_row(const struct spasm_csr *A, int i, int j, struct spasm
  *     proposal   = the leftmost pivot-free column of row i that is not touched; per column the smallest (length, row) wins;
  *     a winner is accepted unless another column of (own pivot-free columns + touched) has a winner with a smaller key.
  * pc / pr: the pivots (column, row), np of them on entry; the new ones are appended.  Returns how many were added. */
+#define GREEDY_REACH_MAX_DEFAULT 2
+#define GREEDY_OCC_MAX_DEFAULT 1
+
 /* breadth-first search from row i through the pivot rows: stamp[r] = mark for the rows reached (queue[0 .. *ntail) lists them).
  * Returns 0 when more than `budget` pivots are reached. */
 static int greedy_search(const struct spasm_csr *A, int i, int mark, const int *prow_of_col, int *stamp, int *queue, int budget, int *ntail)
@@ -333,7 +336,13 @@ static int greedy_search(const struct spasm_csr *A, int i, int mark, const int *
 static int greedy_extend(const struct spasm_csr *A, int *pc, int *pr, int np)
 {
     enum { GREEDY_PASSES = 3, GR_MAXLEN = 256, GR_BUDGET = 1024 };
+    /* the two limits of csrc/greedy.hpp (same defaults, same environment variables): rows that reach more pivots sit the pass out,
+     * columns more rows without pivot hold are no candidates */
+    int reach_max = GREEDY_REACH_MAX_DEFAULT, occ_max = GREEDY_OCC_MAX_DEFAULT;
+    { const char *e = getenv("SPASM_AMD_GREEDY_REACH_MAX"); if (e) { reach_max = atoi(e); if (reach_max > GR_BUDGET) reach_max = GR_BUDGET; if (reach_max < 0) reach_max = 0; } }
+    { const char *e = getenv("SPASM_AMD_GREEDY_OCC_MAX"); if (e) { occ_max = atoi(e); if (occ_max < 1) occ_max = 1; } }
     const int n = A->n, m = A->m;
+    int *occ = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
     int *prow_of_col = malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
     char *taken = calloc((size_t)(n > 0 ? n : 1), 1);
     int *stamp = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));   /* row reached by the search numbered stamp[.] */
@@ -347,21 +356,23 @@ static int greedy_extend(const struct spasm_csr *A, int *pc, int *pr, int np)
     for (int i = 0; i < n; i++) stamp[i] = -1;
     for (int t = 0; t < np; t++) { prow_of_col[pc[t]] = pr[t]; taken[pr[t]] = 1; }
     for (int pass = 1; pass <= GREEDY_PASSES; pass++) {
-        for (int j = 0; j < m; j++) winner[j] = -1;
+        for (int j = 0; j < m; j++) { winner[j] = -1; occ[j] = 0; }
+        for (int i = 0; i < n; i++)
+            if (!taken[i]) for (i64 k = A->p[i]; k < A->p[i + 1]; k++) occ[A->j[k]]++;
         for (int i = 0; i < n; i++) {
             prop[i] = -1;
             i64 len = A->p[i + 1] - A->p[i];
             if (taken[i] || len == 0 || len > GR_MAXLEN) continue;
             int tail = 0;
             mark++;
-            if (!greedy_search(A, i, mark, prow_of_col, stamp, queue, GR_BUDGET, &tail)) continue;
+            if (!greedy_search(A, i, mark, prow_of_col, stamp, queue, reach_max, &tail)) continue;
             for (int t = 0; t < tail; t++)
                 for (i64 k = A->p[queue[t]]; k < A->p[queue[t] + 1]; k++) cstamp[A->j[k]] = mark; /* (pivot columns too: harmless) */
             int best = -1;
             for (i64 k = A->p[i]; k < A->p[i + 1]; k++) {
                 int c = A->j[k];
-                if (prow_of_col[c] >= 0 || cstamp[c] == mark) continue;
-                if (best < 0 || c < best) best = c;
+                if (prow_of_col[c] >= 0 || cstamp[c] == mark || occ[c] > occ_max) continue;
+                if (best < 0 || occ[c] < occ[best] || (occ[c] == occ[best] && c < best)) best = c;
             }
             if (best < 0) continue;
             prop[i] = best;
@@ -377,7 +388,7 @@ static int greedy_extend(const struct spasm_csr *A, int *pc, int *pr, int np)
             if (winner[j] != key) continue;
             int tail = 0;
             mark++;
-            if (!greedy_search(A, i, mark, prow_of_col, stamp, queue, GR_BUDGET, &tail)) continue;
+            if (!greedy_search(A, i, mark, prow_of_col, stamp, queue, reach_max, &tail)) continue;
             int rejected = 0;
             /* full(i) = the pivot-free columns of row i and of the rows it reaches */
             for (int t = -1; t < tail && !rejected; t++) {
@@ -399,7 +410,7 @@ static int greedy_extend(const struct spasm_csr *A, int *pc, int *pr, int np)
         }
         if (nacc == 0) break;
     }
-    free(prow_of_col); free(taken); free(stamp); free(cstamp); free(queue); free(prop); free(acc); free(winner);
+    free(prow_of_col); free(taken); free(stamp); free(cstamp); free(queue); free(prop); free(acc); free(winner); free(occ);
     return added;
 }
 

@@ -901,26 +901,44 @@ __global__ __launch_bounds__(256) void k_tall_gather_cols(int nrows, const int *
     for (int j = threadIdx.x; j < (int)ldo; j += 256) out[(i64d)i * ldo + j] = j < ncols ? D[src + cols[j]] : (DT)0;
 }
 
-// back substitution inside a block of nb pivots (rows t0 .. t0 + nb of Z, pivot rows prow[t], pivot columns pcol[t]):
-// z_t -= sum_{t < s < t0 + nb} D[prow[t]][pcol[s]] z_s, t descending.  One workgroup per 64 columns of Z, one lane per column; the
-// coefficients of row t are read by all lanes alike (a broadcast load).
+// back substitution inside a block of nb <= 64 pivots (rows t0 .. t0 + nb of Z, pivot rows prow[t], pivot columns pcol[t]):
+// z_t -= sum_{t < s < t0 + nb} D[prow[t]][pcol[s]] z_s, t descending.  One workgroup per 16 columns of Z: thread (tx, ty) owns column
+// tx and the rows 4 ty .. 4 ty + 3; the 64 x 64 coefficients and the tile of Z live in LDS.  Right-looking: once z_t is final every
+// row above it takes its term at once (one barrier per t; the sums stay in 64 bits: at most 63 terms below 2^30).
 template <typename DT>
-__global__ __launch_bounds__(64) void k_tall_backsub(int t0, int nb, int ncols, ZpField F, const DT *__restrict__ D, i64d ldc, const int *__restrict__ prow,
-                                                     const int *__restrict__ pcol, DT *__restrict__ Z, i64d ldz)
+__global__ __launch_bounds__(256) void k_tall_backsub(int t0, int nb, int ncols, ZpField F, const DT *__restrict__ D, i64d ldc, const int *__restrict__ prow,
+                                                      const int *__restrict__ pcol, DT *__restrict__ Z, i64d ldz)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= ncols) return;
-    for (int t = t0 + nb - 2; t >= t0; t--) {
-        const i64d urow = (i64d)prow[t] * ldc;
-        long long acc = (long long)Z[(i64d)t * ldz + j];
-        int terms = 0;
-        for (int s = t + 1; s < t0 + nb; s++) {
-            const int u = (int)D[urow + pcol[s]];
-            if (u == 0) continue;
-            acc -= (long long)u * (long long)Z[(i64d)s * ldz + j]; // |term| < 2^30 (p < 2^16)
-            if (++terms == (1 << 20)) { acc = (long long)zp_reduce(F, acc); terms = 0; }
+    __shared__ int s_u[64][65];
+    __shared__ int s_z[64][16];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int j = blockIdx.x * 16 + tx;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int a = idx >> 6, b = idx & 63;
+        s_u[a][b] = (a < nb && b < nb && b > a) ? (int)D[(i64d)prow[t0 + a] * ldc + pcol[t0 + b]] : 0;
+    }
+    long long acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int a = 4 * ty + r;
+        acc[r] = (a < nb && j < ncols) ? (long long)Z[(i64d)(t0 + a) * ldz + j] : 0;
+    }
+    __syncthreads();
+    for (int t = nb - 1; t >= 0; t--) {
+        if ((t >> 2) == ty) s_z[t][tx] = zp_reduce(F, acc[t & 3]); // (uniform per thread row group: the owner publishes z_t)
+        __syncthreads();
+        const int zt = s_z[t][tx];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int a = 4 * ty + r;
+            if (a < t) acc[r] -= (long long)s_u[a][t] * (long long)zt;
         }
-        Z[(i64d)t * ldz + j] = (DT)zp_reduce(F, acc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int a = 4 * ty + r;
+        if (a < nb && j < ncols) Z[(i64d)(t0 + a) * ldz + j] = (DT)s_z[a][tx];
     }
 }
 

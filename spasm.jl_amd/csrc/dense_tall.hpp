@@ -97,18 +97,22 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     D1.zero(s);
     pc1.alloc((size_t)C + 1);
     src.fill(0, R1, D1.p);
+    HIPCHK(hipStreamSynchronize(s));
+    const double tf1 = spasm_wtime() - t0;
     if (!dense_eliminate_i8(D1, R1, C, ldc, F, pc1, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
     HIPCHK(hipStreamSynchronize(s));
+    const double te1 = spasm_wtime() - t0 - tf1;
     const int r1 = dense_extract_U(D1.p, C, ldc, pc1.p, clist, row_orig, U, s);
     ts.r1 = r1;
     ts.t_slab = spasm_wtime() - t0;
+    const double tu1 = ts.t_slab - tf1 - te1;
     const int R2 = R - R1;
     const int f = C - r1;
     ts.f = f;
     if (R2 <= 0 || f <= 0) {
         src.done();
-        spasm_logf("[echelonize/dense] tall and skinny: %d x %d, first slab of %d rows: %d pivots%s [%.2fs]\n", R, C, R1, r1,
-                   f <= 0 && R2 > 0 ? " = every column: the other rows cannot add any" : "", ts.t_slab);
+        spasm_logf("[echelonize/dense] tall and skinny: %d x %d, first slab of %d rows: %d pivots%s [rows %.2fs, elimination %.2fs, rows of U to the host %.2fs]\n", R, C,
+                   R1, r1, f <= 0 && R2 > 0 ? " = every column: the other rows cannot add any" : "", tf1, te1, tu1);
         return r1;
     }
     // ---- 2. columns with / without pivot; Z = the reduced form of the slab's pivot rows on the columns without
@@ -139,7 +143,7 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
             for (int i1 = b1; i1 > b0;) {
                 const int i0 = std::max(b0, (i1 - 1) / IB * IB), ni = i1 - i0;
                 if (i1 < b1) W.gemm_sub(Z.p + (size_t)i0 * (size_t)ldz, ldz, ni, D1.p, ldc, prow.p + i0, pcol.p + i1, b1 - i1, Z.p + (size_t)i1 * (size_t)ldz, ldz, f);
-                hipLaunchKernelGGL((k_tall_backsub<DT>), dim3(cdiv(f, 64)), dim3(64), 0, s, i0, ni, f, F, D1.p, (i64d)ldc, prow.p, pcol.p, Z.p, (i64d)ldz);
+                hipLaunchKernelGGL((k_tall_backsub<DT>), dim3(cdiv(f, 16)), dim3(256), 0, s, i0, ni, f, F, D1.p, (i64d)ldc, prow.p, pcol.p, Z.p, (i64d)ldz);
                 i1 = i0;
             }
             HIPCHK(hipGetLastError());
@@ -155,15 +159,20 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     T.alloc((size_t)R2 * (size_t)ldz);
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
-    i64 RB = std::max<i64>(4096, (i64)(fr / 4) / ((i64)ldc * (i64)sizeof(DT)) / 128 * 128);
+    // (at most 128k rows at a time: a batch buffer of tens of GB costs more to allocate and to clear than the launches of more batches)
+    i64 RB = std::min<i64>(131072, std::max<i64>(4096, (i64)(fr / 4) / ((i64)ldc * (i64)sizeof(DT)) / 128 * 128));
     if (const char *e = getenv("SPASM_AMD_TALL_BATCH")) RB = std::max<i64>(128, atoll(e) / 128 * 128); // tests: several batches
     RB = std::min<i64>(RB, ((i64)R2 + 127) / 128 * 128);
     DevBuf<DT> Db;
     Db.alloc((size_t)RB * (size_t)ldc);
+    double tf2 = 0;
     for (i64 off = 0; off < R2; off += RB) {
         const int cnt = (int)std::min<i64>(RB, R2 - off);
+        const double tb = spasm_wtime();
         HIPCHK(hipMemsetAsync(Db.p, 0, (size_t)cnt * (size_t)ldc * sizeof(DT), s));
         src.fill(R1 + (int)off, cnt, Db.p);
+        HIPCHK(hipStreamSynchronize(s));
+        tf2 += spasm_wtime() - tb;
         DT *Tb = T.p + (size_t)off * (size_t)ldz;
         hipLaunchKernelGGL((k_tall_gather_cols<DT>), dim3(cnt), dim3(256), 0, s, cnt, (const int *)nullptr, Db.p, (i64d)ldc, fcol.p, f, Tb, (i64d)ldz);
         HIPCHK(hipGetLastError());
@@ -184,7 +193,8 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     const int r2 = dense_extract_U(T.p, f, ldz, pc2.p, fclist.p, row_orig + R1, U, s);
     ts.r2 = r2;
     ts.t_tail = spasm_wtime() - t3;
-    spasm_logf("[echelonize/dense] tall and skinny: %d x %d; first slab of %d rows: %d pivots [%.2fs]; reduced form on the %d columns left [%.2fs]; %d rows reduced in one step "
-               "[%.2fs]; their residuals: %d pivots [%.2fs]\n", R, C, R1, r1, ts.t_slab, f, ts.t_z, R2, ts.t_resid, r2, ts.t_tail);
+    spasm_logf("[echelonize/dense] tall and skinny: %d x %d; first slab of %d rows: %d pivots [rows %.2fs, elimination %.2fs, rows of U to the host %.2fs]; reduced form on the "
+               "%d columns left [%.2fs]; %d rows reduced in one step [rows %.2fs, reduction %.2fs]; their residuals: %d pivots [%.2fs]\n", R, C, R1, r1, tf1, te1, tu1, f, ts.t_z,
+               R2, tf2, ts.t_resid - tf2, r2, ts.t_tail);
     return r1 + r2;
 }

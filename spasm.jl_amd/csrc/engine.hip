@@ -436,12 +436,18 @@ struct Round {
         hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, 0, 1, n, pivrow.p, is_piv.p);
         HIPCHK(hipGetLastError());
         int nnew = 0;
+        int reach_max = GREEDY_REACH_MAX_DEFAULT, occ_max = GREEDY_OCC_MAX_DEFAULT;
+        if (const char *e = getenv("SPASM_AMD_GREEDY_REACH_MAX")) reach_max = std::min(GR_BUDGET, std::max(0, atoi(e)));
+        if (const char *e = getenv("SPASM_AMD_GREEDY_OCC_MAX")) occ_max = std::max(1, atoi(e));
+        colcnt.ensure((size_t)m + 1);
         for (int pass = 1; pass <= GREEDY_PASSES; pass++) {
+            HIPCHK(hipMemsetAsync(colcnt.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+            hipLaunchKernelGGL(k_col_histogram, dim3(cdiv((i64)n * 8, 256)), dim3(256), 0, stream, n, is_piv.p, A.start.p, A.len.p, A.ent.p, colcnt.p);
             hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best2.p);
             hipLaunchKernelGGL((k_greedy<1>), dim3(cdiv(n, GR_WPB)), dim3(64 * GR_WPB), 0, stream, n, is_piv.p, A.start.p, A.len.p, A.ent.p, qinv_r.p, pivrow.p, best2.p,
-                               prop.p, gr_accept.p);
+                               prop.p, gr_accept.p, colcnt.p, occ_max, reach_max);
             hipLaunchKernelGGL((k_greedy<2>), dim3(cdiv(n, GR_WPB)), dim3(64 * GR_WPB), 0, stream, n, is_piv.p, A.start.p, A.len.p, A.ent.p, qinv_r.p, pivrow.p, best2.p,
-                               prop.p, gr_accept.p);
+                               prop.p, gr_accept.p, colcnt.p, occ_max, reach_max);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemsetAsync(gr_accept.p + n, 0, sizeof(int), stream));
             scan.exclusive(gr_accept.p, gr_ascan.p, (size_t)n + 1, stream);

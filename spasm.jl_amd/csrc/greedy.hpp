@@ -12,7 +12,9 @@
 //   entries:
 //     reach(i)    the pivots reachable from row i; a row that reaches more than GR_BUDGET pivots sits the pass out;
 //     touched(i)  the columns without pivot that the rows of reach(i) hold;
-//     candidates  the columns of row i without pivot that are not in touched(i); the row PROPOSES the leftmost one, j*(i);
+//     candidates  the columns of row i without pivot that are not in touched(i) and that at most GREEDY_OCC_MAX rows without pivot
+//                 hold (occ[c], counted over the rows that are no pivot rows at the start of the pass); the row PROPOSES the one of
+//                 smallest occupancy (ties: leftmost), j*(i);
 //     winner[c]   per proposed column the smallest key (row length, row) among its proposers;
 //     a winner x is ACCEPTED unless some column c != j*(x) of  full(x) = (columns of row x without pivot) + touched(x)  has a
 //     winner with a SMALLER key: among the accepted rows an edge x -> y (column j*(y) in full(x)) then always goes to a larger key,
@@ -31,7 +33,14 @@
 
 #define GREEDY_PASSES 3
 #define GR_MAXLEN 256     // longest row that searches (its columns live in LDS)
-#define GR_BUDGET 1024    // most pivots a searching row may reach
+#define GR_BUDGET 1024    // most pivots a searching row may reach: capacity of the queue (the limit in force is GREEDY_REACH_MAX)
+// The two limits that keep the search from buying pivots with fill-in (measured, DESIGN.md section 2: without them the Schur
+// complement of config 3 at 1/4 grows 13-fold for 806 more pivots): a pivot on column c must be applied to every row that holds c,
+// directly or through the pivot rows that hold it, and it drags the whole reach of its row along.  Defaults: free pivots only.
+//   GREEDY_REACH_MAX  a row that reaches more pivots than this sits the pass out   (env SPASM_AMD_GREEDY_REACH_MAX, <= GR_BUDGET)
+//   GREEDY_OCC_MAX    a column more rows without pivot than this hold is no candidate  (env SPASM_AMD_GREEDY_OCC_MAX)
+#define GREEDY_REACH_MAX_DEFAULT 2
+#define GREEDY_OCC_MAX_DEFAULT 1
 #define GR_VIS 2048       // slots of the visited set (load <= 1/2)
 #define GR_OWN 512        // slots of the table of the row's own pivot-free columns
 #define GR_WPB 4
@@ -50,7 +59,8 @@ __device__ __forceinline__ unsigned gr_hash(int x) { return (unsigned)x * 265443
 template <int MODE>
 __global__ __launch_bounds__(64 * GR_WPB) void k_greedy(int n, const int *__restrict__ is_piv, const i64d *__restrict__ start, const int *__restrict__ len,
                                                         const int2 *__restrict__ ent, const int *__restrict__ qinv_r, const int *__restrict__ pivrow,
-                                                        u64d *__restrict__ best2, int *__restrict__ prop, int *__restrict__ accept)
+                                                        u64d *__restrict__ best2, int *__restrict__ prop, int *__restrict__ accept,
+                                                        const int *__restrict__ colcnt, int occ_max, int reach_max)
 {
     __shared__ GreedyWave s_w[GR_WPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(64 * GR_WPB) void k_greedy(int n, const int *__rest
             if (old == q) return;
             if (old == -1) {
                 const int pos = atomicAdd(&W.tail, 1);
-                if (pos < GR_BUDGET) v_queue[pos] = q;
+                if (pos < reach_max) v_queue[pos] = q;
                 else *v_overflow = 1;
                 return;
             }
@@ -105,8 +115,11 @@ __global__ __launch_bounds__(64 * GR_WPB) void k_greedy(int n, const int *__rest
         else if (MODE == 1) {
             unsigned h = gr_hash(c) & (GR_OWN - 1);
             while (atomicCAS(&W.own[h], -1, c) != -1) h = (h + 1) & (GR_OWN - 1); // (the columns of a row are distinct)
-            v_alive[h] = 1;
-            atomicAdd(&W.nalive, 1);
+            // (a column more than occ_max rows without pivot hold is no candidate: its pivot would have to be applied to all of them)
+            if (colcnt[c] <= occ_max) {
+                v_alive[h] = 1;
+                atomicAdd(&W.nalive, 1);
+            }
         } else if (c != jstar && best2[c] < mykey) *v_reject = 1;
     }
     __builtin_amdgcn_wave_barrier();
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(64 * GR_WPB) void k_greedy(int n, const int *__rest
     const int team = lane >> 4, tl = lane & 15;
     int head = 0;
     for (;;) {
-        const int tail = min(*v_tail, GR_BUDGET);
+        const int tail = min(*v_tail, reach_max);
         if (head >= tail || *v_overflow) break;
         if (MODE == 1 && *v_nalive <= 0) break;
         if (MODE == 2 && *v_reject) break;
@@ -144,13 +157,14 @@ __global__ __launch_bounds__(64 * GR_WPB) void k_greedy(int n, const int *__rest
     }
     __builtin_amdgcn_wave_barrier();
     if (MODE == 1) {
-        int best = 0x7fffffff;
+        // the surviving candidate of smallest occupancy (ties: leftmost)
+        u64d bestk = ~0ull;
         if (!*v_overflow && *v_nalive > 0)
             for (int k = lane; k < GR_OWN; k += 64)
-                if (v_alive[k]) best = min(best, v_own[k]);
-        best = wave_min_i32(best);
+                if (v_alive[k]) bestk = min(bestk, ((u64d)(unsigned)colcnt[v_own[k]] << 32) | (u64d)(unsigned)v_own[k]);
+        for (int o = 32; o > 0; o >>= 1) bestk = min(bestk, (u64d)__shfl_xor((long long)bestk, o));
         if (lane == 0) {
-            const int choice = best == 0x7fffffff ? -1 : best;
+            const int choice = bestk == ~0ull ? -1 : (int)(unsigned)(bestk & 0xffffffffull);
             prop[i] = choice;
             if (choice >= 0) atomicMin(&best2[choice], mykey);
         }

@@ -89,9 +89,11 @@ def structural_pivots(rows, m, on_columns=True):
 # The third search -- "greedy alternating cycle-free search" (reference README.md:23) -- as DESIGN.md section 2 words it:
 #   a pass (up to three, until one accepts nothing), for every non-empty row that is no pivot row and has at most 256 entries:
 #     reach     the pivots reachable from the row: those on the pivot columns it holds, then those on the pivot columns THEIR rows
-#               hold, and so on; a row that reaches more than 1024 pivots sits the pass out;
+#               hold, and so on; a row that reaches more than GREEDY_REACH_MAX pivots sits the pass out;
 #     touched   the columns without pivot that the rows of the reach hold;
-#     the row proposes the leftmost of its columns that carries no pivot and is not touched;
+#     occ[c]    the number of rows that are no pivot rows (at the start of the pass) and hold column c;
+#     the row proposes, among its columns that carry no pivot, are not touched and have occ <= GREEDY_OCC_MAX, the one of smallest
+#     occ (ties: leftmost);
 #     per proposed column the smallest (row length, row number) wins;
 #     a winner is accepted unless some OTHER column of (its own pivot-free columns + touched) has a winner with a smaller key.
 #   Accepted rows are pivot rows from the next pass on.
@@ -101,6 +103,17 @@ def structural_pivots(rows, m, on_columns=True):
 GREEDY_PASSES = 3
 GR_MAXLEN = 256
 GR_BUDGET = 1024
+GREEDY_REACH_MAX_DEFAULT = 2
+GREEDY_OCC_MAX_DEFAULT = 1
+
+
+def _limits():
+    """The two limits of the search, with the environment variables the engine and the oracle read."""
+    import os
+
+    reach = min(GR_BUDGET, max(0, int(os.environ.get("SPASM_AMD_GREEDY_REACH_MAX", GREEDY_REACH_MAX_DEFAULT))))
+    occ = max(1, int(os.environ.get("SPASM_AMD_GREEDY_OCC_MAX", GREEDY_OCC_MAX_DEFAULT)))
+    return reach, occ
 
 
 def greedy_extend(rows, m, pivots):
@@ -113,27 +126,33 @@ def greedy_extend(rows, m, pivots):
     for _, i in pivots:
         is_piv[i] = True
     added = 0
+    reach_max, occ_max = _limits()
     for _ in range(GREEDY_PASSES):
         proposal, full, winner = {}, {}, {}
+        occ = {}
+        for i, cs in enumerate(cols):
+            if not is_piv[i]:
+                for c in cs:
+                    occ[c] = occ.get(c, 0) + 1
         for i, cs in enumerate(cols):
             if is_piv[i] or not cs or len(cs) > GR_MAXLEN:
                 continue
             reach, todo = set(), [prow_of_col[c] for c in cs if c in prow_of_col]
             reach.update(todo)
-            while todo and len(reach) <= GR_BUDGET:
+            while todo and len(reach) <= reach_max:
                 r = todo.pop()
                 for c in cols[r]:
                     r2 = prow_of_col.get(c)
                     if r2 is not None and r2 not in reach:
                         reach.add(r2)
                         todo.append(r2)
-            if len(reach) > GR_BUDGET:
+            if len(reach) > reach_max:
                 continue
             touched = {c for r in reach for c in cols[r] if c not in prow_of_col}
-            cand = [c for c in cs if c not in prow_of_col and c not in touched]
+            cand = [c for c in cs if c not in prow_of_col and c not in touched and occ[c] <= occ_max]
             if not cand:
                 continue
-            j = min(cand)
+            j = min(cand, key=lambda c: (occ[c], c))
             proposal[i] = j
             full[i] = touched | {c for c in cs if c not in prow_of_col}
             key = (len(cs), i)

@@ -41,15 +41,25 @@ def test_oracle_takes_the_pivots_of_the_written_rule(S, O, monkeypatch, name, ki
     assert all(c not in closed for c, _ in want[:nopen])
 
 
+# the two limits of the third search: the defaults (free pivots only), and wide open (libspasm's search has none)
+GREEDY_LIMITS = [dict(), dict(SPASM_AMD_GREEDY_REACH_MAX="1024", SPASM_AMD_GREEDY_OCC_MAX="2147483647"),
+                 dict(SPASM_AMD_GREEDY_REACH_MAX="16", SPASM_AMD_GREEDY_OCC_MAX="3")]
+GREEDY_LIMIT_IDS = ["default_limits", "no_limits", "reach16_occ3"]
+
+
+@pytest.mark.parametrize("limits", GREEDY_LIMITS, ids=GREEDY_LIMIT_IDS)
 @pytest.mark.parametrize("name,kind,n,m,kw,prime", CASES, ids=[c[0] for c in CASES])
-def test_oracle_takes_the_pivots_of_the_written_rule_with_the_cycle_free_search(S, O, name, kind, n, m, kw, prime):
+def test_oracle_takes_the_pivots_of_the_written_rule_with_the_cycle_free_search(S, O, monkeypatch, name, kind, n, m, kw, prime, limits):
     """All three searches (leftmost, on columns, greedy cycle-free: tests/fl_columns_ref.py structural_pivots3) against the oracle's
     round 0, pair for pair in U's numbering; and what the third search promises: the pivots are permutable to a triangle in the
     order given (a pivot row only holds pivot columns of LATER pivots), every new pivot sits on a non-zero of its row."""
+    for k, v in limits.items():
+        monkeypatch.setenv(k, v)
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xF1C2, **kw)
     rows = A.rows()
     want, nopen, ngreedy = fl_columns_ref.structural_pivots3(rows, m)
-    assert ngreedy > 0 or name == "macaulay_like", "the case must exercise the search"
+    if "SPASM_AMD_GREEDY_OCC_MAX" in limits:
+        assert ngreedy > 0 or name == "macaulay_like", "the case must exercise the search"
     olu = O.echelonize(A, enable_greedy_pivot_search=True, max_round=1)
     assert pivots_of_first_round(olu, len(want)) == want
     idx = {c: k for k, (c, _) in enumerate(want)}

@@ -166,12 +166,21 @@ GREEDY_CASES = [
 ]
 
 
+GREEDY_LIMITS = [dict(), dict(SPASM_AMD_GREEDY_REACH_MAX="1024", SPASM_AMD_GREEDY_OCC_MAX="2147483647"),
+                 dict(SPASM_AMD_GREEDY_REACH_MAX="16", SPASM_AMD_GREEDY_OCC_MAX="3")]
+
+
+@pytest.mark.parametrize("limits", GREEDY_LIMITS, ids=["default_limits", "no_limits", "reach16_occ3"])
 @pytest.mark.parametrize("name,kind,n,m,kw,prime", GREEDY_CASES, ids=[c[0] for c in GREEDY_CASES])
-def test_round0_pivots_match_the_independent_restatement(S, O, name, kind, n, m, kw, prime):
+def test_round0_pivots_match_the_independent_restatement(S, O, monkeypatch, name, kind, n, m, kw, prime, limits):
     """Un-circles the parity of the "FL on columns" search: the engine's round 0 and the oracle's are each compared with the
     plain-Python rule written from DESIGN.md section 2 -- same (column, row) pairs in the same numbering."""
+    for k, v in limits.items():                                # (the engine, the oracle and the Python rule read the same variables)
+        monkeypatch.setenv(k, v)
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xF1C0, **kw)
     want, nopen, ngreedy = fl_columns_ref.structural_pivots3(A.rows(), m)
+    if "SPASM_AMD_GREEDY_OCC_MAX" in limits:
+        assert ngreedy > 0 or name == "macaulay_like"          # the case must exercise the search
     fact = S.echelonize(A, enable_greedy_pivot_search=True, enable_dense=False)
     r0 = S.last_rounds()[0]
     assert (r0["npiv"], r0["npiv_open"], r0["npiv_greedy"]) == (len(want), nopen, ngreedy)

@@ -694,7 +694,6 @@ def test_fl_on_columns_finds_more_pivots_per_round(S, O):
     rl = S.last_rounds()
     assert g.r == l.r
     assert rg[0]["npiv"] - rg[0]["npiv_open"] - rg[0]["npiv_greedy"] == rl[0]["npiv"]   # the leftmost election is the same
-    assert rg[0]["npiv_greedy"] > 0.05 * rl[0]["npiv"], (rg[0], rl[0])                   # the third search adds its share
     assert rg[0]["npiv_open"] > 0.05 * rl[0]["npiv"], (rg[0], rl[0])
     assert len(rg) <= len(rl)
     assert S.factorization_verify(A, g, 3) and S.factorization_verify(A, l, 3)
