@@ -99,10 +99,13 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     src.fill(0, R1, D1.p);
     HIPCHK(hipStreamSynchronize(s));
     const double tf1 = spasm_wtime() - t0;
-    if (!dense_eliminate_i8(D1, R1, C, ldc, F, pc1, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
+    UStreamer us; // (the slab's rows of U leave for the host block by block while it is eliminated)
+    us.init(D1.p, C, ldc, pc1.p, clist, row_orig, U);
+    if (!dense_eliminate_i8(D1, R1, C, ldc, F, pc1, s, &us)) throw EngineError("dense finish: shape outside the panel kernel's range");
     HIPCHK(hipStreamSynchronize(s));
     const double te1 = spasm_wtime() - t0 - tf1;
-    const int r1 = dense_extract_U(D1.p, C, ldc, pc1.p, clist, row_orig, U, s);
+    us.template take<DT>(C);
+    const int r1 = us.found;
     ts.r1 = r1;
     ts.t_slab = spasm_wtime() - t0;
     const double tu1 = ts.t_slab - tf1 - te1;
@@ -111,7 +114,7 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     ts.f = f;
     if (R2 <= 0 || f <= 0) {
         src.done();
-        spasm_logf("[echelonize/dense] tall and skinny: %d x %d, first slab of %d rows: %d pivots%s [rows %.2fs, elimination %.2fs, rows of U to the host %.2fs]\n", R, C,
+        spasm_logf("[echelonize/dense] tall and skinny: %d x %d, first slab of %d rows: %d pivots%s [rows %.2fs, elimination with the rows of U leaving block by block %.2fs, the last block's %.2fs]\n", R, C,
                    R1, r1, f <= 0 && R2 > 0 ? " = every column: the other rows cannot add any" : "", tf1, te1, tu1);
         return r1;
     }
@@ -193,7 +196,7 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     const int r2 = dense_extract_U(T.p, f, ldz, pc2.p, fclist.p, row_orig + R1, U, s);
     ts.r2 = r2;
     ts.t_tail = spasm_wtime() - t3;
-    spasm_logf("[echelonize/dense] tall and skinny: %d x %d; first slab of %d rows: %d pivots [rows %.2fs, elimination %.2fs, rows of U to the host %.2fs]; reduced form on the "
+    spasm_logf("[echelonize/dense] tall and skinny: %d x %d; first slab of %d rows: %d pivots [rows %.2fs, elimination with the rows of U leaving block by block %.2fs, the last block's %.2fs]; reduced form on the "
                "%d columns left [%.2fs]; %d rows reduced in one step [rows %.2fs, reduction %.2fs]; their residuals: %d pivots [%.2fs]\n", R, C, R1, r1, tf1, te1, tu1, f, ts.t_z,
                R2, tf2, ts.t_resid - tf2, r2, ts.t_tail);
     return r1 + r2;

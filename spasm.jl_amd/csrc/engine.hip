@@ -1764,8 +1764,116 @@ int dense_elem_bytes(const ZpField &F, i64 R)
     return F.p <= 255 ? 1 : 2;
 }
 
+// The pivot rows of the dense columns [c_lo, c_hi) of an eliminated (or partly eliminated: the pivot rows of those columns are final)
+// dense matrix, appended to U.  Returns how many.
+// (device buffers of the extraction, kept between calls: hipFree waits for the whole device, which would end the overlap)
+struct ExtractWork {
+    Scanner scan;
+    DevBuf<int> pflag, pscan, pivcol, porig, dj, dx;
+    DevBuf<i64d> ulen, uoff;
+    DevBuf<int2> Ufull;
+};
+
 template <typename DT>
-bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, DevBuf<int> &pivrow_of_col, hipStream_t s)
+int dense_extract_range(const DT *Dp, int C, i64 ldc, const int *pivrow_of_col, int c_lo, int c_hi, const int *clist, const int *row_orig, HostU &U, ExtractWork &W,
+                        hipStream_t s)
+{
+    const int nc = c_hi - c_lo;
+    if (nc <= 0) return 0;
+    Scanner &scan = W.scan;
+    DevBuf<int> &pflag = W.pflag, &pscan = W.pscan;
+    pflag.ensure((size_t)nc + 1); pscan.ensure((size_t)nc + 1);
+    hipLaunchKernelGGL(k_flag_nonneg, dim3(cdiv((i64)nc + 1, 256)), dim3(256), 0, s, nc, pivrow_of_col + c_lo, pflag.p);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(pflag.p, pscan.p, (size_t)nc + 1, s);
+    int npd = 0;
+    HIPCHK(hipMemcpyAsync(&npd, pscan.p + nc, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (npd == 0) return 0;
+    DevBuf<i64d> &ulen = W.ulen, &uoff = W.uoff;
+    ulen.ensure((size_t)npd + 1024); uoff.ensure((size_t)npd + 1024);
+    HIPCHK(hipMemsetAsync(ulen.p, 0, ((size_t)npd + 1) * sizeof(i64d), s));
+    hipLaunchKernelGGL((k_dense_count<DT>), dim3(nc), dim3(256), 0, s, C, Dp, (i64d)ldc, pivrow_of_col, pscan.p, ulen.p, c_lo);
+    HIPCHK(hipGetLastError());
+    scan.exclusive(ulen.p, uoff.p, (size_t)npd + 1, s);
+    i64d tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, uoff.p + npd, sizeof tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    DevBuf<int2> &Ufull = W.Ufull;
+    DevBuf<int> &pivcol = W.pivcol, &porig = W.porig;
+    // (a quarter more than asked for: a later call that needs a little more must not free -- hipFree waits for the whole device)
+    if ((size_t)tot + 1 > Ufull.n) Ufull.alloc((size_t)tot + (size_t)tot / 4 + 1024);
+    pivcol.ensure((size_t)npd + 1024); porig.ensure((size_t)npd + 1024);
+    hipLaunchKernelGGL((k_dense_emit<DT>), dim3(nc), dim3(64), 0, s, C, Dp, (i64d)ldc, pivrow_of_col, pscan.p, uoff.p, clist, row_orig, Ufull.p, pivcol.p, porig.p, c_lo);
+    HIPCHK(hipGetLastError());
+    std::vector<i64d> off((size_t)npd + 1);
+    std::vector<int> pc((size_t)npd), po((size_t)npd);
+    HIPCHK(hipMemcpyAsync(off.data(), uoff.p, ((size_t)npd + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pc.data(), pivcol.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(po.data(), porig.p, (size_t)npd * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const i64 base = U.p.back();
+    for (int k = 0; k < npd; k++) {
+        U.p.push_back(base + off[(size_t)k + 1]);
+        U.pivcol.push_back(pc[(size_t)k]);
+        U.orig.push_back(po[(size_t)k]);
+    }
+    if (tot > 0) {
+        if ((size_t)tot > W.dj.n) { W.dj.alloc((size_t)tot + (size_t)tot / 4 + 1024); W.dx.alloc(W.dj.n); }
+        hipLaunchKernelGGL(k_split_ent, dim3((unsigned)std::min<i64>(((i64)tot + 255) / 256, 65536)), dim3(256), 0, s, (i64d)tot, Ufull.p, W.dj.p, W.dx.p);
+        HIPCHK(hipGetLastError());
+        int *hj = U.j.grow((size_t)tot), *hx = U.x.grow((size_t)tot);
+        HIPCHK(hipMemcpyAsync(hj, W.dj.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hx, W.dx.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return npd;
+}
+
+// The rows of U of a dense elimination on their way to the host WHILE it runs: the pivot rows of a block of columns are final when
+// the block is done (its pivot rows were updated right of the block last), so the block before the one the device works on is
+// extracted and copied on a stream of its own (a 10^9-entry U took as long to download as the elimination took: 1.0 of 1.9 s for
+// config 5 at 1/5).  The host blocks in the copies; the device has the current block's launches queued by then.
+struct UStreamer {
+    const void *Dp = nullptr;
+    int C = 0;
+    i64 ldc = 0;
+    const int *pivrow_of_col = nullptr, *clist = nullptr, *row_orig = nullptr;
+    HostU *U = nullptr;
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev = nullptr;
+    ExtractWork work;
+    int done_to = 0, found = 0;
+    double seconds = 0;
+    UStreamer() {}
+    UStreamer(const UStreamer &) = delete;
+    ~UStreamer()
+    {
+        if (ev) (void)hipEventDestroy(ev);
+        if (s2) (void)hipStreamDestroy(s2);
+    }
+    void init(const void *Dp_, int C_, i64 ldc_, const int *pc, const int *clist_, const int *row_orig_, HostU &U_)
+    {
+        Dp = Dp_; C = C_; ldc = ldc_; pivrow_of_col = pc; clist = clist_; row_orig = row_orig_; U = &U_;
+        HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    // everything queued on `main` so far finishes the columns below c_hi: remember the point ..
+    void mark(hipStream_t main) { HIPCHK(hipEventRecord(ev, main)); }
+    // .. and (later, with more work queued on the main stream) take the pivot rows of [done_to, c_hi)
+    template <typename DT> void take(int c_hi)
+    {
+        if (c_hi <= done_to) return;
+        const double t0 = spasm_wtime();
+        HIPCHK(hipStreamWaitEvent(s2, ev, 0));
+        found += dense_extract_range((const DT *)Dp, C, ldc, pivrow_of_col, done_to, c_hi, clist, row_orig, *U, work, s2);
+        done_to = c_hi;
+        seconds += spasm_wtime() - t0;
+    }
+};
+
+template <typename DT>
+bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, DevBuf<int> &pivrow_of_col, hipStream_t s, UStreamer *us = nullptr)
 {
     static int num_cu = 0;
     if (!num_cu) {
@@ -1853,6 +1961,7 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
         if (ND == 1) hipLaunchKernelGGL((k_trsm_i8<1, DT>), dim3(cdiv(jb - ja, 64)), dim3(64), 0, s, ja, jb, F, D.p, (i64d)ldc, info.p + q, Ut.p, (i64d)uplane, KB, q * DP_W);
         else hipLaunchKernelGGL((k_trsm_i8<2, DT>), dim3(cdiv(jb - ja, 64)), dim3(64), 0, s, ja, jb, F, D.p, (i64d)ldc, info.p + q, Ut.p, (i64d)uplane, KB, q * DP_W);
     };
+    int marked_to = 0; // columns whose pivot rows are final once the event of the streamer has passed
     for (int b0 = 0; b0 < C; b0 += KB) {
         const int b1 = std::min(b0 + KB, C);
         HIPCHK(hipMemsetAsync(Fd.p, 0, (size_t)ND * (size_t)fplane, s));
@@ -1860,6 +1969,9 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
         int q = 0;
         for (int c0 = b0; c0 < b1; c0 += DP_W, q++) {
             const int c1 = std::min(c0 + DP_W, b1), w = c1 - c0;
+            // (the rows of U of the block before this one go to the host now: the first panels of this block are queued, the
+            // copy overlaps them and what follows)
+            if (us && q == 2 && marked_to > us->done_to) us->template take<DT>(marked_to);
             hipLaunchKernelGGL((k_panel_load<DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, D.p, (i64d)ldc, P.p, sync.p);
             {
                 int a_Rp = Rp, a_chunk = tall ? res_chunk : chunk, a_w = w, a_c0 = c0;
@@ -1917,6 +2029,11 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
         }
         gemm(b1, C, 0, npan * DP_W, nullptr, 0);
         HIPCHK(hipGetLastError());
+        if (us) {
+            if (marked_to > us->done_to) us->template take<DT>(marked_to); // (a block of fewer than three panels)
+            us->mark(s);
+            marked_to = b1;
+        }
     }
     DenseState hst;
     HIPCHK(hipMemcpyAsync(&hst, st.p, sizeof hst, hipMemcpyDeviceToHost, s));
@@ -2005,9 +2122,14 @@ int dense_eliminate(DevBuf<DT> &D, int R, int C, i64 ldc, const int *clist, cons
     st.alloc(1);
     is_piv.zero(s); st.zero(s);
     const int rc = std::max(R, C);
+    UStreamer us;
+    bool streamed = false;
     if constexpr (!std::is_same<DT, int>::value) {
-        // narrow D: the int8 path (dense_elem_bytes has checked that it applies); pivrow_of_col is filled, D holds the echelon form
-        if (!dense_eliminate_i8(D, R, C, ldc, F, pivrow_of_col, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
+        // narrow D: the int8 path (dense_elem_bytes has checked that it applies); pivrow_of_col is filled, D holds the echelon form.
+        // The rows of U leave for the host block by block while the elimination goes on (UStreamer).
+        us.init(D.p, C, ldc, pivrow_of_col.p, clist, row_orig, U);
+        streamed = true;
+        if (!dense_eliminate_i8(D, R, C, ldc, F, pivrow_of_col, s, &us)) throw EngineError("dense finish: shape outside the panel kernel's range");
     } else {
         if (F.p <= ((i64)1 << 24)) {
             // blocked: panels of DPB columns, f64-MFMA trailing update (exact: 64 * (p/2)^2 < 2^53)
@@ -2050,9 +2172,20 @@ int dense_eliminate(DevBuf<DT> &D, int R, int C, i64 ldc, const int *clist, cons
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     te1 = spasm_wtime();
-    const int npd = dense_extract_U(D.p, C, ldc, pivrow_of_col.p, clist, row_orig, U, s);
-    spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots [elimination %.2fs, rows of U to the host %.2fs]\n", R, C, npd, te1 - te0,
-               spasm_wtime() - te1);
+    int npd = 0;
+    if constexpr (!std::is_same<DT, int>::value) {
+        if (streamed) {
+            us.template take<DT>(C);
+            npd = us.found;
+        }
+    } else {
+        npd = dense_extract_U(D.p, C, ldc, pivrow_of_col.p, clist, row_orig, U, s);
+    }
+    if (streamed)
+        spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots [elimination with the rows of U leaving block by block %.2fs, the last block's rows %.2fs; %.2fs of copies in all]\n",
+                   R, C, npd, te1 - te0, spasm_wtime() - te1, us.seconds);
+    else
+        spasm_logf("[echelonize/dense] %d x %d dense tail: %d pivots [elimination %.2fs, rows of U to the host %.2fs]\n", R, C, npd, te1 - te0, spasm_wtime() - te1);
     return npd;
 }
 

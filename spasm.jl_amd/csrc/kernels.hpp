@@ -2244,12 +2244,13 @@ __global__ __launch_bounds__(256) void k_dense_elim(int c, int R, int C, ZpField
 }
 
 // U rows out of the eliminated dense matrix: pivot column c (dense index) -> row pivrow_of_col[c], entries at columns >= c
+// (c0: first column of the range the launch covers -- pivrow_of_col and pscan are indexed from there)
 template <typename DT>
 __global__ void k_dense_count(int C, const DT *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
-                              i64d *__restrict__ ulen)
+                              i64d *__restrict__ ulen, int c0 = 0)
 {
     // one workgroup per dense column; pscan = exclusive scan of (pivrow_of_col >= 0)
-    const int c = blockIdx.x;
+    const int c = c0 + blockIdx.x;
     const int p = pivrow_of_col[c];
     if (p < 0) return;
     __shared__ int s_cnt;
@@ -2259,19 +2260,19 @@ __global__ void k_dense_count(int C, const DT *__restrict__ D, i64d ldc, const i
     for (int j = c + threadIdx.x; j < C; j += blockDim.x) cnt += D[(i64d)p * ldc + j] != 0;
     if (cnt) atomicAdd(&s_cnt, cnt);
     __syncthreads();
-    if (threadIdx.x == 0) ulen[pscan[c]] = s_cnt;
+    if (threadIdx.x == 0) ulen[pscan[c - c0]] = s_cnt;
 }
 
 template <typename DT>
 __global__ void k_dense_emit(int C, const DT *__restrict__ D, i64d ldc, const int *__restrict__ pivrow_of_col, const int *__restrict__ pscan,
                              const i64d *__restrict__ uoff, const int *__restrict__ clist, const int *__restrict__ row_orig,
-                             int2 *__restrict__ Ufull, int *__restrict__ pivcol, int *__restrict__ piv_orig)
+                             int2 *__restrict__ Ufull, int *__restrict__ pivcol, int *__restrict__ piv_orig, int c0 = 0)
 {
     // one wave per pivot column keeps the entries of a U row in ascending column order
-    const int c = blockIdx.x;
+    const int c = c0 + blockIdx.x;
     const int p = pivrow_of_col[c];
     if (p < 0) return;
-    const int k = pscan[c];
+    const int k = pscan[c - c0];
     const int lane = threadIdx.x & 63;
     i64d pos = uoff[k];
     for (int j0 = c; j0 < C; j0 += 64) {
