@@ -350,6 +350,42 @@ void spasm_amd_shard_free(spasm_amd_shard *sh);
  * equal those of spasm_echelonize with enable_greedy_pivot_search = 0 whatever nshards is.  What spasm.jl_amd/sharded.py does with
  * one process per GPU and RCCL, behind one call for hosts without torch.distributed (the Julia side: one more @ccall). */
 struct spasm_lu *spasm_amd_echelonize_multi(const struct spasm_csr *A, struct echelonize_opts *opts, int nshards);
+/* ---- the dense finish over row shards with ONE PROCESS PER SHARD (spasm.jl_amd/sharded.py; csrc/dense_multi.hpp states the
+ * protocol).  The steps are the engine's, the exchanges between them the caller's collectives; `*_dev` are DEVICE pointers of the caller.
+ *   shard_import_U      as spasm_amd_shard_import, but stops after U is built (no W / Uinv, no dry run)
+ *   schur_plan_prepare  .. which this catches up on when the round stays sparse after all
+ *   dshard_open         the columns this shard's Schur rows of the round can touch, as flags          -> dshard_flags -> all-reduce(MAX)
+ *   dshard_density      takes the reduced flags (all shards then number the columns alike), estimates the density of the round's
+ *                       Schur complement on 64 columns (spasm_schur_estimate_density); C_out = columns of the dense matrix
+ *   dshard_build        this shard's Schur rows straight into its dense matrix (spasm_schur_dense), guest rows behind them
+ *   per block of KB columns: dshard_block_begin; per panel of 64 (q-th of the block, columns c0 .. c0 + w):
+ *     dshard_candidates   the rows this shard's own elimination of the panel elects, cand_bytes bytes   -> all-gather
+ *     dshard_elect        the panel's pivots among the candidates of all shards (every rank runs it: same result); npp pivots,
+ *                         cnt[k] / first[k]: how many shard k owns and the guest slot of its first
+ *     dshard_pack         this shard's winners: cnt rows of (ldc - c0) elements, then nd planes of cnt x KB bytes -> one broadcast per owner
+ *     dshard_unpack       an owner's buffer into the guest rows (also the owner's own)
+ *     dshard_apply        the panel: elimination by the now known pivots, triangular solve of the pivot rows, update inside the block
+ *   dshard_block_end(b0, b1, panels); after the last block dshard_finish = pivots found by all shards together (< 0: error), and
+ *   dshard_fetch_U = the rows of U this shard owns (pivcol_out / row_out: C ints each, n_out of them used). */
+typedef struct spasm_amd_dshard spasm_amd_dshard;
+spasm_amd_schur_plan *spasm_amd_shard_import_U(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev);
+int spasm_amd_schur_plan_prepare(spasm_amd_schur_plan *plan);
+spasm_amd_dshard *spasm_amd_dshard_open(spasm_amd_schur_plan *plan, int me, int nshards);
+int spasm_amd_dshard_flags(spasm_amd_dshard *ds, int *flags_dev);
+double spasm_amd_dshard_density(spasm_amd_dshard *ds, const int *flags_dev, int free_cols, int *C_out);
+int spasm_amd_dshard_build(spasm_amd_dshard *ds);
+int spasm_amd_dshard_info(spasm_amd_dshard *ds, int *C_out, int *KB, i64 *ldc, int *elem, int *nd, int *cand_bytes);
+int spasm_amd_dshard_block_begin(spasm_amd_dshard *ds);
+int spasm_amd_dshard_candidates(spasm_amd_dshard *ds, int c0, int w, void *cand_dev);
+int spasm_amd_dshard_elect(spasm_amd_dshard *ds, const void *stack_dev, int w, int *npp, int *cnt, int *first);
+i64 spasm_amd_dshard_pack(spasm_amd_dshard *ds, int c0, void *buf_dev);
+int spasm_amd_dshard_unpack(spasm_amd_dshard *ds, int q, int c0, int owner, const void *buf_dev);
+int spasm_amd_dshard_apply(spasm_amd_dshard *ds, int q, int c0, int w, int b1);
+int spasm_amd_dshard_block_end(spasm_amd_dshard *ds, int b0, int b1, int npan);
+int spasm_amd_dshard_finish(spasm_amd_dshard *ds);
+struct spasm_csr *spasm_amd_dshard_fetch_U(spasm_amd_dshard *ds, int *pivcol_out, int *row_out, int *n_out);
+void spasm_amd_dshard_close(spasm_amd_dshard *ds);
+
 /* How the most recent spasm_amd_echelonize_multi of this thread finished: 0 = remainder gathered to device 0 (or nothing left),
  * 1 = a round's Schur complement straight to dense on all shards, 2 = the dense remainder on all shards. */
 int spasm_amd_multi_last_finish(void);

@@ -212,6 +212,23 @@ SIGNATURES = {
     "spasm_amd_schur_plan_advance": (C.c_void_p, [C.c_void_p, _P(C.c_int32), _P(C.c_int64)]),
     "spasm_amd_shard_fetch": (_P(CsrStruct), [C.c_void_p]),
     "spasm_amd_shard_free": (None, [C.c_void_p]),
+    "spasm_amd_shard_import_U": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "spasm_amd_schur_plan_prepare": (C.c_int32, [C.c_void_p]),
+    "spasm_amd_dshard_open": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32]),
+    "spasm_amd_dshard_flags": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "spasm_amd_dshard_density": (C.c_double, [C.c_void_p, C.c_void_p, C.c_int32, _P(C.c_int32)]),
+    "spasm_amd_dshard_build": (C.c_int32, [C.c_void_p]),
+    "spasm_amd_dshard_info": (C.c_int32, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "spasm_amd_dshard_block_begin": (C.c_int32, [C.c_void_p]),
+    "spasm_amd_dshard_candidates": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "spasm_amd_dshard_elect": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "spasm_amd_dshard_pack": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "spasm_amd_dshard_unpack": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "spasm_amd_dshard_apply": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "spasm_amd_dshard_block_end": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "spasm_amd_dshard_finish": (C.c_int32, [C.c_void_p]),
+    "spasm_amd_dshard_fetch_U": (_P(CsrStruct), [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "spasm_amd_dshard_close": (None, [C.c_void_p]),
 }
 DATA_SYMBOLS = ["logcallback"]
 

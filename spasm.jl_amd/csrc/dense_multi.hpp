@@ -89,8 +89,9 @@ template <typename DT> struct DenseShard {
     DevBuf<CandRec> cand, stack;
     DevBuf<PanelGlob> glob;
 
-    // D (with KB zero rows behind its R rows) and row_orig have been moved in
-    void setup(int nshards)
+    // D (with KB zero rows behind its R rows) and row_orig have been moved in.  elect_here: this shard runs the election among the
+    // candidates of all shards itself (one process per shard: every rank elects, nothing is sent back) -- else only shard 0 does
+    void setup(int nshards, bool elect_here = false)
     {
         HIPCHK(hipGetDevice(&dev));
         HIPCHK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -136,7 +137,7 @@ template <typename DT> struct DenseShard {
         glob.alloc(1);
         expD.alloc((size_t)DP_W * (size_t)ldc);
         expF.alloc((size_t)ND * DP_W * (size_t)KB);
-        if (me == 0) {
+        if (me == 0 || elect_here) {
             stack.alloc((size_t)nshards);
             Ps.alloc((size_t)DP_W * (size_t)Rs);
             seq_s.alloc((size_t)Rs);
@@ -214,6 +215,16 @@ template <typename DT> struct DenseShard {
     {
         const int nsh = (int)all.size();
         for (int k = 0; k < nsh; k++) HIPCHK(hipMemcpyAsync(stack.p + k, all[(size_t)k]->cand.p, sizeof(CandRec), hipMemcpyDeviceToDevice, s));
+        elect_stacked(nsh, w, host_glob);
+    }
+    // the same with the candidates of all shards gathered by the caller (a collective): stack_dev holds nsh records
+    void elect_from(const void *stack_dev, int nsh, int w, PanelGlob *host_glob)
+    {
+        HIPCHK(hipMemcpyAsync(stack.p, stack_dev, (size_t)nsh * sizeof(CandRec), hipMemcpyDeviceToDevice, s));
+        elect_stacked(nsh, w, host_glob);
+    }
+    void elect_stacked(int nsh, int w, PanelGlob *host_glob)
+    {
         hipLaunchKernelGGL((k_stack_load<DT>), dim3(cdiv((i64)Rs * DP_W, 256)), dim3(256), 0, s, nsh, Rs, stack.p, Ps.p, seq_s.p, sync_s.p, st_s.p);
         HIPCHK(hipGetLastError());
         launch_panel_lu(true, 1, (size_t)Rs * DP_W * (size_t)xbytes, Rs, Rs, w, Ps.p, seq_s.p, pc_dummy.p, info_s.p, sync_s.p, candrow_s.p, st_s.p);
@@ -224,9 +235,9 @@ template <typename DT> struct DenseShard {
     }
 
     // the rows this shard won, packed for the others to fetch (synchronises)
-    void pack(int c0, const PanelGlob *host_glob)
+    void pack(int c0, const PanelGlob *host_glob, bool glob_is_here = false)
     {
-        if (me != 0) HIPCHK(hipMemcpyAsync(glob.p, host_glob, sizeof(PanelGlob), hipMemcpyHostToDevice, s));
+        if (me != 0 && !glob_is_here) HIPCHK(hipMemcpyAsync(glob.p, host_glob, sizeof(PanelGlob), hipMemcpyHostToDevice, s));
         if (host_glob->cnt[me] > 0) {
             hipLaunchKernelGGL((k_export_pack<DT>), dim3(DP_W, (unsigned)std::max(1, std::min(64, cdiv(ldc - c0, 1024)))), dim3(256), 0, s, me, c0, (i64d)ldc, glob.p, D.p, Fd.p,
                                (i64d)fplane, KB, ND, expD.p, expF.p);
@@ -238,7 +249,6 @@ template <typename DT> struct DenseShard {
     // the winners of all shards into this shard's guest rows of panel q, then the panel as the single-device finish does it
     void apply(const std::vector<DenseShard<DT> *> &all, int q, int c0, int w, int b1, const PanelGlob *host_glob)
     {
-        const int c1 = c0 + w;
         const int guest0 = R + q * DP_W;
         for (size_t k = 0; k < all.size(); k++) {
             const int cnt = host_glob->cnt[k], first = host_glob->first[k];
@@ -250,6 +260,39 @@ template <typename DT> struct DenseShard {
                 HIPCHK(hipMemcpyAsync(Fd.p + (size_t)d * (size_t)fplane + (size_t)(guest0 + first) * (size_t)KB, o.expF.p + (size_t)d * (size_t)cnt * (size_t)KB,
                                       (size_t)cnt * (size_t)KB, hipMemcpyDeviceToDevice, s));
         }
+        apply_panel(q, c0, w, b1);
+    }
+
+    // one process per shard: this shard's packed winners (pack) in the caller's buffer -- cnt rows of ldc - c0 elements, then ND planes of
+    // cnt rows of KB multiplier digits.  Returns the bytes written.
+    i64 export_to(int c0, const PanelGlob *host_glob, void *buf)
+    {
+        const int cnt = host_glob->cnt[me];
+        if (cnt <= 0) return 0;
+        const size_t wbytes = (size_t)(ldc - c0) * sizeof(DT);
+        HIPCHK(hipMemcpy2DAsync(buf, wbytes, expD.p + c0, (size_t)ldc * sizeof(DT), wbytes, (size_t)cnt, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync((char *)buf + wbytes * (size_t)cnt, expF.p, (size_t)ND * (size_t)cnt * (size_t)KB, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return (i64)(wbytes * (size_t)cnt + (size_t)ND * (size_t)cnt * (size_t)KB);
+    }
+    // .. and an owner's buffer (after the broadcast) into this shard's guest rows of panel q
+    void import_from(int q, int c0, int owner, const PanelGlob *host_glob, const void *buf)
+    {
+        const int cnt = host_glob->cnt[owner], first = host_glob->first[owner];
+        if (cnt <= 0) return;
+        const int guest0 = R + q * DP_W;
+        const size_t wbytes = (size_t)(ldc - c0) * sizeof(DT);
+        HIPCHK(hipMemcpy2DAsync(D.p + (size_t)(guest0 + first) * (size_t)ldc + c0, (size_t)ldc * sizeof(DT), buf, wbytes, wbytes, (size_t)cnt, hipMemcpyDeviceToDevice, s));
+        for (int d = 0; d < ND; d++)
+            HIPCHK(hipMemcpyAsync(Fd.p + (size_t)d * (size_t)fplane + (size_t)(guest0 + first) * (size_t)KB, (const char *)buf + wbytes * (size_t)cnt + (size_t)d * (size_t)cnt * (size_t)KB,
+                                  (size_t)cnt * (size_t)KB, hipMemcpyDeviceToDevice, s));
+    }
+
+    // the panel once the winners sit in the guest rows: apply, store, the pivot rows' triangular solve, the update inside the block
+    void apply_panel(int q, int c0, int w, int b1)
+    {
+        const int c1 = c0 + w;
+        const int guest0 = R + q * DP_W;
         hipLaunchKernelGGL(k_apply_prep, dim3(1), dim3(DP_W), 0, s, me, R, q, glob.p, seq.p, own_map.p);
         hipLaunchKernelGGL((k_panel_load<DT>), dim3(Rp / 64), dim3(256), 0, s, Rext, Rp, c0, w, D.p, (i64d)ldc, P.p, sync.p);
         hipLaunchKernelGGL((k_panel_apply<1024, DT>), dim3(G_app), dim3(1024), (size_t)app_chunk * DP_W * (size_t)xbytes, s, Rp, app_chunk, w, F, P.p, seq.p, glob.p, me,

@@ -4330,6 +4330,122 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
     return N;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The dense finish over row shards with ONE PROCESS PER SHARD (spasm.jl_amd/sharded.py: torch.distributed, RCCL): the steps of
+// dense_finish_multi behind the C ABI, the exchanges between them are the caller's collectives -- an all-gather of the candidate
+// records (every rank then runs the election itself: deterministic, nothing is sent back) and one broadcast per owner of the
+// packed winner rows.
+// ------------------------------------------------------------------------------------------------
+struct DShardBase {
+    virtual ~DShardBase() {}
+    virtual void build(spasm_amd_schur_plan *P, DenseW &W, int me, int nshards, int C) = 0;
+    virtual void block_begin() = 0;
+    virtual void candidates(int c0, int w, void *cand_dev) = 0;
+    virtual void elect(const void *stack_dev, int w) = 0;
+    virtual i64 pack(int c0, void *buf) = 0;
+    virtual void unpack(int q, int c0, int owner, const void *buf) = 0;
+    virtual void apply(int q, int c0, int w, int b1) = 0;
+    virtual void block_end(int b0, int b1, int npan) = 0;
+    virtual int finish() = 0;
+    virtual int extract(const int *clist, HostU &U) = 0;
+    virtual void info(int *KB, i64 *ldc, int *elem, int *nd) = 0;
+    PanelGlob hglob;
+    int nshards = 1;
+};
+
+template <typename DT> struct DShardT : DShardBase {
+    DenseShard<DT> sh;
+    void build(spasm_amd_schur_plan *P, DenseW &W, int me, int nsh, int C) override
+    {
+        nshards = nsh;
+        memset(&hglob, 0, sizeof hglob);
+        sh.me = me;
+        sh.C = C;
+        sh.ldc = ((i64)C + 63) / 64 * 64;
+        sh.F = P->R.F;
+        sh.KB = dense_kb();
+        sh.R = P->R.nnp;
+        sh.s = P->R.stream;
+        schur_dense_build(P->R, P->A, sh.R, W, sh.KB, sh.D, sh.row_orig, P->R.stream);
+        sh.setup(nsh, true);
+    }
+    void block_begin() override { sh.block_begin(); }
+    void candidates(int c0, int w, void *cand_dev) override
+    {
+        sh.candidates(c0, w);
+        HIPCHK(hipMemcpyAsync(cand_dev, sh.cand.p, sizeof(CandRec), hipMemcpyDeviceToDevice, sh.s));
+        HIPCHK(hipStreamSynchronize(sh.s));
+    }
+    void elect(const void *stack_dev, int w) override { sh.elect_from(stack_dev, nshards, w, &hglob); }
+    i64 pack(int c0, void *buf) override
+    {
+        sh.pack(c0, &hglob, true);
+        return sh.export_to(c0, &hglob, buf);
+    }
+    void unpack(int q, int c0, int owner, const void *buf) override { sh.import_from(q, c0, owner, &hglob, buf); }
+    void apply(int q, int c0, int w, int b1) override { sh.apply_panel(q, c0, w, b1); }
+    void block_end(int b0, int b1, int npan) override { sh.block_end(b0, b1, npan); }
+    int finish() override { return sh.finish(); }
+    int extract(const int *clist, HostU &U) override { return dense_extract_U(sh.D.p, sh.C, sh.ldc, sh.own_pc.p, clist, sh.row_orig.p, U, sh.s); }
+    void info(int *KB, i64 *ldc, int *elem, int *nd) override
+    {
+        if (KB) *KB = sh.KB;
+        if (ldc) *ldc = sh.ldc;
+        if (elem) *elem = (int)sizeof(DT);
+        if (nd) *nd = sh.ND;
+    }
+};
+
+} // namespace
+
+struct spasm_amd_dshard {
+    spasm_amd_schur_plan *plan = nullptr; // not owned
+    std::unique_ptr<DenseW> dw;
+    std::unique_ptr<DShardBase> impl;
+    int me = 0, nshards = 1, C = 0;
+};
+
+namespace {
+
+spasm_amd_dshard *dshard_open(spasm_amd_schur_plan *P, int me, int nshards)
+{
+    if (!P) throw EngineError("spasm_amd_dshard_open: null plan");
+    if (!P->R.F.small) throw EngineError("spasm_amd_dshard_open: the dense finish over shards takes primes below 2^16");
+    const int elem = P->R.F.p <= 255 ? 1 : 2;
+    if (nshards < 1 || nshards > DM_MAXSHARDS || nshards * DP_W > 147456 / (DP_W * elem)) throw EngineError("spasm_amd_dshard_open: too many shards for the election workgroup");
+    if (me < 0 || me >= nshards) throw EngineError("spasm_amd_dshard_open: shard number out of range");
+    std::unique_ptr<spasm_amd_dshard> ds(new spasm_amd_dshard());
+    ds->plan = P;
+    ds->me = me;
+    ds->nshards = nshards;
+    ds->dw.reset(new DenseW(P->R, P->A, P->R.stream));
+    ds->dw->flag_columns();
+    HIPCHK(hipStreamSynchronize(P->R.stream));
+    return ds.release();
+}
+
+// the rows of U this shard owns after the finish, as a host CSR; pivcol_out / row_out: their pivot columns and originating rows
+struct spasm_csr *dshard_fetch_U(spasm_amd_dshard *ds, int *pivcol_out, int *row_out, int *n_out)
+{
+    HostU U;
+    U.p.push_back(0);
+    const int got = ds->impl->extract(ds->dw->clist.p, U);
+    const i64 nz = U.p.back();
+    struct spasm_csr *Uc = spasm_csr_alloc(got, ds->plan->A.m, nz, ds->plan->prime, true);
+    if (!Uc) throw EngineError("out of host memory for the shard's rows of U");
+    for (int k = 0; k <= got; k++) Uc->p[k] = U.p[(size_t)k];
+    if (nz > 0) {
+        memcpy(Uc->j, U.j.data(), sizeof(int) * (size_t)nz);
+        memcpy(Uc->x, U.x.data(), sizeof(int) * (size_t)nz);
+    }
+    for (int k = 0; k < got; k++) {
+        if (pivcol_out) pivcol_out[k] = U.pivcol[(size_t)k];
+        if (row_out) row_out[k] = U.orig[(size_t)k];
+    }
+    if (n_out) *n_out = got;
+    return Uc;
+}
+
 } // namespace
 
 // ================================================================================================
@@ -4796,6 +4912,80 @@ SPASM_API int spasm_amd_zp_probe(i64 prime, int n, const int *a, const int *b, c
 }
 
 SPASM_API int spasm_amd_multi_last_finish(void) { return g_multi_finish; }
+
+// ---- the dense finish over row shards, one process per shard (include/spasm_amd.h)
+#define DSHARD_TRY(name, body, fail)                                   \
+    spasm_clear_error();                                               \
+    try { body }                                                       \
+    catch (const std::exception &e) { spasm_set_error(name ": %s", e.what()); return fail; }
+
+SPASM_API spasm_amd_schur_plan *spasm_amd_shard_import_U(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev)
+{
+    DSHARD_TRY("spasm_amd_shard_import_U", return shard_import(sh, n_rows, n_entries, hdr_dev, ent_dev, false);, nullptr)
+}
+SPASM_API int spasm_amd_schur_plan_prepare(spasm_amd_schur_plan *plan)
+{
+    DSHARD_TRY("spasm_amd_schur_plan_prepare", if (!plan) throw EngineError("null plan"); shard_import_finish(plan); return 0;, -1)
+}
+SPASM_API spasm_amd_dshard *spasm_amd_dshard_open(spasm_amd_schur_plan *plan, int me, int nshards)
+{
+    DSHARD_TRY("spasm_amd_dshard_open", return dshard_open(plan, me, nshards);, nullptr)
+}
+SPASM_API int spasm_amd_dshard_flags(spasm_amd_dshard *ds, int *flags_dev)
+{
+    DSHARD_TRY("spasm_amd_dshard_flags",
+               HIPCHK(hipMemcpy(flags_dev, ds->dw->cflag.p, ((size_t)ds->plan->A.m + 1) * sizeof(int), hipMemcpyDeviceToDevice)); return 0;, -1)
+}
+SPASM_API double spasm_amd_dshard_density(spasm_amd_dshard *ds, const int *flags_dev, int free_cols, int *C_out)
+{
+    DSHARD_TRY("spasm_amd_dshard_density",
+               HIPCHK(hipMemcpy(ds->dw->cflag.p, flags_dev, ((size_t)ds->plan->A.m + 1) * sizeof(int), hipMemcpyDeviceToDevice));
+               ds->C = ds->dw->finish_columns();
+               if (C_out) *C_out = ds->C;
+               Round &R = ds->plan->R;
+               return ds->dw->estimate_density(R.np_rows.p, R.nnp, free_cols);, -1.0)
+}
+SPASM_API int spasm_amd_dshard_build(spasm_amd_dshard *ds)
+{
+    DSHARD_TRY("spasm_amd_dshard_build",
+               if (ds->C <= 0) throw EngineError("no column left (call spasm_amd_dshard_density first)");
+               if (ds->plan->R.F.p <= 255) ds->impl.reset(new DShardT<signed char>());
+               else ds->impl.reset(new DShardT<short>());
+               ds->impl->build(ds->plan, *ds->dw, ds->me, ds->nshards, ds->C);
+               return 0;, -1)
+}
+SPASM_API int spasm_amd_dshard_info(spasm_amd_dshard *ds, int *C_out, int *KB, i64 *ldc, int *elem, int *nd, int *cand_bytes)
+{
+    DSHARD_TRY("spasm_amd_dshard_info", if (!ds->impl) throw EngineError("not built"); if (C_out) *C_out = ds->C; ds->impl->info(KB, ldc, elem, nd);
+               if (cand_bytes) *cand_bytes = (int)sizeof(CandRec); return 0;, -1)
+}
+SPASM_API int spasm_amd_dshard_block_begin(spasm_amd_dshard *ds) { DSHARD_TRY("spasm_amd_dshard_block_begin", ds->impl->block_begin(); return 0;, -1) }
+SPASM_API int spasm_amd_dshard_candidates(spasm_amd_dshard *ds, int c0, int w, void *cand_dev)
+{
+    DSHARD_TRY("spasm_amd_dshard_candidates", ds->impl->candidates(c0, w, cand_dev); return 0;, -1)
+}
+SPASM_API int spasm_amd_dshard_elect(spasm_amd_dshard *ds, const void *stack_dev, int w, int *npp, int *cnt, int *first)
+{
+    DSHARD_TRY("spasm_amd_dshard_elect", ds->impl->elect(stack_dev, w); if (npp) *npp = ds->impl->hglob.npp;
+               for (int k = 0; k < ds->nshards; k++) { if (cnt) cnt[k] = ds->impl->hglob.cnt[k]; if (first) first[k] = ds->impl->hglob.first[k]; }
+               return 0;, -1)
+}
+SPASM_API i64 spasm_amd_dshard_pack(spasm_amd_dshard *ds, int c0, void *buf_dev) { DSHARD_TRY("spasm_amd_dshard_pack", return ds->impl->pack(c0, buf_dev);, -1) }
+SPASM_API int spasm_amd_dshard_unpack(spasm_amd_dshard *ds, int q, int c0, int owner, const void *buf_dev)
+{
+    DSHARD_TRY("spasm_amd_dshard_unpack", ds->impl->unpack(q, c0, owner, buf_dev); return 0;, -1)
+}
+SPASM_API int spasm_amd_dshard_apply(spasm_amd_dshard *ds, int q, int c0, int w, int b1) { DSHARD_TRY("spasm_amd_dshard_apply", ds->impl->apply(q, c0, w, b1); return 0;, -1) }
+SPASM_API int spasm_amd_dshard_block_end(spasm_amd_dshard *ds, int b0, int b1, int npan)
+{
+    DSHARD_TRY("spasm_amd_dshard_block_end", ds->impl->block_end(b0, b1, npan); return 0;, -1)
+}
+SPASM_API int spasm_amd_dshard_finish(spasm_amd_dshard *ds) { DSHARD_TRY("spasm_amd_dshard_finish", return ds->impl->finish();, -1) }
+SPASM_API struct spasm_csr *spasm_amd_dshard_fetch_U(spasm_amd_dshard *ds, int *pivcol_out, int *row_out, int *n_out)
+{
+    DSHARD_TRY("spasm_amd_dshard_fetch_U", return dshard_fetch_U(ds, pivcol_out, row_out, n_out);, nullptr)
+}
+SPASM_API void spasm_amd_dshard_close(spasm_amd_dshard *ds) { delete ds; }
 
 SPASM_API int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds)
 {

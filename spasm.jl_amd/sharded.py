@@ -59,15 +59,21 @@ class GpuShardEngine:
             raise RuntimeError("spasm_amd_shard_export failed: " + _abi.last_error())
         return hdr[: self.n_own], ent[: self.nnz_own]
 
-    def import_(self, hdr_all, ent_all):
+    def import_(self, hdr_all, ent_all, prepare=True):
+        """prepare=False: stop after U (spasm_amd_shard_import_U) -- the caller decides first whether the round's Schur complement
+        goes dense, and calls prepare() when it does not."""
         hdr_all = hdr_all.to(self.device).contiguous()
         ent_all = ent_all.to(self.device).contiguous()
-        plan = self.lib.spasm_amd_shard_import(self.shard, int(hdr_all.shape[0]), int(ent_all.shape[0]),
-                                               C.c_void_p(hdr_all.data_ptr()), C.c_void_p(ent_all.data_ptr()))
+        fn = self.lib.spasm_amd_shard_import if prepare else self.lib.spasm_amd_shard_import_U
+        plan = fn(self.shard, int(hdr_all.shape[0]), int(ent_all.shape[0]), C.c_void_p(hdr_all.data_ptr()), C.c_void_p(ent_all.data_ptr()))
         if not plan:
             raise RuntimeError("spasm_amd_shard_import failed: " + _abi.last_error())
         self.plan = plan
         return plan
+
+    def prepare(self):
+        if self.lib.spasm_amd_schur_plan_prepare(self.plan) != 0:
+            raise RuntimeError("spasm_amd_schur_plan_prepare failed: " + _abi.last_error())
 
     def close(self):
         if self.plan:
@@ -246,7 +252,126 @@ def _balanced(v, prime):
     return v - prime if v > prime // 2 else v
 
 
-def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, engine_cls=None, finish=None):
+def _chk(rc, what):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise RuntimeError(what + " failed: " + _abi.last_error())
+    return rc
+
+
+def dense_round_sharded(eng, free_cols, sparsity_threshold, group=None, force=False):
+    """The round whose pivots have just been exchanged (eng.plan holds U, unprepared), when its Schur complement is dense: every
+    rank's Schur rows go straight into its dense matrix and the ranks eliminate them TOGETHER (csrc/dense_multi.hpp: rows stay where
+    they are; per panel of 64 columns an all-gather of the candidates' panel entries, the election on every rank, one broadcast of
+    the winners' rows per owner).  Returns None when the round stays sparse (estimated density at or below the threshold), else this
+    rank's share of the rows of U as (row lengths, columns, values, pivot columns, original rows) and the number of pivots found by
+    all ranks."""
+    import numpy as np
+
+    from .api import CSR
+
+    lib = eng.lib
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    ds = lib.spasm_amd_dshard_open(eng.plan, rank, world)
+    if not ds:
+        raise RuntimeError("spasm_amd_dshard_open failed: " + _abi.last_error())
+    try:
+        m = eng.m
+        flags = torch.empty(m + 1, dtype=torch.int32, device=eng.device)
+        _chk(lib.spasm_amd_dshard_flags(ds, C.c_void_p(flags.data_ptr())), "spasm_amd_dshard_flags")
+        if world > 1:
+            f = _collective_device(flags, group)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
+            flags = f.to(eng.device)
+        Cc = C.c_int32(0)
+        est = lib.spasm_amd_dshard_density(ds, C.c_void_p(flags.data_ptr()), int(free_cols), C.byref(Cc))
+        if est < 0:
+            raise RuntimeError("spasm_amd_dshard_density failed: " + _abi.last_error())
+        # rank 0's estimate decides for all (its rows are a strided sample of all rows)
+        dec = torch.tensor([float(est), float(Cc.value)], dtype=torch.float64)
+        if world > 1:
+            d = dec if dist.get_backend(group) == "gloo" else dec.to(eng.device)
+            dist.broadcast(d, src=0, group=group)
+            dec = d.cpu()
+        if int(dec[1]) <= 0 or not (force or float(dec[0]) > sparsity_threshold):
+            return None
+        _chk(lib.spasm_amd_dshard_build(ds), "spasm_amd_dshard_build")
+        Cn, KB, ldc, elem, nd, cb = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _chk(lib.spasm_amd_dshard_info(ds, C.byref(Cn), C.byref(KB), C.byref(ldc), C.byref(elem), C.byref(nd), C.byref(cb)), "spasm_amd_dshard_info")
+        Cn, KB, ldc, elem, nd, cb = Cn.value, KB.value, ldc.value, elem.value, nd.value, cb.value
+        cand = torch.empty(cb, dtype=torch.uint8, device=eng.device)
+        npp, cnt, first = C.c_int32(0), (C.c_int32 * world)(), (C.c_int32 * world)()
+        for b0 in range(0, Cn, KB):
+            b1 = min(b0 + KB, Cn)
+            _chk(lib.spasm_amd_dshard_block_begin(ds), "spasm_amd_dshard_block_begin")
+            q = 0
+            for c0 in range(b0, b1, 64):
+                w = min(c0 + 64, b1) - c0
+                _chk(lib.spasm_amd_dshard_candidates(ds, c0, w, C.c_void_p(cand.data_ptr())), "spasm_amd_dshard_candidates")
+                if world > 1:
+                    cdev = _collective_device(cand, group)
+                    outs = [torch.empty_like(cdev) for _ in range(world)]
+                    dist.all_gather(outs, cdev, group=group)
+                    stack = torch.cat(outs).to(eng.device)
+                else:
+                    stack = cand
+                _chk(lib.spasm_amd_dshard_elect(ds, C.c_void_p(stack.data_ptr()), w, C.byref(npp), cnt, first), "spasm_amd_dshard_elect")
+                for k in range(world):
+                    if cnt[k] <= 0:
+                        continue
+                    nbytes = cnt[k] * (ldc - c0) * elem + nd * cnt[k] * KB
+                    buf = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)
+                    if k == rank:
+                        got = lib.spasm_amd_dshard_pack(ds, c0, C.c_void_p(buf.data_ptr()))
+                        if got != nbytes:
+                            raise RuntimeError(f"spasm_amd_dshard_pack wrote {got} bytes, {nbytes} expected: " + _abi.last_error())
+                    if world > 1:
+                        bdev = _collective_device(buf, group)
+                        dist.broadcast(bdev, src=k, group=group)
+                        buf = bdev.to(eng.device)
+                    _chk(lib.spasm_amd_dshard_unpack(ds, q, c0, k, C.c_void_p(buf.data_ptr())), "spasm_amd_dshard_unpack")
+                _chk(lib.spasm_amd_dshard_apply(ds, q, c0, w, b1), "spasm_amd_dshard_apply")
+                q += 1
+            _chk(lib.spasm_amd_dshard_block_end(ds, b0, b1, q), "spasm_amd_dshard_block_end")
+        npiv = lib.spasm_amd_dshard_finish(ds)
+        if npiv < 0:
+            raise RuntimeError("spasm_amd_dshard_finish failed: " + _abi.last_error())
+        pc = np.empty(max(Cn, 1), dtype=np.int32)
+        ro = np.empty(max(Cn, 1), dtype=np.int32)
+        nown = C.c_int32(0)
+        P = C.POINTER(C.c_int32)
+        ptr = lib.spasm_amd_dshard_fetch_U(ds, pc.ctypes.data_as(P), ro.ctypes.data_as(P), C.byref(nown))
+        if not ptr:
+            raise RuntimeError("spasm_amd_dshard_fetch_U failed: " + _abi.last_error())
+        Uc = CSR(ptr)
+        up = np.asarray(Uc.p)
+        nz = int(up[Uc.n])
+        k = int(nown.value)
+        return ((np.diff(up).astype(np.int64), np.array(Uc.j[:nz], dtype=np.int64), np.array(Uc.x[:nz], dtype=np.int64),
+                 pc[:k].astype(np.int64), ro[:k].astype(np.int64)), int(npiv))
+    finally:
+        lib.spasm_amd_dshard_close(ds)
+
+
+def _gather_U_blocks(blk, group):
+    """every rank's share of the rows of U (dense_round_sharded) on every rank, in rank order"""
+    import numpy as np
+
+    lens, cols, vals, pcs, origs = blk
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return blk
+    counts = all_gather_counts([len(lens), len(cols)], group)
+    dev = "cuda" if dist.get_backend(group) != "gloo" else "cpu"
+    rows = torch.as_tensor(np.stack([lens, pcs, origs], axis=1).reshape(-1, 3), dtype=torch.int64, device=dev)
+    ents = torch.as_tensor(np.stack([cols, vals], axis=1).reshape(-1, 2), dtype=torch.int64, device=dev)
+    g_rows = all_gather_var(rows, counts[:, 0].tolist(), group).cpu().numpy()
+    g_ents = all_gather_var(ents, counts[:, 1].tolist(), group).cpu().numpy()
+    return (g_rows[:, 0].astype(np.int64), g_ents[:, 0].astype(np.int64), g_ents[:, 1].astype(np.int64), g_rows[:, 1].astype(np.int64),
+            g_rows[:, 2].astype(np.int64))
+
+
+def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, engine_cls=None, finish=None, dense_over_shards=None):
     """Row-sharded echelonize of A (every rank passes the same matrix; rank r keeps rows r, r + G, ...).
     Per round: all-reduce(MIN) of the election keys, all-gather of the elected pivot rows, local Schur complement of the
     rank's rows.  When at most `finish_nnz` entries are left in total, or the remainder is dense enough for the dense tail
@@ -266,6 +391,11 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
     sparsity_threshold = float(api.EchelonizeOpts().struct.sparsity_threshold)
     n, m, prime = A.n, A.m, int(A.prime)
     eng = engine_cls(A, rank, n, stride=world)  # the rank's rows stay on its device from here on
+    # the dense finish over the ranks: primes below 2^16 (the int8 path), engines that have the steps (the numpy engine of the
+    # protocol tests has not).  With it the "one round ahead" rule below is not needed: the estimate after the exchange decides.
+    if dense_over_shards is None:
+        dense_over_shards = True
+    dense_ok = bool(dense_over_shards) and prime < 65536 and isinstance(eng, GpuRoundEngine) and world <= 16
     blocks = []  # per round: (row lengths, columns, values, pivot columns, original rows) of its rows of U
     n_u = 0
     rounds = []
@@ -284,7 +414,7 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
             # fill keeps growing at the rate of the last round, would the NEXT Schur complement be dense?  Then it is never built
             # sparse here (100k x 100k, 6 per row: the round that was skipped wrote 3.4e8 entries that the hand-off then had to
             # gather: 9 of 15 s).
-            if rounds and not rounds[-1]["finish"] and rounds[-1]["nnz"] > 0 and nnz_left > rounds[-1]["nnz"]:
+            if not dense_ok and rounds and not rounds[-1]["finish"] and rounds[-1]["nnz"] > 0 and nnz_left > rounds[-1]["nnz"]:
                 predicted = nnz_left * (nnz_left / rounds[-1]["nnz"])
                 dense_enough = dense_enough or predicted > sparsity_threshold * rows_left * max(free_cols, 1)
             if nnz_left <= finish_nnz or len(rounds) >= max_rounds or dense_enough:
@@ -324,7 +454,10 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
             hdr, ent = eng.export()
             hdr_all = all_gather_var(hdr, counts[:, 0].tolist(), group)
             ent_all = all_gather_var(ent, counts[:, 1].tolist(), group)
-            eng.import_(hdr_all, ent_all)
+            if dense_ok:
+                eng.import_(hdr_all, ent_all, prepare=False)
+            else:
+                eng.import_(hdr_all, ent_all)
             t_exchange = _time.time()
             # the round's rows of U come from the engine as it built them on the device (scaled to a unit pivot, in pivot order):
             # nothing is recomputed on the host
@@ -333,6 +466,20 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
                 blocks.append(blk)
                 n_u += len(blk[0])
             t_u = _time.time()
+            if dense_ok:
+                # is the Schur complement of this round dense?  Then it is never built sparse: all ranks eliminate it together
+                got = dense_round_sharded(eng, m - n_u, sparsity_threshold, group)
+                if got is not None:
+                    dblk, dpiv = got
+                    dblk = _gather_U_blocks(dblk, group)
+                    if len(dblk[0]):
+                        blocks.append(dblk)
+                        n_u += len(dblk[0])
+                    rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv), "seconds": {}})
+                    rounds.append({"round": len(rounds), "finish": True, "dense_over_shards": True, "rows": rows_left, "nnz": -1, "npiv": int(dpiv),
+                                   "seconds": {"dense_finish": _time.time() - t_u}})
+                    break
+                eng.prepare()
             eng.advance()  # the round runs; its Schur rows are the shard's matrix of the next round, still on the device
             rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv),
                            "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4),

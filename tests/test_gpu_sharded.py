@@ -234,3 +234,72 @@ def test_dense_finish_over_row_shards_rank_deficient(S, O, monkeypatch):
     assert np.asarray(got.qinv >= 0).tolist() == np.asarray(ref.qinv >= 0).tolist()
     assert S.factorization_verify(A, got, 7)
     assert S.kernel(got).rows() == S.kernel(ref).rows()
+
+
+def _dense_over_ranks_worker(rank, world, port, kind, n, m, kw, p, seed, env, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    for k, v in env.items():
+        os.environ[k] = v
+    import torch
+    import torch.distributed as dist
+
+    import spasm_jl_amd as S
+    from spasm_jl_amd import sharded
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        A = S.synth_csr(kind, n, m, prime=p, seed=seed, **kw)
+        fact, info = sharded.echelonize_sharded(A, finish_nnz=1000)
+        assert S.factorization_verify(A, fact, 9)
+        K = S.kernel(fact)
+        q.put((rank, fact.r, np.asarray(fact.qinv).tolist(), np.asarray(fact.p).tolist(), K.rows(),
+               [(r["finish"], r["npiv"], bool(r.get("dense_over_shards"))) for r in info["rounds"]]))
+    except Exception as exc:
+        import traceback
+
+        q.put((rank, -1, repr(exc) + traceback.format_exc(), [], [], []))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,n,m,kw,p,env", [
+    (2, 2, 4000, 1600, dict(row_nnz=30), 127, dict()),
+    (4, 2, 5000, 2000, dict(row_nnz=30), 127, dict(SPASM_AMD_DENSE_KB="128")),
+    (3, 1, 1500, 1200, dict(row_nnz=30), 65521, dict(SPASM_AMD_DENSE_KB="256")),
+], ids=["macaulay_2_ranks", "macaulay_4_ranks_several_blocks", "two_digits_3_ranks"])
+def test_dense_finish_over_ranks(S, O, world, kind, n, m, kw, p, env):
+    """The dense finish with ONE PROCESS PER SHARD (sharded.dense_round_sharded over the spasm_amd_dshard_* steps):
+    2, 3 and 4 ranks share the test box's one GPU, the exchanges -- an all-gather of the candidate records, one broadcast of the
+    winners' rows per owner -- go over gloo.  Every rank returns the same LU; rank, pivot columns and kernel are those of the
+    single-device leftmost-pivot run; the run must have taken the distributed finish."""
+    seed = 0x0D15
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dense_over_ranks_worker, args=(r, world, port, kind, n, m, kw, p, seed, env, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] >= 0 for r in results), [r[2] for r in results]
+    assert all(pr.exitcode == 0 for pr in procs)
+    A = S.synth_csr(kind, n, m, prime=p, seed=seed, **kw)
+    ref = S.echelonize(A, **LM)
+    refK = S.kernel(ref)
+    assert ref.r == O.echelonize(A, **LM).r
+    results.sort()
+    for rank, r, qinv, perm, Krows, rounds in results:
+        assert r == ref.r
+        assert [c >= 0 for c in qinv] == [c >= 0 for c in np.asarray(ref.qinv).tolist()]
+        assert Krows == refK.rows()
+        assert len(set(perm[:r])) == r and all(0 <= g < n for g in perm[:r])
+        assert rounds == results[0][5]
+        assert any(d for _, _, d in rounds), rounds                        # the finish went over the ranks
+        assert sum(np_ for _, np_, _ in rounds) == ref.r
