@@ -2192,6 +2192,16 @@ int dense_eliminate(DevBuf<DT> &D, int R, int C, i64 ldc, const int *clist, cons
 
 #include "dense_tall.hpp"
 
+// cells of dense matrix a finish of `rows` x `cols` keeps resident: all of it, or -- tall and skinny -- the first slab and a batch
+double dense_cells_resident(const struct echelonize_opts *opts, const ZpField &F, i64 rows, i64 cols)
+{
+    if (rows <= INT_MAX && cols <= INT_MAX && tall_applies(opts, F, rows, cols)) {
+        const i64 slab = tall_first_slab((int)rows, (int)cols);
+        return ((double)slab + (double)std::min<i64>(rows - slab, 131072)) * (double)cols;
+    }
+    return (double)rows * (double)cols;
+}
+
 // the live rows of a sparse matrix, a range at a time, as dense rows (RowSource of dense_tall.hpp)
 template <typename DT> struct FillRowSource {
     const DevMat &M;
@@ -2673,7 +2683,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         {
             const i64 cfree = (i64)m - (i64)U.pivcol.size();
             const double cells = (double)cur_live * (double)cfree;
-            if (use_dense && cur_nnz > 0 && cells > 0 && cells <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) &&
+            if (use_dense && cur_nnz > 0 && cells > 0 && dense_cells_resident(opts, R->F, cur_live, cfree) <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) &&
                 (double)cur_nnz > opts->sparsity_threshold * cells) {
                 spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                            cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
@@ -2711,7 +2721,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
                 // dense when the remainder is dense enough (the reference's rule) or small enough for the cubic work not to matter
                 // (2^28 cells: a 16384 x 16384 remainder); a large sparse remainder is better served by more sparse rounds
                 const bool worth = (double)cur_nnz > opts->sparsity_threshold * cells || cells <= (double)((i64)1 << 28);
-                if (use_dense && cells > 0 && cells <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) && worth) {
+                if (use_dense && cells > 0 && dense_cells_resident(opts, R->F, cur_live, cfree) <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) && worth) {
                     spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                                cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
                     run_dense_tail(*cur, R->F, U, stream, opts);
@@ -2768,7 +2778,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         double rec_per_row = 4.0 * (double)cur_nnz / (double)std::max(nnp, 1), slots_per_row = 0;
         double est_density = -1;
         const int free_now = m - (int)U.pivcol.size() - R->npiv;
-        const bool dense_possible = use_dense && nnp > 64 && (double)nnp * (double)free_now <= (double)dense_max_entries(dense_elem_bytes(R->F, nnp));
+        const bool dense_possible = use_dense && nnp > 64 && dense_cells_resident(opts, R->F, nnp, free_now) <= (double)dense_max_entries(dense_elem_bytes(R->F, nnp));
         std::unique_ptr<DenseW> dw;
         if (nnp > 0 && dense_possible && !R->use_uinv && !R->use_w) {
             // No Uinv: the rows of this round reach many pivots (or there are few rows), and the row sample below would walk those
