@@ -76,11 +76,11 @@ while time.time() < t_end:
     else:
         env = dict(SPASM_AMD_GREEDY_REACH_MAX=int(rng.choice([0, 1, 2, 8, 64, 1024])), SPASM_AMD_GREEDY_OCC_MAX=int(rng.choice([1, 2, 5, 1 << 30])))
         setenv(**env)
-        got = S.echelonize(A, enable_greedy_pivot_search=True, enable_dense=False, max_round=2)
-        og = O.echelonize(A, enable_greedy_pivot_search=True, max_round=2)
+        # (one sparse round: what follows it differs in the ORDER of the rows of U -- the engine finishes in rounds, the oracle row by row)
+        got = S.echelonize(A, enable_greedy_pivot_search=True, enable_dense=False, max_round=1)
+        og = O.echelonize(A, enable_greedy_pivot_search=True, max_round=1)
         assert got.r == og.r == ref.r and pattern(got) == pattern(og), ("greedy engine vs oracle", case, A.n, A.m, p, env)
-        r0 = S.last_rounds()
-        k = sum(r["npiv"] for r in r0 if r["round"] < 2)
+        k = S.last_rounds()[0]["npiv"]
         assert got.U.rows()[:k] == og.U.rows()[:k], ("greedy rows of U", case, A.n, A.m, p, env)
         assert S.factorization_verify(A, got, 3), ("greedy verify", case, env)
         assert S.kernel(got).rows() == O.kernel(og).rows(), ("greedy kernel", case, env)
