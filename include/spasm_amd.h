@@ -390,6 +390,11 @@ void spasm_amd_dshard_close(spasm_amd_dshard *ds);
  * 1 = a round's Schur complement straight to dense on all shards, 2 = the dense remainder on all shards. */
 int spasm_amd_multi_last_finish(void);
 
+/* rank(A) = rank(echelonize(A)) (reference src/SpaSM.jl:1149) without materialising U on the host: the pivot rows are counted where
+ * they are found.  For matrices whose U outgrows the host (BASELINE config 5: 10^10 entries and more above 1/3 scale).  Same
+ * options as spasm_echelonize (L excluded); -1 on error. */
+i64 spasm_amd_rank(const struct spasm_csr *A, struct echelonize_opts *opts);
+
 /* Per-round records of the most recent spasm_echelonize call on this thread. */
 int spasm_amd_last_rounds(struct spasm_amd_round_stats *out, int max_rounds);
 

@@ -190,6 +190,7 @@ SIGNATURES = {
     "spasm_amd_schur_plan_fetch": (_P(CsrStruct), [C.c_void_p, _P(C.c_int32)]),
     "spasm_amd_schur_plan_free": (None, [C.c_void_p]),
     "spasm_amd_last_rounds": (C.c_int32, [_P(RoundStats), C.c_int32]),
+    "spasm_amd_rank": (C.c_int64, [_P(CsrStruct), _P(EchelonizeOptsStruct)]),
     "spasm_amd_zp_probe": (C.c_int32, [C.c_int64, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "spasm_amd_shard_create": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32]),
     "spasm_amd_shard_create_strided": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),

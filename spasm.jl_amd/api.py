@@ -476,9 +476,23 @@ def factorization_verify(A, fact, seed=0):
     return bool(_abi.lib().spasm_factorization_verify(A.data, fact.data, int(seed) & 0xFFFFFFFFFFFFFFFF))
 
 
-def rank(A, **kwargs):
-    """rank(N::LU) = N.r; rank(A::CSR) = rank(echelonize(A)) (reference src/SpaSM.jl:305, :1149)."""
-    return A.r if isinstance(A, LU) else echelonize(A, **kwargs).r
+def rank(A, rank_only=False, verbose=False, **kwargs):
+    """rank(N::LU) = N.r; rank(A::CSR) = rank(echelonize(A)) (reference src/SpaSM.jl:305, :1149).  rank_only=True (engine extension,
+    spasm_amd_rank): the rows of U are counted on the device and never assembled on the host -- for matrices whose U outgrows it."""
+    if isinstance(A, LU):
+        return A.r
+    if not rank_only:
+        return echelonize(A, verbose=verbose, **kwargs).r
+    opts = EchelonizeOpts()
+    for k, v in kwargs.items():
+        if not hasattr(opts.struct, k):
+            raise AttributeError(f"type EchelonizeOpts has no field {k}")
+        setattr(opts.struct, k, v)
+    with _quiet(not verbose):
+        r = _abi.lib().spasm_amd_rank(A.data, C.byref(opts.struct))
+    if r < 0:
+        raise SpasmError("spasm_amd_rank failed: " + _abi.last_error())
+    return int(r)
 
 
 def last_rounds(max_rounds=4096):

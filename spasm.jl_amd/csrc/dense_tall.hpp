@@ -99,6 +99,7 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     src.fill(0, R1, D1.p);
     HIPCHK(hipStreamSynchronize(s));
     const double tf1 = spasm_wtime() - t0;
+    if ((double)R1 * (double)C > 4e9) spasm_logf("[echelonize/dense] tall and skinny: %d x %d; first slab of %d rows built [%.2fs], eliminating\n", R, C, R1, tf1);
     UStreamer us; // (the slab's rows of U leave for the host block by block while it is eliminated)
     us.init(D1.p, C, ldc, pc1.p, clist, row_orig, U);
     if (!dense_eliminate_i8(D1, R1, C, ldc, F, pc1, s, &us)) throw EngineError("dense finish: shape outside the panel kernel's range");
@@ -120,6 +121,7 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     }
     // ---- 2. columns with / without pivot; Z = the reduced form of the slab's pivot rows on the columns without
     const double t1 = spasm_wtime();
+    if ((double)R1 * (double)C > 4e9) spasm_logf("[echelonize/dense] tall and skinny: first slab: %d pivots [%.2fs]; reduced form on the %d columns left\n", r1, te1, f);
     Scanner scan;
     DevBuf<int> pflag, pscan, pcol, prow, fcol, fclist;
     pflag.alloc((size_t)C + 1); pscan.alloc((size_t)C + 1); pcol.alloc((size_t)r1 + 1); prow.alloc((size_t)r1 + 1); fcol.alloc((size_t)f + 1); fclist.alloc((size_t)f + 1);
@@ -181,6 +183,10 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
         HIPCHK(hipGetLastError());
         for (int s0 = 0; s0 < r1; s0 += W.KB)
             W.gemm_sub(Tb, ldz, cnt, Db.p, ldc, nullptr, pcol.p + s0, std::min(W.KB, r1 - s0), Z.p + (size_t)s0 * (size_t)ldz, ldz, f);
+        if ((double)R1 * (double)C > 4e9) {
+            HIPCHK(hipStreamSynchronize(s));
+            spasm_logf("[echelonize/dense] tall and skinny: %lld of %d other rows reduced [%.1fs]\n", (long long)(off + cnt), R2, spasm_wtime() - t2);
+        }
     }
     HIPCHK(hipStreamSynchronize(s));
     Db.release();

@@ -1689,13 +1689,17 @@ struct HostU {
     HostInts j, x;
     std::vector<int> pivcol; // pivot column of each row
     std::vector<int> orig;   // originating row of the input
+    // rank only (spasm_amd_rank): the rows of U are counted, their entries never leave the device -- at config 5's scale they are
+    // what outgrows the host (10^10 entries and more), not anything the device holds
+    bool rank_only = false;
+    i64 uncollected = 0;     // pivots counted without a row of U to show for them
 };
 
 // entries of pivot rows (device, {col,val} pairs) appended to the host arrays of U: split on the device, downloaded straight
 // into the tails of U.j / U.x (was: a host copy of the pairs and 2 x nnz push_backs -- a third of config 2's echelonize)
 void append_entries(HostU &U, const int2 *dent, i64 count, hipStream_t s)
 {
-    if (count <= 0) return;
+    if (count <= 0 || U.rank_only) return;
     DevBuf<int> dj, dx;
     dj.alloc((size_t)count);
     dx.alloc((size_t)count);
@@ -1790,6 +1794,7 @@ int dense_extract_range(const DT *Dp, int C, i64 ldc, const int *pivrow_of_col, 
     HIPCHK(hipMemcpyAsync(&npd, pscan.p + nc, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (npd == 0) return 0;
+    if (U.rank_only) { U.uncollected += npd; return npd; }
     DevBuf<i64d> &ulen = W.ulen, &uoff = W.uoff;
     ulen.ensure((size_t)npd + 1024); uoff.ensure((size_t)npd + 1024);
     HIPCHK(hipMemsetAsync(ulen.p, 0, ((size_t)npd + 1) * sizeof(i64d), s));
@@ -2074,6 +2079,7 @@ int dense_extract_U(const DT *Dp, int C, i64 ldc, const int *pivrow_of_col, cons
     HIPCHK(hipMemcpyAsync(&npd, pscan.p + C, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (npd == 0) return 0;
+    if (U.rank_only) { U.uncollected += npd; return npd; }
     DevBuf<i64d> ulen, uoff;
     ulen.alloc((size_t)npd + 1); uoff.alloc((size_t)npd + 1);
     ulen.zero(s);
@@ -2196,10 +2202,23 @@ int dense_eliminate(DevBuf<DT> &D, int R, int C, i64 ldc, const int *clist, cons
 double dense_cells_resident(const struct echelonize_opts *opts, const ZpField &F, i64 rows, i64 cols)
 {
     if (rows <= INT_MAX && cols <= INT_MAX && tall_applies(opts, F, rows, cols)) {
+        // (the slab, and the smallest batch of other rows: batches and the dense W adapt to what memory is left)
         const i64 slab = tall_first_slab((int)rows, (int)cols);
-        return ((double)slab + (double)std::min<i64>(rows - slab, 131072)) * (double)cols;
+        return ((double)slab + (double)std::min<i64>(rows - slab, 4096)) * (double)cols;
     }
     return (double)rows * (double)cols;
+}
+
+// cells the finish of `rows` x `cols` may keep resident: the shape cap of dense_max_entries, or -- tall and skinny, where the resident
+// part is the slab that carries the pivots and cannot be smaller -- what 55 % of the free memory holds (config 5 at full size:
+// a slab of 365k x 324k bytes = 118 GB)
+double dense_cells_allowed(const struct echelonize_opts *opts, const ZpField &F, i64 rows, i64 cols, int elem)
+{
+    if (rows <= INT_MAX && cols <= INT_MAX && tall_applies(opts, F, rows, cols)) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) return 0.55 * (double)fr / (double)std::max(elem, 1);
+    }
+    return (double)dense_max_entries(elem);
 }
 
 // the live rows of a sparse matrix, a range at a time, as dense rows (RowSource of dense_tall.hpp)
@@ -2640,7 +2659,7 @@ void collect_L_pivots(HostL &L, Round &R, const HostU &U, int ubase, hipStream_t
 struct HostL;
 struct spasm_lu *assemble_lu(HostU &U, int n, int m, i64 prime, HostL *HLp);
 
-struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts)
+struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts, i64 *rank_only = nullptr)
 {
     // max_round, min_pivot_proportion, enable_dense and sparsity_threshold (reference src/SpaSM.jl:329-337) decide how far the
     // sparse rounds go and what finishes.  With enable_greedy_pivot_search off every pivot is a leftmost entry, and rank, pivot
@@ -2659,6 +2678,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     hipStream_t stream = nullptr;
     HostU U;
     U.p.push_back(0);
+    U.rank_only = rank_only != nullptr;
     std::unique_ptr<DevMat> cur(new DevMat());
     upload_csr(A, 0, n, *cur, stream);
     i64 cur_nnz = spasm_nnz(A);
@@ -2683,7 +2703,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         {
             const i64 cfree = (i64)m - (i64)U.pivcol.size();
             const double cells = (double)cur_live * (double)cfree;
-            if (use_dense && cur_nnz > 0 && cells > 0 && dense_cells_resident(opts, R->F, cur_live, cfree) <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) &&
+            if (use_dense && cur_nnz > 0 && cells > 0 && dense_cells_resident(opts, R->F, cur_live, cfree) <= dense_cells_allowed(opts, R->F, cur_live, cfree, dense_elem_bytes(R->F, cur_live)) &&
                 (double)cur_nnz > opts->sparsity_threshold * cells) {
                 spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                            cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
@@ -2721,7 +2741,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
                 // dense when the remainder is dense enough (the reference's rule) or small enough for the cubic work not to matter
                 // (2^28 cells: a 16384 x 16384 remainder); a large sparse remainder is better served by more sparse rounds
                 const bool worth = (double)cur_nnz > opts->sparsity_threshold * cells || cells <= (double)((i64)1 << 28);
-                if (use_dense && cells > 0 && dense_cells_resident(opts, R->F, cur_live, cfree) <= (double)dense_max_entries(dense_elem_bytes(R->F, cur_live)) && worth) {
+                if (use_dense && cells > 0 && dense_cells_resident(opts, R->F, cur_live, cfree) <= dense_cells_allowed(opts, R->F, cur_live, cfree, dense_elem_bytes(R->F, cur_live)) && worth) {
                     spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", (double)cur_nnz / cells,
                                cfree > 0 ? (double)cur_live / (double)cfree : 0.0);
                     run_dense_tail(*cur, R->F, U, stream, opts);
@@ -2778,7 +2798,7 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         double rec_per_row = 4.0 * (double)cur_nnz / (double)std::max(nnp, 1), slots_per_row = 0;
         double est_density = -1;
         const int free_now = m - (int)U.pivcol.size() - R->npiv;
-        const bool dense_possible = use_dense && nnp > 64 && dense_cells_resident(opts, R->F, nnp, free_now) <= (double)dense_max_entries(dense_elem_bytes(R->F, nnp));
+        const bool dense_possible = use_dense && nnp > 64 && dense_cells_resident(opts, R->F, nnp, free_now) <= dense_cells_allowed(opts, R->F, nnp, free_now, dense_elem_bytes(R->F, nnp));
         std::unique_ptr<DenseW> dw;
         if (nnp > 0 && dense_possible && !R->use_uinv && !R->use_w) {
             // No Uinv: the rows of this round reach many pivots (or there are few rows), and the row sample below would walk those
@@ -2945,6 +2965,12 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         if (cur_nnz == 0) break;
     }
 
+    if (rank_only) {
+        *rank_only = (i64)U.pivcol.size() + U.uncollected;
+        spasm_logf("[echelonize] Done in %.1fs. Rank %lld%s (rank only: the rows of U stayed on the device)\n", spasm_wtime() - t0, (long long)*rank_only,
+                   partial ? " (not finished: a lower bound)" : "");
+        return nullptr;
+    }
     struct spasm_lu *N = assemble_lu(U, n, m, prime, want_L ? &HL : nullptr);
     spasm_logf("[echelonize] Done in %.1fs. Rank %d%s, %lld nz in basis\n", spasm_wtime() - t0, N->r, partial ? " (not finished: a lower bound)" : "", (long long)U.p.back());
     return N;
@@ -4499,6 +4525,24 @@ SPASM_API struct spasm_lu *spasm_echelonize(const struct spasm_csr *A, struct ec
     } catch (const std::exception &e) {
         spasm_set_error("spasm_echelonize: %s", e.what());
         return nullptr;
+    }
+}
+
+// rank(A) = rank(echelonize(A)) (reference src/SpaSM.jl:1149) without the rows of U ever leaving the device; -1 on error
+SPASM_API i64 spasm_amd_rank(const struct spasm_csr *A, struct echelonize_opts *opts)
+{
+    spasm_clear_error();
+    try {
+        struct echelonize_opts o;
+        if (opts) o = *opts;
+        else spasm_echelonize_init_opts(&o);
+        if (o.L) throw EngineError("the L factor needs the rows of U");
+        i64 r = -1;
+        (void)do_echelonize(A, &o, &r);
+        return r;
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_rank: %s", e.what());
+        return -1;
     }
 }
 

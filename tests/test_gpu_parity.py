@@ -966,3 +966,25 @@ def test_tall_and_skinny_finish_of_a_schur_complement(S, O, monkeypatch, env):
     assert np.asarray(fact.qinv >= 0).tolist() == np.asarray(olu.qinv >= 0).tolist()
     assert S.kernel(fact).rows() == O.kernel(olu).rows()
     assert S.factorization_verify(A, fact, 9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,m,kw,prime,env", [
+    (1, 3000, 3000, dict(row_nnz=6), 65521, {}),
+    (2, 6000, 1500, dict(row_nnz=40), 127, dict(SPASM_AMD_TALL="1", SPASM_AMD_TALL_SLAB="256")),
+    (2, 4000, 1600, dict(row_nnz=40), 127, dict(SPASM_AMD_TALL="0")),
+    (0, 900, 1300, dict(density=0.01), 2147483647, {}),
+    (0, 500, 300, dict(density=0.4), 0xFFFFFFFB, {}),
+], ids=["sparse_rounds_then_dense", "tall_finish", "dense_finish", "f64_panels", "rank1_updates"])
+def test_rank_only_counts_what_echelonize_finds(S, O, monkeypatch, kind, n, m, kw, prime, env):
+    """spasm_amd_rank (rank(A), reference src/SpaSM.jl:1149, without the rows of U on the host): the same rank as the factorization
+    and as the oracle, through every finish."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0x4A4B, **kw)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    full = S.echelonize(A)
+    r = S.rank(A, rank_only=True)
+    r_lm = S.rank(A, rank_only=True, enable_greedy_pivot_search=False)
+    for k in env:
+        monkeypatch.delenv(k)
+    assert r == r_lm == full.r == O.echelonize(A, **LM).r

@@ -7,6 +7,10 @@ scale = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 n, m = 5_000_000 // scale, 2_000_000 // scale
 t0 = time.time(); A = S.synth_csr(2, n, m, row_nnz=40, prime=127, seed=0x5A5A0005); t1 = time.time()
 print(f"generated {n} x {m}, nnz {S.nnz(A)} in {t1-t0:.2f}s", flush=True)
+if "--rank-only" in sys.argv:   # spasm_amd_rank: the rows of U never leave the device (above 1/3 scale they outgrow the host)
+    t0 = time.time(); r = S.rank(A, rank_only=True, verbose=("-v" in sys.argv)); t1 = time.time()
+    print(f"rank only {t1-t0:.3f}s rank {r}", flush=True)
+    sys.exit(0)
 t0 = time.time(); fact = S.echelonize(A, verbose=("-v" in sys.argv)); t1 = time.time()
 print(f"echelonize {t1-t0:.3f}s rank {fact.r} nnz(U) {S.nnz(fact.U)}", flush=True)
 for r in S.last_rounds():
