@@ -858,13 +858,14 @@ __global__ void k_or_int(int n, int *__restrict__ a, const int *__restrict__ b)
 // ================================================================================================
 
 // F[d][i][k] = digit d of D[rowidx ? rowidx[i] : i][cols[k]], k < K; 0 for K <= k < Kpad
+// (col_off: D holds a slab of the columns, starting at column col_off of the numbering `cols` uses)
 template <int ND, typename DT>
 __global__ __launch_bounds__(256) void k_tall_gather_F(int nrows, const int *__restrict__ rowidx, const DT *__restrict__ D, i64d ldc, const int *__restrict__ cols, int K,
-                                                       int Kpad, ZpField F, signed char *__restrict__ Fd, i64d fplane, int KB)
+                                                       int Kpad, ZpField F, signed char *__restrict__ Fd, i64d fplane, int KB, int col_off = 0)
 {
     const int i = blockIdx.x;
     if (i >= nrows) return;
-    const i64d src = (i64d)(rowidx ? rowidx[i] : i) * ldc;
+    const i64d src = (i64d)(rowidx ? rowidx[i] : i) * ldc - col_off;
     for (int k = threadIdx.x; k < Kpad; k += 256) {
         int v = k < K ? (int)D[src + cols[k]] : 0;
         int d0, d1;
@@ -899,6 +900,17 @@ __global__ __launch_bounds__(256) void k_tall_gather_cols(int nrows, const int *
     if (i >= nrows) return;
     const i64d src = (i64d)(rowidx ? rowidx[i] : i) * ldc;
     for (int j = threadIdx.x; j < (int)ldo; j += 256) out[(i64d)i * ldo + j] = j < ncols ? D[src + cols[j]] : (DT)0;
+}
+
+// out[i][j0 + j] = D[i][cols[j] - col_off], j < ncols: the columns cols[0 .. ncols) of a slab of D that starts at column col_off
+template <typename DT>
+__global__ __launch_bounds__(256) void k_tall_gather_slab(int nrows, const DT *__restrict__ D, i64d ldc, const int *__restrict__ cols, int ncols, int col_off,
+                                                          DT *__restrict__ out, i64d ldo, int j0)
+{
+    const int i = blockIdx.x;
+    if (i >= nrows) return;
+    const i64d src = (i64d)i * ldc - col_off;
+    for (int j = threadIdx.x; j < ncols; j += 256) out[(i64d)i * ldo + j0 + j] = D[src + cols[j]];
 }
 
 // back substitution inside a block of nb <= 64 pivots (rows t0 .. t0 + nb of Z, pivot rows prow[t], pivot columns pcol[t]):

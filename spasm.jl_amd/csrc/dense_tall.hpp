@@ -4,7 +4,8 @@
 //
 // RowSource: where the dense rows come from -- fill(off, cnt, Dp) writes rows off .. off + cnt of the remainder, all C columns,
 // into Dp (cnt x ldc, zero on entry): the Schur rows of a round through the dense W (SchurRowSource) or the live rows of the
-// current matrix (FillRowSource).  Rows are only ever materialised a slab at a time.
+// current matrix (FillRowSource).  Rows are only ever materialised a slab at a time.  For the rows beyond the first slab the source
+// is asked column slab by column slab (nslabs, slab_range, prepare_slab -- the dense W of the slab, built once --, fill_slab).
 #pragma once
 
 struct TallStats {
@@ -38,20 +39,20 @@ template <typename DT> struct TallWork {
         }
     }
     // T[i][0 .. ncols) -= sum_k Src[rowidx ? rowidx[i] : i][cols[k]] * Z[k][0 .. ncols), i < nrows, k < K (K <= KB)
-    void gemm_sub(DT *T, i64 ldt, int nrows, const DT *Src, i64 lds, const int *rowidx, const int *cols, int K, const DT *Z, i64 ldz, int ncols)
+    void gemm_sub(DT *T, i64 ldt, int nrows, const DT *Src, i64 lds, const int *rowidx, const int *cols, int K, const DT *Z, i64 ldz, int ncols, int col_off = 0)
     {
         if (nrows <= 0 || K <= 0 || ncols <= 0) return;
         ensure(nrows, ncols);
         const int Kpad = (K + 63) / 64 * 64;
         const int ncp = (ncols + 63) / 64 * 64 + 128;
         if (ND == 1) {
-            hipLaunchKernelGGL((k_tall_gather_F<1, DT>), dim3(nrows), dim3(256), 0, s, nrows, rowidx, Src, (i64d)lds, cols, K, Kpad, F, Fd.p, (i64d)fplane, KB);
+            hipLaunchKernelGGL((k_tall_gather_F<1, DT>), dim3(nrows), dim3(256), 0, s, nrows, rowidx, Src, (i64d)lds, cols, K, Kpad, F, Fd.p, (i64d)fplane, KB, col_off);
             hipLaunchKernelGGL((k_tall_Ut<1, DT>), dim3(ncp), dim3(256), 0, s, Z, (i64d)ldz, K, Kpad, ncols, ncp, F, Ut.p, (i64d)uplane, KB);
             const int ntm = cdiv(nrows, 128), ntn = cdiv(ncols, 128);
             hipLaunchKernelGGL((k_gemm_i8<1, 2, 2, 2, 2, DT>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, nrows, 0, ncols, 0, Kpad, F, T, (i64d)ldt, live.p, (const int *)nullptr, 0,
                                Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB, ntm, ntn);
         } else {
-            hipLaunchKernelGGL((k_tall_gather_F<2, DT>), dim3(nrows), dim3(256), 0, s, nrows, rowidx, Src, (i64d)lds, cols, K, Kpad, F, Fd.p, (i64d)fplane, KB);
+            hipLaunchKernelGGL((k_tall_gather_F<2, DT>), dim3(nrows), dim3(256), 0, s, nrows, rowidx, Src, (i64d)lds, cols, K, Kpad, F, Fd.p, (i64d)fplane, KB, col_off);
             hipLaunchKernelGGL((k_tall_Ut<2, DT>), dim3(ncp), dim3(256), 0, s, Z, (i64d)ldz, K, Kpad, ncols, ncp, F, Ut.p, (i64d)uplane, KB);
             const int ntm = cdiv(nrows, 128), ntn = cdiv(ncols, 64);
             hipLaunchKernelGGL((k_gemm_i8<2, 4, 1, 1, 2, DT>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, nrows, 0, ncols, 0, Kpad, F, T, (i64d)ldt, live.p, (const int *)nullptr, 0,
@@ -158,34 +159,58 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     HIPCHK(hipStreamSynchronize(s));
     D1.release();
     ts.t_z = spasm_wtime() - t1;
-    // ---- 3. every other row in one step: t = d_N - d_P Z, a batch of rows at a time
+    // ---- 3. every other row in one step: t = d_N - d_P Z.  Column slab by column slab of the source (the dense W of a slab is built
+    // once: config 5 at full size has six, and rebuilding them for every batch of rows took 205 of the run's 268 s), a batch of rows
+    // at a time inside; T collects the residuals of all rows.
     const double t2 = spasm_wtime();
     DevBuf<DT> T;
     T.alloc((size_t)R2 * (size_t)ldz);
-    size_t fr = 0, tot = 0;
-    HIPCHK(hipMemGetInfo(&fr, &tot));
-    // (at most 128k rows at a time: a batch buffer of tens of GB costs more to allocate and to clear than the launches of more batches)
-    i64 RB = std::min<i64>(131072, std::max<i64>(4096, (i64)(fr / 4) / ((i64)ldc * (i64)sizeof(DT)) / 128 * 128));
-    if (const char *e = getenv("SPASM_AMD_TALL_BATCH")) RB = std::max<i64>(128, atoll(e) / 128 * 128); // tests: several batches
-    RB = std::min<i64>(RB, ((i64)R2 + 127) / 128 * 128);
-    DevBuf<DT> Db;
-    Db.alloc((size_t)RB * (size_t)ldc);
+    T.zero(s);
+    std::vector<int> h_pcol((size_t)std::max(r1, 1)), h_fcol((size_t)std::max(f, 1));
+    if (r1 > 0) HIPCHK(hipMemcpyAsync(h_pcol.data(), pcol.p, (size_t)r1 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_fcol.data(), fcol.p, (size_t)f * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     double tf2 = 0;
-    for (i64 off = 0; off < R2; off += RB) {
-        const int cnt = (int)std::min<i64>(RB, R2 - off);
+    const int nsl = src.nslabs();
+    DevBuf<DT> Db;
+    for (int k = 0; k < nsl; k++) {
+        i64 s0 = 0;
+        int w = 0;
+        src.slab_range(k, s0, w);
+        const int pa = (int)(std::lower_bound(h_pcol.begin(), h_pcol.begin() + r1, (int)s0) - h_pcol.begin());
+        const int pb = (int)(std::lower_bound(h_pcol.begin(), h_pcol.begin() + r1, (int)std::min<i64>(s0 + w, INT_MAX)) - h_pcol.begin());
+        const int fa = (int)(std::lower_bound(h_fcol.begin(), h_fcol.begin() + f, (int)s0) - h_fcol.begin());
+        const int fb = (int)(std::lower_bound(h_fcol.begin(), h_fcol.begin() + f, (int)std::min<i64>(s0 + w, INT_MAX)) - h_fcol.begin());
+        if (pa == pb && fa == fb) continue;
         const double tb = spasm_wtime();
-        HIPCHK(hipMemsetAsync(Db.p, 0, (size_t)cnt * (size_t)ldc * sizeof(DT), s));
-        src.fill(R1 + (int)off, cnt, Db.p);
+        src.prepare_slab(k);
         HIPCHK(hipStreamSynchronize(s));
         tf2 += spasm_wtime() - tb;
-        DT *Tb = T.p + (size_t)off * (size_t)ldz;
-        hipLaunchKernelGGL((k_tall_gather_cols<DT>), dim3(cnt), dim3(256), 0, s, cnt, (const int *)nullptr, Db.p, (i64d)ldc, fcol.p, f, Tb, (i64d)ldz);
-        HIPCHK(hipGetLastError());
-        for (int s0 = 0; s0 < r1; s0 += W.KB)
-            W.gemm_sub(Tb, ldz, cnt, Db.p, ldc, nullptr, pcol.p + s0, std::min(W.KB, r1 - s0), Z.p + (size_t)s0 * (size_t)ldz, ldz, f);
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        // (at most 128k rows at a time: a batch buffer of tens of GB costs more to allocate and to clear than the launches of more batches)
+        i64 RB = std::min<i64>(131072, std::max<i64>(4096, (i64)((fr + Db.n * sizeof(DT)) / 4) / ((i64)w * (i64)sizeof(DT)) / 128 * 128));
+        if (const char *e = getenv("SPASM_AMD_TALL_BATCH")) RB = std::max<i64>(128, atoll(e) / 128 * 128); // tests: several batches
+        RB = std::min<i64>(RB, ((i64)R2 + 127) / 128 * 128);
+        Db.ensure((size_t)RB * (size_t)w);
+        for (i64 off = 0; off < R2; off += RB) {
+            const int cnt = (int)std::min<i64>(RB, R2 - off);
+            const double tc = spasm_wtime();
+            HIPCHK(hipMemsetAsync(Db.p, 0, (size_t)cnt * (size_t)w * sizeof(DT), s));
+            src.fill_slab(k, R1 + (int)off, cnt, Db.p, (i64)w);
+            HIPCHK(hipStreamSynchronize(s));
+            tf2 += spasm_wtime() - tc;
+            DT *Tb = T.p + (size_t)off * (size_t)ldz;
+            if (fb > fa) {
+                hipLaunchKernelGGL((k_tall_gather_slab<DT>), dim3(cnt), dim3(256), 0, s, cnt, Db.p, (i64d)w, fcol.p + fa, fb - fa, (int)s0, Tb, (i64d)ldz, fa);
+                HIPCHK(hipGetLastError());
+            }
+            for (int c0 = pa; c0 < pb; c0 += W.KB)
+                W.gemm_sub(Tb, ldz, cnt, Db.p, (i64)w, nullptr, pcol.p + c0, std::min(W.KB, pb - c0), Z.p + (size_t)c0 * (size_t)ldz, ldz, f, (int)s0);
+        }
         if ((double)R1 * (double)C > 4e9) {
             HIPCHK(hipStreamSynchronize(s));
-            spasm_logf("[echelonize/dense] tall and skinny: %lld of %d other rows reduced [%.1fs]\n", (long long)(off + cnt), R2, spasm_wtime() - t2);
+            spasm_logf("[echelonize/dense] tall and skinny: column slab %d of %d applied to the %d other rows [%.1fs]\n", k + 1, nsl, R2, spasm_wtime() - t2);
         }
     }
     HIPCHK(hipStreamSynchronize(s));

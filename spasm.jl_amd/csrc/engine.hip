@@ -2233,6 +2233,10 @@ template <typename DT> struct FillRowSource {
         hipLaunchKernelGGL((k_dense_fill<DT>), dim3(cdiv((i64)cnt * 64, 256)), dim3(256), 0, s, cnt, rows + off, M.start.p, M.len.p, M.ent.p, cmap, Dp, (i64d)ldc);
         HIPCHK(hipGetLastError());
     }
+    int nslabs() const { return 1; }
+    void slab_range(int, i64 &s0, int &w) const { s0 = 0; w = (int)ldc; }
+    void prepare_slab(int) {}
+    void fill_slab(int, int off, int cnt, DT *Dp, i64) { fill(off, cnt, Dp); }
     void done() {}
 };
 
@@ -2555,6 +2559,26 @@ template <typename DT> struct SchurRowSource {
             }
             W.rows_into(R.np_rows.p + off, cnt, w, Dp, ldc, (int)s0);
         }
+    }
+    int nslabs() const { return (int)((ldc + Cs - 1) / Cs); }
+    void slab_range(int k, i64 &s0, int &w) const { s0 = (i64)k * Cs; w = (int)std::min<i64>(Cs, ldc - s0); }
+    void prepare_slab(int k)
+    {
+        if (Cs >= ldc && built) return;
+        i64 s0;
+        int w;
+        slab_range(k, s0, w);
+        W.slab((int)s0, w, 0);
+        W.build_w(w);
+        built = true;
+    }
+    // rows off .. off + cnt on the columns of the slab prepare_slab(k) has built: Dp[i][j], j < w, leading dimension ldw
+    void fill_slab(int k, int off, int cnt, DT *Dp, i64 ldw)
+    {
+        i64 s0;
+        int w;
+        slab_range(k, s0, w);
+        if (cnt > 0) W.rows_into(R.np_rows.p + off, cnt, w, Dp, ldw, 0);
     }
     void done() { W.Wd.release(); built = false; }
 };
