@@ -466,6 +466,14 @@ __global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, DT *_
 // C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 #define GI_LDS_STRIDE 80
 #define GI_BAND 32
+// stages of K in flight in registers (one digit / two digits).  Four (168 VGPRs, no scratch) changed nothing: 0.420 s against 0.413 s
+// for the GEMMs of config 5 at 1/5 -- the kernel does not wait for the latency of its loads, it is bound by what LDS and L1 carry
+#ifndef GI_NPF
+#define GI_NPF 1
+#endif
+#ifndef GI_NPF2
+#define GI_NPF2 1
+#endif
 template <int ND, int APT, int BPT>
 __device__ __forceinline__ void gemm_i8_fetch(v4i32 (&ra)[ND][APT], v4i32 (&rb)[ND][BPT], const signed char *__restrict__ Fd, i64d fplane,
                                               const signed char *__restrict__ Ut, i64d uplane, const i64d (&aoff)[APT], i64d boff, int KB, int ks)
@@ -532,23 +540,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k
     // software pipeline: the global loads of stage s + 1 are in flight while stage s is multiplied out of LDS.  (Check the
     // ISA after touching this: when the staging registers end up in scratch memory every "prefetch" is waited for and spilled at once.)
     // Rows that are skipped load row 0 instead of branching around the load; their products are never stored.
-    v4i32 ra[ND][APT], rb[ND][BPT]; // (native vectors: arrays of HIP's int4 struct stayed in scratch memory)
+    // GI_NPF stages of 64 bytes of K are in flight in registers (see GI_NPF: deeper than one bought nothing)
+    constexpr int NPF = ND == 1 ? GI_NPF : GI_NPF2;
+    v4i32 ra[NPF][ND][APT], rb[NPF][ND][BPT]; // (native vectors: arrays of HIP's int4 struct stayed in scratch memory)
     i64d aoff[APT];
 #pragma unroll
     for (int u = 0; u < APT; u++) aoff[u] = (i64d)(gia[u] >= 0 ? gia[u] : 0) * KB + k0 + seg * 16;
     const i64d boff = (i64d)(j0 + prow) * KB + k0 + seg * 16;
-    gemm_i8_fetch<ND, APT, BPT>(ra, rb, Fd, fplane, Ut, uplane, aoff, boff, KB, 0);
-    for (int ks = 0; ks < K; ks += 64) {
+#pragma unroll
+    for (int p = 0; p < NPF; p++)
+        if (64 * p < K) gemm_i8_fetch<ND, APT, BPT>(ra[p], rb[p], Fd, fplane, Ut, uplane, aoff, boff, KB, 64 * p);
+    for (int ks0 = 0; ks0 < K; ks0 += 64 * NPF) {
+#pragma unroll
+      for (int p = 0; p < NPF; p++) {
+        const int ks = ks0 + 64 * p;
+        if (ks >= K) break; // (uniform)
         __syncthreads(); // the previous stage has been consumed
 #pragma unroll
         for (int d = 0; d < ND; d++) {
 #pragma unroll
-            for (int u = 0; u < APT; u++) *(v4i32 *)(&s_a[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = ra[d][u];
+            for (int u = 0; u < APT; u++) *(v4i32 *)(&s_a[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = ra[p][d][u];
 #pragma unroll
-            for (int u = 0; u < BPT; u++) *(v4i32 *)(&s_b[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = rb[d][u];
+            for (int u = 0; u < BPT; u++) *(v4i32 *)(&s_b[d][(prow + 64 * u) * GI_LDS_STRIDE + seg * 16]) = rb[p][d][u];
         }
         __syncthreads();
-        if (ks + 64 < K) gemm_i8_fetch<ND, APT, BPT>(ra, rb, Fd, fplane, Ut, uplane, aoff, boff, KB, ks + 64);
+        if (ks + 64 * NPF < K) gemm_i8_fetch<ND, APT, BPT>(ra[p], rb[p], Fd, fplane, Ut, uplane, aoff, boff, KB, ks + 64 * NPF);
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             const int ko = kk * 32 + 16 * (lane >> 5);
@@ -572,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k
                     }
                 }
         }
+      }
     }
     // epilogue, tile by tile: the 16 elements of D a lane owns are loaded together (rows that are skipped read row 0 and are not
     // stored), then reduced, then stored -- one round trip per tile, not one per element
