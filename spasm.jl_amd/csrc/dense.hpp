@@ -486,8 +486,8 @@ __device__ __forceinline__ void gemm_i8_fetch(v4i32 (&ra)[ND][APT], v4i32 (&rb)[
         for (int u = 0; u < BPT; u++) rb[d][u] = *(const v4i32 *)(Ut + (i64d)d * uplane + boff + (i64d)(64 * u) * KB + ks);
     }
 }
-template <int ND, int WM, int WN, int TM, int TN, typename DT>
-__global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, DT *__restrict__ D, i64d ldc, const int *__restrict__ seq,
+template <int ND, int WM, int WN, int TM, int TN, typename DT, int MINB = 2, int NPFX = 0>
+__global__ __launch_bounds__(256, MINB) void k_gemm_i8(int R, int ja, int jb, int k0, int K, ZpField F, DT *__restrict__ D, i64d ldc, const int *__restrict__ seq,
                                                     const int *__restrict__ rows, int nrows, const signed char *__restrict__ Fd, i64d fplane,
                                                     const signed char *__restrict__ Ut, i64d uplane, int KB, int ntm, int ntn)
 {
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(int R, int ja, int jb, int k
     // ISA after touching this: when the staging registers end up in scratch memory every "prefetch" is waited for and spilled at once.)
     // Rows that are skipped load row 0 instead of branching around the load; their products are never stored.
     // GI_NPF stages of 64 bytes of K are in flight in registers (see GI_NPF: deeper than one bought nothing)
-    constexpr int NPF = ND == 1 ? GI_NPF : GI_NPF2;
+    constexpr int NPF = NPFX ? NPFX : (ND == 1 ? GI_NPF : GI_NPF2);
     v4i32 ra[NPF][ND][APT], rb[NPF][ND][BPT]; // (native vectors: arrays of HIP's int4 struct stayed in scratch memory)
     i64d aoff[APT];
 #pragma unroll

@@ -1914,7 +1914,7 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     DevBuf<int> follow_flag;
     if (tall) follow_flag.alloc(1);
     int redone = 0, npanels_done = 0;
-    const int Cp = (int)ldc + 128; // (the GEMM stages whole tiles of 128 columns of Ut, starting at any multiple of 64)
+    const int Cp = (int)ldc + 256; // (the GEMM stages whole tiles of 128 or 256 columns of Ut, starting at any multiple of 64)
     DevBuf<DT> P;
     DevBuf<int> seq, candrow, invtab;
     DevBuf<signed char> Fd, Ut;
