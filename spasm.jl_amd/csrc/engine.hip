@@ -4118,6 +4118,10 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
         const int elem = F0.p <= 255 ? 1 : 2;
         const char *gather_env = getenv("SPASM_AMD_MULTI_GATHER");
         const bool ddf_ok = opts->enable_dense && F0.small && nshards * DP_W <= 147456 / (DP_W * elem) && nshards <= DM_MAXSHARDS && !(gather_env && atoi(gather_env));
+        // .. and remainders worth it: below 16 GiB of dense matrix one device finishes faster than the shards exchange panels
+        // (a 44k x 44k remainder over two ranks: 25 s of collectives against 1 s).  SPASM_AMD_MULTI_DENSE_MIN_BYTES (tests): 0.
+        double dense_min_bytes = 17179869184.0;
+        if (const char *e = getenv("SPASM_AMD_MULTI_DENSE_MIN_BYTES")) dense_min_bytes = atof(e);
         std::vector<int> devs((size_t)nshards);
         for (int k = 0; k < nshards; k++) devs[(size_t)k] = dev_of(k);
         // does a dense matrix of `rows` local rows and `cols` columns fit a shard's device beside what the elimination needs?
@@ -4214,9 +4218,10 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
             // (one round ahead as well: when the fill keeps growing at the rate of the last round the next Schur complement would
             // be dense -- it is then never built sparse; the single-device density estimate plays this role there)
             // (with the distributed finish the estimate after the election decides instead: dense_round)
-            if (!ddf_ok && last_nnz > 0 && nnz_left > last_nnz)
+            const bool ddf_now = ddf_ok && cells * (double)elem >= dense_min_bytes;
+            if (!ddf_now && last_nnz > 0 && nnz_left > last_nnz)
                 dense_enough = dense_enough || (opts->enable_dense && (double)nnz_left * ((double)nnz_left / (double)last_nnz) > opts->sparsity_threshold * cells);
-            if (ddf_ok && dense_enough && nnz_left > finish_nnz) {
+            if (ddf_now && dense_enough && nnz_left > finish_nnz) {
                 spasm_logf("[echelonize] finishing; density = %.3f; aspect ratio = %.1f; dense finish on %d shards\n", (double)nnz_left / cells,
                            free_cols > 0 ? (double)rows_left / (double)free_cols : 0.0, nshards);
                 if (dense_now()) { g_multi_finish = 2; break; }
@@ -4224,7 +4229,7 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
             // max_round sparse rounds are over and the remainder is still sparse: the single-device engine would elect once more and
             // estimate the density of that Schur complement before choosing its finish -- so do the shards, once
             const bool spent = round >= opts->max_round;
-            const bool one_more = ddf_ok && spent && !extra_round_done && !dense_enough && nnz_left > finish_nnz;
+            const bool one_more = ddf_now && spent && !extra_round_done && !dense_enough && nnz_left > finish_nnz;
             if (one_more) extra_round_done = true;
             if (!one_more && (nnz_left <= finish_nnz || spent || dense_enough)) {
                 // ---- hand-off: the remaining rows, under their original numbers, to the single-device engine on device 0
@@ -4334,7 +4339,7 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
                 HIPCHK(hipSetDevice(dev_of(k)));
                 ShardState &q = *st[(size_t)k];
                 spasm_amd_shard *sh = q.sh;
-                q.plan = shard_import(sh, npiv, tot_ent, q.hdr_all.p, q.ent_all.p, !ddf_ok); // (the shard hands its matrix to the plan)
+                q.plan = shard_import(sh, npiv, tot_ent, q.hdr_all.p, q.ent_all.p, !ddf_now); // (the shard hands its matrix to the plan)
                 q.sh = nullptr;
                 delete sh;
             }
@@ -4356,7 +4361,7 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
                 }
                 spasm_csr_free(Uc);
             }
-            if (ddf_ok) {
+            if (ddf_now) {
                 if (dense_round()) {
                     g_multi_finish = 1;
                     spasm_logf("[echelonize] round %d (sharded): %d pivots, %lld rows / %lld entries before it; its Schur complement went dense\n", round, npiv,

@@ -396,6 +396,12 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
     if dense_over_shards is None:
         dense_over_shards = True
     dense_ok = bool(dense_over_shards) and prime < 65536 and isinstance(eng, GpuRoundEngine) and world <= 16
+    # .. and remainders worth it: below 16 GiB of dense matrix one device finishes faster than the ranks exchange panels (a 44k x 44k
+    # remainder over two gloo ranks: 25 s of collectives against 1 s).  SPASM_AMD_MULTI_DENSE_MIN_BYTES (tests): 0.
+    import os as _os
+
+    dense_min_bytes = float(_os.environ.get("SPASM_AMD_MULTI_DENSE_MIN_BYTES", 1 << 34))
+    dense_allowed, elem = dense_ok, (1 if prime <= 255 else 2)
     blocks = []  # per round: (row lengths, columns, values, pivot columns, original rows) of its rows of U
     n_u = 0
     rounds = []
@@ -409,6 +415,7 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
             if nnz_left == 0:
                 break
             free_cols = m - n_u
+            dense_ok = dense_allowed and rows_left * max(free_cols, 1) * elem >= dense_min_bytes
             dense_enough = nnz_left > sparsity_threshold * rows_left * max(free_cols, 1)  # the single-device rule for its dense tail
             # ... applied one round ahead as well, like the single-device density estimate (spasm_schur_estimate_density): when the
             # fill keeps growing at the rate of the last round, would the NEXT Schur complement be dense?  Then it is never built
@@ -432,7 +439,18 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
                 sel = _ranges(starts[:-1][order], g_len[order])
                 rest = _virtual_csr(n, m, prime, g_ids[order], np.concatenate([[0], np.cumsum(g_len[order])]), g_ent[sel, 0], g_ent[sel, 1])
                 t_gather = _time.time()
-                fact = finish(rest)
+                # Ranks that SHARE a device (rehearsals on a one-GPU box) take turns: the dense finish's panel kernel is a persistent
+                # grid with its own barrier, and two of them from different processes cannot both be resident on one device (the
+                # kernel gives up with "a grid barrier ... timed out").  One device per rank: all at once.
+                shared = world > 1 and torch.cuda.is_available() and torch.cuda.device_count() < world
+                if shared:
+                    fact = None
+                    for turn in range(world):
+                        if turn == rank:
+                            fact = finish(rest)
+                        dist.barrier(group=group)
+                else:
+                    fact = finish(rest)
                 t_finish = _time.time()
                 Uc, fp, fq = fact.U, np.asarray(fact.p), np.asarray(fact.qinv)
                 up, uj, ux = np.asarray(Uc.p), np.asarray(Uc.j), np.asarray(Uc.x)

@@ -196,6 +196,7 @@ def test_dense_finish_over_row_shards(S, O, monkeypatch, kind, n, m, kw, prime, 
     distinct rows of A."""
     A = S.synth_csr(kind, n, m, prime=prime, seed=0xDD5E, **kw)
     ref = S.echelonize(A, **LM)
+    monkeypatch.setenv("SPASM_AMD_MULTI_DENSE_MIN_BYTES", "0")  # (by default remainders below 16 GiB are finished on one device)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     got = S.echelonize_multi(A, nshards)
@@ -227,6 +228,7 @@ def test_dense_finish_over_row_shards_rank_deficient(S, O, monkeypatch):
     A = S.CSR(M.T.copy(), prime=p)
     ref = S.echelonize(A, **LM)
     monkeypatch.setenv("SPASM_AMD_MULTI_FINISH_NNZ", "1000")
+    monkeypatch.setenv("SPASM_AMD_MULTI_DENSE_MIN_BYTES", "0")
     monkeypatch.setenv("SPASM_AMD_DENSE_KB", "128")
     got = S.echelonize_multi(A, 3)
     assert S._abi.lib().spasm_amd_multi_last_finish() == 2
@@ -241,6 +243,7 @@ def _dense_over_ranks_worker(rank, world, port, kind, n, m, kw, p, seed, env, q)
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "tests")]
+    os.environ["SPASM_AMD_MULTI_DENSE_MIN_BYTES"] = "0"  # (by default remainders below 16 GiB are finished on one device)
     for k, v in env.items():
         os.environ[k] = v
     import torch

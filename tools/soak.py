@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 LM = dict(enable_greedy_pivot_search=False)
 t_end = time.time() + budget
 done = {"multi": 0, "tall": 0, "greedy": 0}
-KEYS = ["SPASM_AMD_MULTI_FINISH_NNZ", "SPASM_AMD_DENSE_KB", "SPASM_AMD_TALL", "SPASM_AMD_TALL_SLAB", "SPASM_AMD_TALL_BATCH", "SPASM_AMD_GREEDY_REACH_MAX",
+KEYS = ["SPASM_AMD_MULTI_DENSE_MIN_BYTES", "SPASM_AMD_MULTI_FINISH_NNZ", "SPASM_AMD_DENSE_KB", "SPASM_AMD_TALL", "SPASM_AMD_TALL_SLAB", "SPASM_AMD_TALL_BATCH", "SPASM_AMD_GREEDY_REACH_MAX",
         "SPASM_AMD_GREEDY_OCC_MAX", "SPASM_AMD_PANEL_GLOBAL"]
 
 
@@ -59,7 +59,7 @@ while time.time() < t_end:
     which = case % 3
     if which == 0:
         nsh = int(rng.integers(1, 9))
-        env = dict(SPASM_AMD_MULTI_FINISH_NNZ=int(rng.choice([1, 1000, 1 << 22])), SPASM_AMD_DENSE_KB=int(rng.choice([64, 128, 256, 1024])))
+        env = dict(SPASM_AMD_MULTI_DENSE_MIN_BYTES=0, SPASM_AMD_MULTI_FINISH_NNZ=int(rng.choice([1, 1000, 1 << 22])), SPASM_AMD_DENSE_KB=int(rng.choice([64, 128, 256, 1024])))
         if rng.random() < 0.2:
             env["SPASM_AMD_PANEL_GLOBAL"] = 1
         setenv(**env)

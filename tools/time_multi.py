@@ -2,6 +2,7 @@
    python tools/time_multi.py CONFIG SCALE NSHARDS [-v] [--verify]     CONFIG 5 = Macaulay-like 5M x 2M / SCALE, p = 127;
                                                                         CONFIG 3 = 1M x 1M / SCALE, 20 per row, p = 65521"""
 import sys, time, os
+os.environ.setdefault("SPASM_AMD_MULTI_DENSE_MIN_BYTES", "0")  # (time the dense finish over the shards whatever the size)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import spasm_jl_amd as S
