@@ -5001,6 +5001,9 @@ SPASM_API int spasm_amd_multi_last_finish(void) { return g_multi_finish; }
     spasm_clear_error();                                               \
     try { body }                                                       \
     catch (const std::exception &e) { spasm_set_error(name ": %s", e.what()); return fail; }
+// (a step called out of order -- no handle, or before dshard_build -- is an error, not a crash)
+#define DSHARD_BUILT(ds) do { if (!(ds) || !(ds)->impl) throw EngineError("no dense shard (spasm_amd_dshard_open / _density / _build come first)"); } while (0)
+#define DSHARD_OPEN(ds) do { if (!(ds) || !(ds)->dw) throw EngineError("no dense shard (spasm_amd_dshard_open comes first)"); } while (0)
 
 SPASM_API spasm_amd_schur_plan *spasm_amd_shard_import_U(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev)
 {
@@ -5016,12 +5019,12 @@ SPASM_API spasm_amd_dshard *spasm_amd_dshard_open(spasm_amd_schur_plan *plan, in
 }
 SPASM_API int spasm_amd_dshard_flags(spasm_amd_dshard *ds, int *flags_dev)
 {
-    DSHARD_TRY("spasm_amd_dshard_flags",
+    DSHARD_TRY("spasm_amd_dshard_flags", DSHARD_OPEN(ds);
                HIPCHK(hipMemcpy(flags_dev, ds->dw->cflag.p, ((size_t)ds->plan->A.m + 1) * sizeof(int), hipMemcpyDeviceToDevice)); return 0;, -1)
 }
 SPASM_API double spasm_amd_dshard_density(spasm_amd_dshard *ds, const int *flags_dev, int free_cols, int *C_out)
 {
-    DSHARD_TRY("spasm_amd_dshard_density",
+    DSHARD_TRY("spasm_amd_dshard_density", DSHARD_OPEN(ds);
                HIPCHK(hipMemcpy(ds->dw->cflag.p, flags_dev, ((size_t)ds->plan->A.m + 1) * sizeof(int), hipMemcpyDeviceToDevice));
                ds->C = ds->dw->finish_columns();
                if (C_out) *C_out = ds->C;
@@ -5030,7 +5033,7 @@ SPASM_API double spasm_amd_dshard_density(spasm_amd_dshard *ds, const int *flags
 }
 SPASM_API int spasm_amd_dshard_build(spasm_amd_dshard *ds)
 {
-    DSHARD_TRY("spasm_amd_dshard_build",
+    DSHARD_TRY("spasm_amd_dshard_build", DSHARD_OPEN(ds);
                if (ds->C <= 0) throw EngineError("no column left (call spasm_amd_dshard_density first)");
                if (ds->plan->R.F.p <= 255) ds->impl.reset(new DShardT<signed char>());
                else ds->impl.reset(new DShardT<short>());
@@ -5039,34 +5042,34 @@ SPASM_API int spasm_amd_dshard_build(spasm_amd_dshard *ds)
 }
 SPASM_API int spasm_amd_dshard_info(spasm_amd_dshard *ds, int *C_out, int *KB, i64 *ldc, int *elem, int *nd, int *cand_bytes)
 {
-    DSHARD_TRY("spasm_amd_dshard_info", if (!ds->impl) throw EngineError("not built"); if (C_out) *C_out = ds->C; ds->impl->info(KB, ldc, elem, nd);
+    DSHARD_TRY("spasm_amd_dshard_info", DSHARD_BUILT(ds); if (C_out) *C_out = ds->C; ds->impl->info(KB, ldc, elem, nd);
                if (cand_bytes) *cand_bytes = (int)sizeof(CandRec); return 0;, -1)
 }
-SPASM_API int spasm_amd_dshard_block_begin(spasm_amd_dshard *ds) { DSHARD_TRY("spasm_amd_dshard_block_begin", ds->impl->block_begin(); return 0;, -1) }
+SPASM_API int spasm_amd_dshard_block_begin(spasm_amd_dshard *ds) { DSHARD_TRY("spasm_amd_dshard_block_begin", DSHARD_BUILT(ds); ds->impl->block_begin(); return 0;, -1) }
 SPASM_API int spasm_amd_dshard_candidates(spasm_amd_dshard *ds, int c0, int w, void *cand_dev)
 {
-    DSHARD_TRY("spasm_amd_dshard_candidates", ds->impl->candidates(c0, w, cand_dev); return 0;, -1)
+    DSHARD_TRY("spasm_amd_dshard_candidates", DSHARD_BUILT(ds); ds->impl->candidates(c0, w, cand_dev); return 0;, -1)
 }
 SPASM_API int spasm_amd_dshard_elect(spasm_amd_dshard *ds, const void *stack_dev, int w, int *npp, int *cnt, int *first)
 {
-    DSHARD_TRY("spasm_amd_dshard_elect", ds->impl->elect(stack_dev, w); if (npp) *npp = ds->impl->hglob.npp;
+    DSHARD_TRY("spasm_amd_dshard_elect", DSHARD_BUILT(ds); ds->impl->elect(stack_dev, w); if (npp) *npp = ds->impl->hglob.npp;
                for (int k = 0; k < ds->nshards; k++) { if (cnt) cnt[k] = ds->impl->hglob.cnt[k]; if (first) first[k] = ds->impl->hglob.first[k]; }
                return 0;, -1)
 }
-SPASM_API i64 spasm_amd_dshard_pack(spasm_amd_dshard *ds, int c0, void *buf_dev) { DSHARD_TRY("spasm_amd_dshard_pack", return ds->impl->pack(c0, buf_dev);, -1) }
+SPASM_API i64 spasm_amd_dshard_pack(spasm_amd_dshard *ds, int c0, void *buf_dev) { DSHARD_TRY("spasm_amd_dshard_pack", DSHARD_BUILT(ds); return ds->impl->pack(c0, buf_dev);, -1) }
 SPASM_API int spasm_amd_dshard_unpack(spasm_amd_dshard *ds, int q, int c0, int owner, const void *buf_dev)
 {
-    DSHARD_TRY("spasm_amd_dshard_unpack", ds->impl->unpack(q, c0, owner, buf_dev); return 0;, -1)
+    DSHARD_TRY("spasm_amd_dshard_unpack", DSHARD_BUILT(ds); ds->impl->unpack(q, c0, owner, buf_dev); return 0;, -1)
 }
-SPASM_API int spasm_amd_dshard_apply(spasm_amd_dshard *ds, int q, int c0, int w, int b1) { DSHARD_TRY("spasm_amd_dshard_apply", ds->impl->apply(q, c0, w, b1); return 0;, -1) }
+SPASM_API int spasm_amd_dshard_apply(spasm_amd_dshard *ds, int q, int c0, int w, int b1) { DSHARD_TRY("spasm_amd_dshard_apply", DSHARD_BUILT(ds); ds->impl->apply(q, c0, w, b1); return 0;, -1) }
 SPASM_API int spasm_amd_dshard_block_end(spasm_amd_dshard *ds, int b0, int b1, int npan)
 {
-    DSHARD_TRY("spasm_amd_dshard_block_end", ds->impl->block_end(b0, b1, npan); return 0;, -1)
+    DSHARD_TRY("spasm_amd_dshard_block_end", DSHARD_BUILT(ds); ds->impl->block_end(b0, b1, npan); return 0;, -1)
 }
-SPASM_API int spasm_amd_dshard_finish(spasm_amd_dshard *ds) { DSHARD_TRY("spasm_amd_dshard_finish", return ds->impl->finish();, -1) }
+SPASM_API int spasm_amd_dshard_finish(spasm_amd_dshard *ds) { DSHARD_TRY("spasm_amd_dshard_finish", DSHARD_BUILT(ds); return ds->impl->finish();, -1) }
 SPASM_API struct spasm_csr *spasm_amd_dshard_fetch_U(spasm_amd_dshard *ds, int *pivcol_out, int *row_out, int *n_out)
 {
-    DSHARD_TRY("spasm_amd_dshard_fetch_U", return dshard_fetch_U(ds, pivcol_out, row_out, n_out);, nullptr)
+    DSHARD_TRY("spasm_amd_dshard_fetch_U", DSHARD_BUILT(ds); return dshard_fetch_U(ds, pivcol_out, row_out, n_out);, nullptr)
 }
 SPASM_API void spasm_amd_dshard_close(spasm_amd_dshard *ds) { delete ds; }
 

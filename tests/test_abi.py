@@ -94,3 +94,19 @@ def test_hot_path_fails_loudly_without_gpu(S):
         S.echelonize(A, **LM)
     with pytest.raises(S.SpasmError, match="no HIP device"):
         S.transpose(A)
+
+
+def test_dense_shard_steps_out_of_order_are_errors_not_crashes():
+    """The per-process steps of the dense finish over row shards (spasm_amd_dshard_*) without a handle: an error code and a message."""
+    import ctypes as C
+
+    from spasm_jl_amd import _abi
+
+    lib = _abi.lib()
+    assert lib.spasm_amd_dshard_block_begin(None) == -1 and "dense shard" in _abi.last_error()
+    assert lib.spasm_amd_dshard_apply(None, 0, 0, 64, 64) == -1
+    assert lib.spasm_amd_dshard_finish(None) == -1
+    assert lib.spasm_amd_dshard_pack(None, 0, None) == -1
+    assert not lib.spasm_amd_dshard_fetch_U(None, None, None, None)
+    assert not lib.spasm_amd_dshard_open(None, 0, 2) and "null plan" in _abi.last_error()
+    lib.spasm_amd_dshard_close(None)
