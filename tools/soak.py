@@ -1,6 +1,6 @@
 """Randomised soak of the round-3 paths against the single-device leftmost-pivot run and the oracle (small matrices, many shapes):
 the dense finish over row shards (random shard counts and block sizes), the tall-and-skinny finish (random slabs and batches), the
-greedy search (random limits; engine vs oracle pair for pair through max_round = 1 runs).   python tools/soak.py [seconds=120] [seed=1]"""
+greedy search (random limits; engine vs oracle pair for pair through max_round = 1 runs).   python tools/soak.py [seconds=120] [seed=1] [scale=1]"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [root, os.path.join(root, "tests")]
@@ -10,6 +10,7 @@ import oracle_ffi as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+SC = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # matrix sizes times SC
 LM = dict(enable_greedy_pivot_search=False)
 t_end = time.time() + budget
 done = {"multi": 0, "tall": 0, "greedy": 0}
@@ -32,18 +33,18 @@ def random_matrix():
     p = int(rng.choice([3, 7, 127, 251, 257, 42013, 65521]))
     kind = int(rng.integers(0, 4))
     if kind == 0:      # sparse, fixed entries per row
-        n, m = int(rng.integers(50, 3000)), int(rng.integers(50, 3000))
+        n, m = int(rng.integers(50, 3000 * SC)), int(rng.integers(50, 3000 * SC))
         return S.synth_csr(1, n, m, row_nnz=int(rng.integers(2, min(m, 12))), prime=p, seed=int(rng.integers(1 << 30))), p
     if kind == 1:      # Macaulay-like
-        m = int(rng.integers(200, 1500)); n = int(m * rng.uniform(1.5, 4))
+        m = int(rng.integers(200, 1500 * SC)); n = int(m * rng.uniform(1.5, 4))
         return S.synth_csr(2, n, m, row_nnz=int(rng.integers(10, 40)), prime=p, seed=int(rng.integers(1 << 30))), p
     if kind == 2:      # dense, low rank pieces
-        m = int(rng.integers(20, 400)); n = int(rng.integers(20, 1500)); r = int(rng.integers(1, min(n, m) + 1))
+        m = int(rng.integers(20, 400 * SC)); n = int(rng.integers(20, 1500 * SC)); r = int(rng.integers(1, min(n, m) + 1))
         M = (rng.integers(0, p, size=(n, r)).astype(np.int64).dot(rng.integers(0, p, size=(r, m)).astype(np.int64))) % p
         if rng.random() < 0.5:
             M[:, rng.integers(0, m, size=max(1, m // 10))] = 0
         return S.CSR(M.T.copy(), prime=p), p
-    n, m = int(rng.integers(30, 1200)), int(rng.integers(30, 1200))   # Bernoulli
+    n, m = int(rng.integers(30, 1200 * SC)), int(rng.integers(30, 1200 * SC))   # Bernoulli
     return S.synth_csr(0, n, m, density=float(rng.uniform(0.01, 0.4)), prime=p, seed=int(rng.integers(1 << 30))), p
 
 
