@@ -590,39 +590,74 @@ __global__ __launch_bounds__(256, MINB) void k_gemm_i8(int R, int ja, int jb, in
         }
       }
     }
-    // epilogue, tile by tile: the 16 elements of D a lane owns are loaded together (rows that are skipped read row 0 and are not
-    // stored), then reduced, then stored -- one round trip per tile, not one per element
+    // epilogue.  A lane holds 16 ROWS of one column of every 32 x 32 tile (the MFMA's C layout): written to D as it is that is 16
+    // narrow loads and 16 narrow stores per tile and lane -- as much time in the address path as the tile's MFMAs take (the LDS-DMA
+    // kernel below gained 15 % from this change alone).  Each tile goes through LDS instead (the staging buffers are free now) and
+    // comes back row-wise: a lane then owns 16 consecutive elements of one row of D -- 16-byte loads and stores.
+    static_assert(sizeof(DT) <= 2, "D is kept as bytes or shorts");
+    __syncthreads();
+    // 32 rows of 36 ints per wave: waves 0, 1 in s_a, waves 2, 3 in s_b (each at least 10 KB)
+    static_assert(sizeof(s_a) >= 2 * 32 * 36 * 4 && sizeof(s_b) >= 2 * 32 * 36 * 4, "epilogue scratch");
+    int *S = (int *)(wave < 2 ? &s_a[0][0] : &s_b[0][0]) + (wave & 1) * (32 * 36);
+    const int erow = lane >> 1, ecol = (lane & 1) * 16;
 #pragma unroll
     for (int m = 0; m < TM; m++)
 #pragma unroll
         for (int n = 0; n < TN; n++) {
-            const int col = j0 + (wn * TN + n) * 32 + (lane & 31);
-            const bool colok = col < jb;
-            const int ccol = colok ? col : ja;
-            int gis[16];
-            int dv[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int mrow = (wm * TM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                gis[r] = s_gi[mrow];
-                dv[r] = (int)D[(i64d)(gis[r] >= 0 ? gis[r] : 0) * ldc + ccol];
+                int w;
+                if (ND == 1) w = acc[0][m][n][r];
+                else w = zp_reduce(F, (long long)acc[0][m][n][r] + (long long)acc[A1][m][n][r] * 256 + (long long)acc[A2][m][n][r] * 65536);
+                S[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = w;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int av[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                int x;
-                if (ND == 1) {
-                    // |acc| <= K * 127^2 < 2^25 for K <= 2048: 32-bit lazy reduction (|x / p| < 2^22) and one correction
-                    x = zp_small_lazy(dv[r] - acc[0][m][n][r], -F.finvp, (int)F.p);
-                    if (x > (int)F.halfp) x -= (int)F.p;
-                    else if (x < (int)F.mhalfp) x += (int)F.p;
-                } else {
-                    const long long v = (long long)acc[0][m][n][r] + (long long)acc[A1][m][n][r] * 256 + (long long)acc[A2][m][n][r] * 65536;
-                    x = zp_reduce(F, (long long)dv[r] - v);
+            for (int q = 0; q < 4; q++) {
+                const v4i32 t = *(const v4i32 *)(S + erow * 36 + ecol + 4 * q);
+                av[4 * q] = t[0]; av[4 * q + 1] = t[1]; av[4 * q + 2] = t[2]; av[4 * q + 3] = t[3];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int gi = s_gi[(wm * TM + m) * 32 + erow];
+            const int col0 = j0 + (wn * TN + n) * 32 + ecol;
+            if (gi >= 0 && col0 < jb) {
+                DT *dp = D + (i64d)gi * ldc + col0;
+                constexpr int NV = (int)sizeof(DT); // 16-byte pieces of the 16 elements
+                v4i32 in[NV], out[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) in[v] = ((const v4i32 *)dp)[v];
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    int dvv;
+                    if (NV == 1) dvv = (int)(signed char)((in[0][e >> 2] >> (8 * (e & 3))) & 255);
+                    else dvv = (int)(short)((in[e >> 3][(e >> 1) & 3] >> (16 * (e & 1))) & 65535);
+                    int x;
+                    if (ND == 1) {
+                        // |acc| <= K * 127^2 < 2^25 for K <= 2048: 32-bit lazy reduction (|x / p| < 2^22) and one correction
+                        x = zp_small_lazy(dvv - av[e], -F.finvp, (int)F.p);
+                        if (x > (int)F.halfp) x -= (int)F.p;
+                        else if (x < (int)F.mhalfp) x += (int)F.p;
+                    } else {
+                        x = dvv - av[e]; // both balanced residues
+                        if (x > (int)F.halfp) x -= (int)F.p;
+                        else if (x < (int)F.mhalfp) x += (int)F.p;
+                    }
+                    if (col0 + e >= jb) x = dvv;
+                    if (NV == 1) {
+                        if ((e & 3) == 0) out[0][e >> 2] = 0;
+                        out[0][e >> 2] |= (x & 255) << (8 * (e & 3));
+                    } else {
+                        if ((e & 1) == 0) out[e >> 3][(e >> 1) & 3] = 0;
+                        out[e >> 3][(e >> 1) & 3] |= (x & 65535) << (16 * (e & 1));
+                    }
                 }
-                if (gis[r] >= 0 && colok) D[(i64d)gis[r] * ldc + col] = (DT)x;
+#pragma unroll
+                for (int v = 0; v < NV; v++) ((v4i32 *)dp)[v] = out[v];
             }
         }
 }
+
 
 // ================================================================================================
 // Dense finish over ROW SHARDS (engine.hip: dense_finish_multi).  Rows never move: every shard keeps its rows of D, eliminates
@@ -986,4 +1021,159 @@ __global__ void k_gather_int2(int n, const int *__restrict__ idx, const int *__r
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];
+}
+
+// ================================================================================================
+// The large updates of the one-digit finish (p < 2^8) on a 256 x 256 tile: the structure the CDNA guide names for getting past the
+// ceiling of the 128 x 128, two-barriers-per-stage kernel above -- one workgroup of 8 waves per CU, operands by LDS-DMA
+// (global_load_lds, 16 bytes per lane: no staging registers), four LDS buffers, the loads of two K-tiles in flight ACROSS raw
+// barriers (counted vmcnt, never 0 in the loop).  LDS image of a K-tile (64 bytes of K): A[row][64 bytes] and B[row][64 bytes] -- a wave
+// instruction of the DMA fills 16 rows, four lanes per row (whole 64-byte runs of global memory) --, the four 16-byte pieces of a row
+// permuted by (row >> 1) & 3 on the SOURCE side so that the fragment reads (32 rows, one piece) fall on all banks.
+// Waves 2 (rows) x 4 (columns), 128 x 64 each: 4 x 2 tiles of 32 x 32.
+// ================================================================================================
+#define GL_BM 256
+#define GL_BN 256
+#define GL_NBUF 4
+#define GL_TILE_BYTES 32768 // A 16 KB + B 16 KB per K-tile
+#define GL_LDS_BYTES (GL_NBUF * GL_TILE_BYTES + GL_BM * 4)
+
+__device__ __forceinline__ void gl_dma16(const signed char *g, unsigned char *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+template <typename DT>
+__global__ __launch_bounds__(512, 1) void k_gemm_i8_glds(int R, int ja, int jb, int k0, int K, ZpField F, DT *__restrict__ D, i64d ldc, const int *__restrict__ seq,
+                                                         const signed char *__restrict__ Fd, const signed char *__restrict__ Ut, int KB, int ntm, int ntn)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_gl[]; // [GL_NBUF][A | B], then the 256 row numbers of the tile
+    int *s_gi = (int *)(s_gl + GL_NBUF * GL_TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    {
+        const int per_band = GI_BAND * ntn;
+        const int band = blockIdx.x / per_band, within = blockIdx.x % per_band;
+        const int rows_in_band = min(GI_BAND, ntm - band * GI_BAND);
+        tn = within / rows_in_band;
+        tm = band * GI_BAND + within % rows_in_band;
+        if (tn >= ntn) return;
+    }
+    const int m0 = tm * GL_BM, j0 = ja + tn * GL_BN;
+    if (tid < GL_BM) {
+        const int mi = m0 + tid;
+        s_gi[tid] = (mi < R && seq[mi] < 0) ? mi : -1;
+    }
+    __syncthreads();
+    // the two A and two B pieces this wave brings in per K-tile: piece id = 2 wave + i = 16 rows, all 64 bytes of the K slice (four
+    // lanes per row: whole 64-byte runs of global memory); the 16-byte slot a lane fills holds seg = slot ^ ((row >> 1) & 3)
+    const signed char *pa[2], *pb[2];
+    int lo[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int id = 2 * wave + i;
+        const int row = id * 16 + (lane >> 2), seg = (lane & 3) ^ ((row >> 1) & 3);
+        const int gi = s_gi[row];
+        pa[i] = Fd + (i64d)(gi >= 0 ? gi : 0) * KB + k0 + seg * 16;
+        pb[i] = Ut + (i64d)(j0 + row) * KB + k0 + seg * 16;
+        lo[i] = id * 1024;
+    }
+    auto issue = [&](int t, int b) {
+        unsigned char *base = s_gl + b * GL_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            gl_dma16(pa[i] + (i64d)t * 64, base + lo[i]);
+            gl_dma16(pb[i] + (i64d)t * 64, base + 16384 + lo[i]);
+        }
+    };
+    v16i32 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0;
+    const int nt = K >> 6;
+    // (Reading the fragments of the next half K-tile while the MFMAs of this one run -- explicit software pipelining inside a wave --
+    // changed nothing: 0.243 s against 0.234 s on config 5 at 1/5; the second wave of the SIMD already fills those gaps.)
+    const int r31 = lane & 31;
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    for (int t = 0; t < nt; t++) {
+        const int b = t & 3;
+        if (t + 2 < nt) {
+            issue(t + 2, (t + 2) & 3);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (t + 1 < nt) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ONE barrier per K-tile: with four buffers the DMAs issued above, K-tile t + 2, go to the buffer of K-tile t - 2, which every
+        // wave had finished reading before it arrived at the barrier of iteration t - 1
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *A = s_gl + b * GL_TILE_BYTES, *B = A + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            // row 32 rb + (lane & 31), seg 2 kk + (lane >> 5): slot = seg ^ ((row >> 1) & 3) (32 rb is a multiple of 8: the lane decides)
+            const int so = r31 * 64 + (((2 * kk + (lane >> 5)) ^ ((r31 >> 1) & 3)) << 4);
+            v4i32 fa[4], fb[2];
+#pragma unroll
+            for (int m = 0; m < 4; m++) fa[m] = *(const v4i32 *)(A + so + (wm * 4 + m) * 2048);
+#pragma unroll
+            for (int n = 0; n < 2; n++) fb[n] = *(const v4i32 *)(B + so + (wn * 2 + n) * 2048);
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    // epilogue.  A lane holds 16 ROWS of one column of every 32 x 32 tile (the MFMA's C layout): written to D as it is that is 32
+    // byte-wide loads and stores per tile and lane, as much time in the address path as the tile's MFMAs take.  Each tile goes
+    // through LDS instead (the K-tile buffers are free now) and comes back row-wise: a lane then owns 16 consecutive bytes of one
+    // row of D -- one 16-byte load, one 16-byte store.
+    static_assert(sizeof(DT) == 1, "the one-digit finish keeps D as bytes");
+    __syncthreads();
+    int *S = (int *)(s_gl + wave * (32 * 36 * 4)); // 32 rows of 36 ints (16-byte aligned rows, odd multiple of 4 banks)
+    const int erow = lane >> 1, ecol = (lane & 1) * 16;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[m][n][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int av[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const v4i32 t = *(const v4i32 *)(S + erow * 36 + ecol + 4 * q);
+                av[4 * q] = t[0]; av[4 * q + 1] = t[1]; av[4 * q + 2] = t[2]; av[4 * q + 3] = t[3];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int gi = s_gi[(wm * 4 + m) * 32 + erow];
+            const int col0 = j0 + (wn * 2 + n) * 32 + ecol;
+            if (gi >= 0 && col0 < jb) {
+                signed char *dp = (signed char *)D + (i64d)gi * ldc + col0;
+                const v4i32 dv4 = *(const v4i32 *)dp;
+                v4i32 out;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int word = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int dvv = (int)(signed char)((dv4[q] >> (8 * e)) & 255);
+                        int x = zp_small_lazy(dvv - av[4 * q + e], -F.finvp, (int)F.p);
+                        if (x > (int)F.halfp) x -= (int)F.p;
+                        else if (x < (int)F.mhalfp) x += (int)F.p;
+                        if (col0 + 4 * q + e >= jb) x = dvv;
+                        word |= (x & 255) << (8 * e);
+                    }
+                    out[q] = word;
+                }
+                *(v4i32 *)dp = out;
+            }
+        }
 }

@@ -1946,12 +1946,24 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
         HIPCHK(hipFuncSetAttribute((const void *)k_panel_follow<1024, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456 - (int)sizeof(int) * (DP_W * DP_W + DP_W) - 1024));
         attr_done = true;
     }
+    const char *glds_env = getenv("SPASM_AMD_GEMM_GLDS"); // A/B: the 256 x 256 LDS-DMA kernel for the large one-digit updates
+    const bool glds_tile = glds_env && atoi(glds_env) != 0;
+    if constexpr (std::is_same<DT, signed char>::value) {
+        if (glds_tile) HIPCHK(hipFuncSetAttribute((const void *)k_gemm_i8_glds<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES));
+    }
     auto gemm = [&](int ja, int jb, int k0, int K, const int *rows, int nrows) {
         if (jb <= ja || K <= 0) return;
         // (1-D grid: the kernel orders the tiles itself, in bands of row tiles; a partial last band has fewer row tiles, and its
         // tiles still number rows_in_band * ntn, so the total is simply ntm * ntn)
         const int ntm = cdiv(rows ? nrows : R, 128);
-        if (ND == 1) {
+        if (ND == 1 && glds_tile && !rows && K >= 256 && jb - ja >= 1024 && R >= 4096 && std::is_same<DT, signed char>::value) {
+            // the large updates of the one-digit finish: 256 x 256 tile, operands by LDS-DMA, loads in flight across barriers
+            if constexpr (std::is_same<DT, signed char>::value) {
+                const int ntm2 = cdiv(R, GL_BM), ntn2 = cdiv(jb - ja, GL_BN);
+                hipLaunchKernelGGL((k_gemm_i8_glds<DT>), dim3((unsigned)((i64)ntm2 * ntn2)), dim3(512), GL_LDS_BYTES, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, Fd.p, Ut.p,
+                                   KB, ntm2, ntn2);
+            }
+        } else if (ND == 1) {
             const int ntn = cdiv(jb - ja, 128);
             hipLaunchKernelGGL((k_gemm_i8<1, 2, 2, 2, 2, DT>), dim3((unsigned)((i64)ntm * ntn)), dim3(256), 0, s, R, ja, jb, k0, K, F, D.p, (i64d)ldc, seq.p, rows, nrows,
                                Fd.p, (i64d)fplane, Ut.p, (i64d)uplane, KB, ntm, ntn);

@@ -988,3 +988,21 @@ def test_rank_only_counts_what_echelonize_finds(S, O, monkeypatch, kind, n, m, k
     for k in env:
         monkeypatch.delenv(k)
     assert r == r_lm == full.r == O.echelonize(A, **LM).r
+
+
+@pytest.mark.gpu
+def test_dense_finish_with_the_lds_dma_gemm(S, O, monkeypatch):
+    """SPASM_AMD_GEMM_GLDS=1: the large one-digit updates on the 256 x 256 LDS-DMA kernel (dense.hpp k_gemm_i8_glds; off by default:
+    it ties the 128 x 128 kernel since that one writes its tiles back row-wise).  A remainder large enough to reach it (more than 4096
+    rows, more than 1024 columns right of the first block); rank, pivot columns and kernel of the default path; verified."""
+    A = S.synth_csr(2, 14000, 4600, row_nnz=40, prime=127, seed=0x61D5)
+    monkeypatch.setenv("SPASM_AMD_TALL", "0")
+    ref = S.echelonize(A, **LM)
+    monkeypatch.setenv("SPASM_AMD_GEMM_GLDS", "1")
+    got = S.echelonize(A, **LM)
+    monkeypatch.delenv("SPASM_AMD_GEMM_GLDS")
+    monkeypatch.delenv("SPASM_AMD_TALL")
+    assert S.last_rounds()[-1]["nnz_out"] == -1
+    assert got.r == ref.r and np.asarray(got.qinv >= 0).tolist() == np.asarray(ref.qinv >= 0).tolist()
+    assert got.U.rows() == ref.U.rows()          # the same elimination, other kernels for its large updates
+    assert S.factorization_verify(A, got, 5)
