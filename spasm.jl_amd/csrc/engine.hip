@@ -2408,11 +2408,21 @@ struct DenseW {
             constexpr int TEAM = 16;
             hipLaunchKernelGGL((k_wd_seed<TEAM, WT>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, s, npiv, R.F, R.uhdr.p, R.UPN.p, cmap_s.p, wd, (i64d)ldw);
             HIPCHK(hipGetLastError());
+            // (narrow residues: 16 bytes per lane and term -- kernels.hpp, WideRow)
+            constexpr bool wide = sizeof(WT) < 4;
+            const int ept = 16 / (int)sizeof(WT);
+            const int btw = Cs / ept >= 256 ? 256 : std::max(16, Cs / ept);
+            const unsigned gyw = (unsigned)cdiv(Cs, ept * btw);
             for (int l = 1; l <= depth; l++) {
                 const int lo = lvl_off[(size_t)l - 1], cnt = lvl_off[(size_t)l] - lo;
                 if (cnt == 0) continue;
-                if (R.F.small) hipLaunchKernelGGL((k_wd_level<true, WT>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, wd, (i64d)ldw, Cs);
-                else hipLaunchKernelGGL((k_wd_level<false, WT>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, wd, (i64d)ldw, Cs);
+                if constexpr (wide) {
+                    if (R.F.small) hipLaunchKernelGGL((k_wd_level_wide<WT>), dim3((unsigned)cnt, gyw), dim3(btw), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, wd, (i64d)ldw, Cs);
+                    else hipLaunchKernelGGL((k_wd_level<false, WT>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, wd, (i64d)ldw, Cs);
+                } else {
+                    if (R.F.small) hipLaunchKernelGGL((k_wd_level<true, WT>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, wd, (i64d)ldw, Cs);
+                    else hipLaunchKernelGGL((k_wd_level<false, WT>), dim3((unsigned)cnt, gy), dim3(bt), 0, s, cnt, order.p + lo, R.F, R.uhdr.p, R.UPP.p, wd, (i64d)ldw, Cs);
+                }
                 if ((l & 1023) == 0) HIPCHK(hipGetLastError());
             }
         };
@@ -2461,6 +2471,15 @@ struct DenseW {
         auto go = [&](auto tag) {
             using WT = decltype(tag);
             const WT *wd = (const WT *)Wd.p;
+            if constexpr (sizeof(WT) < 4 && std::is_same<WT, DT>::value) {
+                if (R.F.small) { // narrow residues: 16 bytes per lane and term
+                    const int ept = 16 / (int)sizeof(WT);
+                    const int btw = Cs / ept >= 256 ? 256 : std::max(16, Cs / ept);
+                    hipLaunchKernelGGL((k_wd_rows_wide<WT>), dim3((unsigned)nrows, (unsigned)cdiv(Cs, ept * btw)), dim3(btw), 0, s, nrows, R.F, poff.p, plist.p, wd, (i64d)Cs, Cs, Dp,
+                                       (i64d)ldc, dcol0);
+                    return;
+                }
+            }
             if (R.F.small) hipLaunchKernelGGL((k_wd_rows<true, DT, WT>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, wd, (i64d)Cs, Cs, Dp,
                                               (i64d)ldc, dcol0);
             else hipLaunchKernelGGL((k_wd_rows<false, DT, WT>), dim3((unsigned)nrows, gy), dim3(bt), 0, s, nrows, R.F, poff.p, plist.p, wd, (i64d)Cs, Cs, Dp, (i64d)ldc,

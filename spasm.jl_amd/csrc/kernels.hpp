@@ -2398,6 +2398,93 @@ __global__ __launch_bounds__(256) void k_wd_level(int nrows, const int *__restri
     (void)nrows;
 }
 
+// ---- the same two combinations of dense rows for narrow residues (bytes for p < 2^8, shorts for p < 2^16), 16 BYTES per lane and term
+// instead of four elements: with byte-wide W a four-element load moves 256 bytes per wave instruction, and the build of the dense
+// rows of config 5 ran at half a TB/s (k_wd_rows 9.2 of 58.7 s of kernel time at full size, k_wd_level 6.0).
+template <typename WT> struct WideRow {
+    static constexpr int EPT = 16 / (int)sizeof(WT);
+    static __device__ __forceinline__ void load(const WT *p, int (&w)[EPT])
+    {
+        const v4i32 raw = *(const v4i32 *)p;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            if (sizeof(WT) == 1) w[i] = (int)(signed char)((raw[i >> 2] >> (8 * (i & 3))) & 255);
+            else w[i] = (int)(short)((raw[i >> 1] >> (16 * (i & 1))) & 65535);
+        }
+    }
+    static __device__ __forceinline__ void store(WT *p, const int (&w)[EPT])
+    {
+        v4i32 raw = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            if (sizeof(WT) == 1) raw[i >> 2] |= (w[i] & 255) << (8 * (i & 3));
+            else raw[i >> 1] |= (w[i] & 65535) << (16 * (i & 1));
+        }
+        *(v4i32 *)p = raw;
+    }
+};
+
+// rows order[0 .. nrows) of W (one level): W[q] -= sum v * W[c]; a lane owns WideRow<WT>::EPT consecutive columns
+template <typename WT>
+__global__ __launch_bounds__(256) void k_wd_level_wide(int nrows, const int *__restrict__ order, ZpField F, const UHdr *__restrict__ uhdr,
+                                                       const int2 *__restrict__ UPP, WT *__restrict__ Wd, i64d ldw, int Cs)
+{
+    constexpr int EPT = WideRow<WT>::EPT;
+    const int q = order[blockIdx.x];
+    const int j = (blockIdx.y * blockDim.x + threadIdx.x) * EPT;
+    if (j >= Cs) return;
+    const UHdr h = uhdr[q];
+    long long acc[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) acc[i] = 0;
+    const int2 *up = UPP + (i64d)h.off;
+    for (int k = 0; k < h.npp; k++) {
+        const int2 e = up[k]; // (uniform over the workgroup)
+        int w[EPT];
+        WideRow<WT>::load(Wd + (i64d)e.x * ldw + j, w);
+        const int c = zp_neg(F, e.y);
+#pragma unroll
+        for (int i = 0; i < EPT; i++) acc[i] += (long long)c * w[i]; // |c w| < 2^30: an i64 takes 2^33 terms
+    }
+    WT *dst = Wd + (i64d)q * ldw + j;
+    int b[EPT];
+    WideRow<WT>::load(dst, b);
+#pragma unroll
+    for (int i = 0; i < EPT; i++) b[i] = zp_reduce(F, acc[i] + b[i]);
+    WideRow<WT>::store(dst, b);
+    (void)nrows;
+}
+
+// dense Schur rows: D[t][dcol0 + j] += sum a * W[q][j] over the row's list (q, a); D and W hold residues of the same width
+template <typename WT>
+__global__ __launch_bounds__(256) void k_wd_rows_wide(int nrows, ZpField F, const i64d *__restrict__ poff, const int2 *__restrict__ plist,
+                                                      const WT *__restrict__ Wd, i64d ldw, int Cs, WT *__restrict__ D, i64d ldc, int dcol0)
+{
+    constexpr int EPT = WideRow<WT>::EPT;
+    const int t = blockIdx.x;
+    const int j = (blockIdx.y * blockDim.x + threadIdx.x) * EPT;
+    if (j >= Cs) return;
+    const i64d lo = poff[t], hi = poff[t + 1];
+    if (lo == hi) return; // (the own entries are there already)
+    long long acc[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) acc[i] = 0;
+    for (i64d k = lo; k < hi; k++) {
+        const int2 e = plist[k]; // (uniform over the workgroup)
+        int w[EPT];
+        WideRow<WT>::load(Wd + (i64d)e.x * ldw + j, w);
+#pragma unroll
+        for (int i = 0; i < EPT; i++) acc[i] += (long long)e.y * w[i];
+    }
+    WT *dst = D + (i64d)t * ldc + dcol0 + j;
+    int b[EPT];
+    WideRow<WT>::load(dst, b);
+#pragma unroll
+    for (int i = 0; i < EPT; i++) b[i] = zp_reduce(F, acc[i] + b[i]);
+    WideRow<WT>::store(dst, b);
+    (void)nrows;
+}
+
 // The entries of the non-pivot rows on pivot columns, as (pivot index, value) lists (once per round: every slab of columns and the
 // density estimate go along them), and the scatter of the other entries into the dense rows.
 template <int TEAM>
