@@ -1776,6 +1776,52 @@ struct ExtractWork {
     DevBuf<int> pflag, pscan, pivcol, porig, dj, dx;
     DevBuf<i64d> ulen, uoff;
     DevBuf<int2> Ufull;
+    // Device -> pageable host memory runs at ~7 GB/s (the runtime stages it through its own pinned chunks, one host thread copying):
+    // the 21 GB of U of a 73k x 73k finish took 3.1 s, longer than the elimination.  Two pinned buffers of our own instead: the DMA of
+    // piece i + 1 runs while piece i is copied out by all host threads.
+    static constexpr size_t PIN_BYTES = (size_t)64 << 20;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t pev[2] = {nullptr, nullptr};
+    ExtractWork() {}
+    ExtractWork(const ExtractWork &) = delete;
+    ~ExtractWork()
+    {
+        for (int b = 0; b < 2; b++) {
+            if (pin[b]) (void)hipHostFree(pin[b]);
+            if (pev[b]) (void)hipEventDestroy(pev[b]);
+        }
+    }
+    void d2h(void *dst, const void *src, size_t bytes, hipStream_t s)
+    {
+        if (bytes < ((size_t)8 << 20)) {
+            HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            return;
+        }
+        for (int b = 0; b < 2; b++) {
+            if (!pin[b]) HIPCHK(hipHostMalloc(&pin[b], PIN_BYTES, hipHostMallocDefault));
+            if (!pev[b]) HIPCHK(hipEventCreateWithFlags(&pev[b], hipEventDisableTiming));
+        }
+        const size_t npieces = (bytes + PIN_BYTES - 1) / PIN_BYTES;
+        auto piece = [&](size_t i) { return std::min(PIN_BYTES, bytes - i * PIN_BYTES); };
+        HIPCHK(hipMemcpyAsync(pin[0], src, piece(0), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(pev[0], s));
+        for (size_t i = 0; i < npieces; i++) {
+            const int b = (int)(i & 1);
+            if (i + 1 < npieces) {
+                HIPCHK(hipMemcpyAsync(pin[b ^ 1], (const char *)src + (i + 1) * PIN_BYTES, piece(i + 1), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipEventRecord(pev[b ^ 1], s));
+            }
+            HIPCHK(hipEventSynchronize(pev[b]));
+            const size_t n = piece(i);
+            char *out = (char *)dst + i * PIN_BYTES;
+            const char *in = (const char *)pin[b];
+            const size_t part = (size_t)4 << 20;
+            const long long nparts = (long long)((n + part - 1) / part);
+#pragma omp parallel for schedule(static) num_threads(8)
+            for (long long q = 0; q < nparts; q++) memcpy(out + (size_t)q * part, in + (size_t)q * part, std::min(part, n - (size_t)q * part));
+        }
+    }
 };
 
 template <typename DT>
@@ -1828,9 +1874,8 @@ int dense_extract_range(const DT *Dp, int C, i64 ldc, const int *pivrow_of_col, 
         hipLaunchKernelGGL(k_split_ent, dim3((unsigned)std::min<i64>(((i64)tot + 255) / 256, 65536)), dim3(256), 0, s, (i64d)tot, Ufull.p, W.dj.p, W.dx.p);
         HIPCHK(hipGetLastError());
         int *hj = U.j.grow((size_t)tot), *hx = U.x.grow((size_t)tot);
-        HIPCHK(hipMemcpyAsync(hj, W.dj.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hx, W.dx.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        W.d2h(hj, W.dj.p, (size_t)tot * sizeof(int), s);
+        W.d2h(hx, W.dx.p, (size_t)tot * sizeof(int), s);
     }
     return npd;
 }
@@ -1986,9 +2031,6 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
         int q = 0;
         for (int c0 = b0; c0 < b1; c0 += DP_W, q++) {
             const int c1 = std::min(c0 + DP_W, b1), w = c1 - c0;
-            // (the rows of U of the block before this one go to the host now: the first panels of this block are queued, the
-            // copy overlaps them and what follows)
-            if (us && q == 2 && marked_to > us->done_to) us->template take<DT>(marked_to);
             hipLaunchKernelGGL((k_panel_load<DT>), dim3(Rp / 64), dim3(256), 0, s, R, Rp, c0, w, D.p, (i64d)ldc, P.p, sync.p);
             {
                 int a_Rp = Rp, a_chunk = tall ? res_chunk : chunk, a_w = w, a_c0 = c0;
@@ -2047,7 +2089,9 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
         gemm(b1, C, 0, npan * DP_W, nullptr, 0);
         HIPCHK(hipGetLastError());
         if (us) {
-            if (marked_to > us->done_to) us->template take<DT>(marked_to); // (a block of fewer than three panels)
+            // this block is queued as a whole: the rows of U of the block BEFORE it go to the host now (the host blocks in the copy,
+            // the device works through this block meanwhile); then the event that says this block is done
+            if (marked_to > us->done_to) us->template take<DT>(marked_to);
             us->mark(s);
             marked_to = b1;
         }
