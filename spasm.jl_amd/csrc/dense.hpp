@@ -465,7 +465,9 @@ __global__ __launch_bounds__(64) void k_trsm_i8(int ja, int jb, ZpField F, DT *_
 // B[same k][column l & 31] (both operands take the same k, so any permutation of k inside the instruction cancels);
 // C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 #define GI_LDS_STRIDE 80
+#ifndef GI_BAND
 #define GI_BAND 32
+#endif
 // stages of K in flight in registers (one digit / two digits).  Four (168 VGPRs, no scratch) changed nothing: 0.420 s against 0.413 s
 // for the GEMMs of config 5 at 1/5 -- the kernel does not wait for the latency of its loads, it is bound by what LDS and L1 carry
 #ifndef GI_NPF
