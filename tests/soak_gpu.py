@@ -1,6 +1,6 @@
 """Randomised soak of the round-3 paths against the single-device leftmost-pivot run and the oracle (small matrices, many shapes):
 the dense finish over row shards (random shard counts and block sizes), the tall-and-skinny finish (random slabs and batches), the
-greedy search (random limits; engine vs oracle pair for pair through max_round = 1 runs).   python tools/soak.py [seconds=120] [seed=1] [scale=1]"""
+greedy search (random limits; engine vs oracle pair for pair through max_round = 1 runs).   python tests/soak_gpu.py [seconds=120] [seed=1] [scale=1]   (test infrastructure: it uses the oracle; not collected by pytest)"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [root, os.path.join(root, "tests")]
