@@ -183,11 +183,21 @@ def main():
         cls = max(range(16), key=lambda c: d["ms_class"][c])
         k_bytes = 8 * d["ent_class"][cls] + 16 * d["seg_class"][cls]
         k_ms = d["ms_class"][cls]
+        k_name = (f"k_stream class {cls - 8}" if cls >= 8 else f"k_scatter class {cls}") + f" ({d['rows_class'][cls]} rows)"
+        fused = d.get("rows_fused", 0) > 0 and d.get("ms_fused", 0.0) >= k_ms
+        if fused:
+            # the fused kernel (csrc/fused.hpp): 8 B per streamed entry + 16 B per row segment (the row itself and every run of W)
+            cls = -1
+            k_bytes = 8 * d["ent_fused"] + 16 * d["seg_fused"]
+            k_ms = d["ms_fused"]
+            k_name = f"k_schur_fused ({d['rows_fused']} rows)"
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # HBM traffic of that kernel from the PMC counters (collected in separate rocprofv3 passes and calibrated for
         # this access shape, profiles/r02_final_traffic.json); only quoted for the workload it was measured on
         prefix = None
-        if args.prime < 65536:
+        if fused:
+            prefix = "k_schur_fused<"
+        elif args.prime < 65536:
             prefix = SCATTER_KERNEL_PREFIX[cls] if cls < 8 else (STREAM_KERNEL_PREFIX[cls - 8] if cls < 15 else None)
         traffic = None
         for tf in TRAFFIC_FILES:
@@ -202,7 +212,7 @@ def main():
                 pass
         roofline = {
             "bound": "hbm",
-            "kernel": (f"k_stream class {cls - 8}" if cls >= 8 else f"k_scatter class {cls}") + f" ({d['rows_class'][cls]} rows)",
+            "kernel": k_name,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -220,6 +230,10 @@ def main():
             "per_class_ms": {"hash": [round(x, 4) for x in d["ms_class"][:8]], "stream": [round(x, 4) for x in d["ms_class"][8:15]]},
             "per_class_rows": {"hash": d["rows_class"][:8], "stream": d["rows_class"][8:15]},
             "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"], "stream_fix_ms": round(d["ms_class"][15], 4),
+            "fused": {"ms": round(d.get("ms_fused", 0.0), 4), "fix_ms": round(d.get("ms_fused_fix", 0.0), 4), "rows": d.get("rows_fused", 0),
+                      "entries": d.get("ent_fused", 0), "segments": d.get("seg_fused", 0), "rows_left_to_general_path": d.get("rows_rejected", 0),
+                      "s_entries_used": d.get("s_entries_used", 0)},
+            "levels_ms": round(d.get("ms_levels", 0.0), 4),
         }
         # beside the algorithmic bytes, (i) the measured HBM bytes of a whole round and (ii) the compulsory floor
         # 8 (nnz(A) + nnz(U)) + 8 (n + r): every entry of A and of the pivot rows read once, one pointer pair per row

@@ -260,6 +260,18 @@ struct spasm_amd_round_stats {
     i64 w_entries;
     i64 w_long_rows;
     i64 npiv_greedy;      /* of npiv: pivots the greedy cycle-free search added (reference README.md:23; csrc/greedy.hpp) */
+    /* the fused Schur kernel (csrc/fused.hpp: plan + stream of a row in one kernel; round 4): device time of its launch and of the
+     * fix-up launch behind it (plans with class timing on; 0 otherwise), rows it took, entries it streamed, row segments it visited
+     * (1 per row + 1 per run of W), rows it left to the general path (whose launches are the classes above), entries of S its waves
+     * took from the cursor */
+    double ms_fused;
+    double ms_fused_fix;
+    i64 rows_fused;
+    i64 ent_fused;
+    i64 seg_fused;
+    i64 rows_rejected;
+    i64 s_entries_used;
+    double ms_levels;     /* the levels of the pivot graph (relaxation + sort), once per round: part of ms_w */
 };
 
 typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;

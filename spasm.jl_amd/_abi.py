@@ -111,6 +111,14 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
         ("w_entries", C.c_int64),
         ("w_long_rows", C.c_int64),
         ("npiv_greedy", C.c_int64),
+        ("ms_fused", C.c_double),
+        ("ms_fused_fix", C.c_double),
+        ("rows_fused", C.c_int64),
+        ("ent_fused", C.c_int64),
+        ("seg_fused", C.c_int64),
+        ("rows_rejected", C.c_int64),
+        ("s_entries_used", C.c_int64),
+        ("ms_levels", C.c_double),
     ]
 
     def as_dict(self):

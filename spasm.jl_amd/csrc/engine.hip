@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 #include "stream.hpp"
 #include "wlevel.hpp"
+#include "fused.hpp"
 #include "greedy.hpp"
 #include "dense.hpp"
 #include <cstring>
@@ -267,6 +268,23 @@ struct Round {
     DevBuf<u64d> stamps;            // diagnostic build only
     DevMat S;
     i64 s_capacity = 0;      // entries S.ent can hold (sum of bounds at the time it was sized)
+    i64 s_ent_base = 0;      // where the rows of run_scatter start in S.ent (behind the rows of the fused step, when it left any to the general path)
+    // ---- the fused Schur step (fused.hpp): plan + stream of a row in one kernel, S written compactly from one cursor
+    bool use_fused = true;   // SPASM_AMD_FUSED=0: k_wplan + k_bin + the streaming classes instead
+    DevBuf<int4> rinfo;      // per row slot: {start, length, originating row}
+    DevBuf<unsigned> fz_work;
+    DevBuf<u64d> fz_cursor;
+    DevBuf<int> fz_counts;   // [0] rows left to the launch with large tables, [1] rows left to the general path
+    DevBuf<RoundCounters> fz_ctr; // statistics of the fused kernels (the general path clears its own when it runs behind them)
+    RoundCounters hfz;       // .. on the host
+    bool last_fused = false; // the last Schur step went through run_fused
+    DevBuf<int> fz_long_list, fz_rej_list, fz_rej_rows;
+    DevBuf<i64d> fb_start;   // the general path's own row arrays while it works for the fused step
+    DevBuf<int> fb_len, fb_lead, fb_orig;
+    i64 fz_used = 0;         // entries of S handed out by the last fused step (incl. what its waves left of their blocks)
+    int fz_nrej = 0, fz_nlong = 0;
+    int fz_rows = 0;         // rows the fused kernels took
+    hipEvent_t ev_fz[3] = {nullptr, nullptr, nullptr}; // around the fused kernels (class_timing)
     i64 s_total_bound = 0;
     int free_cols = 0;
     // timing
@@ -293,6 +311,8 @@ struct Round {
         memset(hclass_count, 0, sizeof hclass_count);
         memset(launch_cls, 0, sizeof launch_cls);
         if (const char *e = getenv("SPASM_AMD_STREAM")) use_stream = atoi(e) != 0;
+        if (const char *e = getenv("SPASM_AMD_FUSED")) use_fused = atoi(e) != 0;
+        for (auto &e : ev_fz) HIPCHK(hipEventCreate(&e));
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
@@ -301,6 +321,7 @@ struct Round {
     {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : ev_cls) if (e) (void)hipEventDestroy(e);
+        for (auto &e : ev_fz) if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         for (auto &e : lane_ev) if (e) (void)hipEventDestroy(e);
@@ -665,6 +686,7 @@ struct Round {
     // rows of Uinv: the chain solve applied to the unit rows e_r (once per round, after build_U)
     // expected_rows = rows the solve will process: building Uinv costs npiv chain solves, so it pays only for more rows than that
     double ms_uinv = 0, ms_w = 0;   // wall time of the last prepare_uinv / prepare_w, host synchronisations included
+    double ms_levels = 0;           // of ms_w: the levels of the pivot graph (build_levels)
 
     void prepare_uinv(i64 expected_rows = ((i64)1 << 62))
     {
@@ -967,8 +989,15 @@ struct Round {
     {
         use_w = false;
         wtotal = 0;
+        ms_levels = 0;
         if (!use_stream || force_lists || want_idx || m >= (1 << 24) || npiv == 0 || expected_rows < 2 * (i64)npiv) return;
-        build_levels();
+        {
+            HIPCHK(hipStreamSynchronize(stream));
+            const double t0 = spasm_wtime();
+            build_levels();
+            HIPCHK(hipStreamSynchronize(stream));
+            ms_levels = 1e3 * (spasm_wtime() - t0);
+        }
         if (depth < 0) return;
         // room for the rows' own entries: what they have, half as much again for uneven regions, and a block per team of the plan kernel
         const i64 own_room = ((own_entries + own_entries / 2 + (i64)num_cu * 16 * 16 * 256 + NPOOL) + 15) & ~(i64)15;
@@ -1181,10 +1210,10 @@ struct Round {
     }
 
     // sum of the NCTR statistic copies (synchronises)
-    RoundCounters read_counters()
+    RoundCounters read_counters(const RoundCounters *from = nullptr)
     {
         std::vector<RoundCounters> h(NCTR);
-        HIPCHK(hipMemcpyAsync(h.data(), ctr.p, NCTR * sizeof(RoundCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h.data(), from ? from : ctr.p, NCTR * sizeof(RoundCounters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         RoundCounters c = h[0];
         for (int i = 1; i < NCTR; i++) {
@@ -1255,6 +1284,7 @@ struct Round {
         S.n = nrows;
         S.m = m;
         nlaunch = 0;
+        last_fused = false;
         if (nrows == 0) return;
         // (class_count was cleared by the reset kernel of the solve that precedes every scatter)
         int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1; // 12-byte slots: the 2^14 table exceeds LDS
@@ -1290,7 +1320,7 @@ struct Round {
         a.uhdr = uhdr.p;
         a.UPN = UPN.p;
         a.Lpool = recs;
-        a.Sent = S.ent.p;
+        a.Sent = S.ent.p + s_ent_base;
         a.Slen = S.len.p;
         a.Slead = S.lead.p;
         a.ctr = ctr.p;
@@ -1310,7 +1340,7 @@ struct Round {
         sa.qinv_r = qinv_r.p;
         sa.UPN = UPN.p;
         sa.Lpool = recs;
-        sa.Sent = S.ent.p;
+        sa.Sent = S.ent.p + s_ent_base;
         sa.Slen = S.len.p;
         sa.Slead = S.lead.p;
         sa.ctr = ctr.p;
@@ -1374,7 +1404,7 @@ struct Round {
             fa.fixcnt = fixcnt.p;
             fa.fixbuf = fixbuf.p;
             fa.sstart = sstart.p;
-            fa.Sent = S.ent.p;
+            fa.Sent = S.ent.p + s_ent_base;
             fa.Slen = S.len.p;
             fa.Slead = S.lead.p;
             fa.ctr = ctr.p;
@@ -1472,6 +1502,212 @@ struct Round {
         HIPCHK(hipGetLastError());
         // the Schur rows start where their slots start
         HIPCHK(hipMemcpyAsync(S.start.p, sstart.p, ((size_t)nrows + 1) * sizeof(i64d), hipMemcpyDeviceToDevice, stream));
+    }
+
+    // ---- (3 + 4, fused) the Schur rows of `nrows` rows of M in one pass over the rows (fused.hpp).  S.ent must hold `scap` entries.
+    // No host synchronisation; afterwards fetch_fused() tells how many rows were left to the general path (fused_fallback()).
+    bool fused_ok() const { return use_fused && use_w && !force_lists && !want_idx && m < (1 << 24); }
+    static constexpr int FZ_LOGT = 11, FZ_WPB = 4;
+    // capacity of S the fused step wants for an estimated `entries` of Schur rows: every wave may leave a block unfinished
+    i64 fused_capacity(i64 entries) const { return entries + entries / 50 + (i64)num_cu * 16 * (i64)FZ_SBLK + 64; }
+    void run_fused(const DevMat &M, const int *rows, int nrows, i64 scap)
+    {
+        S.n = nrows;
+        S.m = m;
+        nlaunch = 0;
+        fb_ran = false;
+        rinfo.ensure((size_t)nrows + 1);
+        S.start.ensure((size_t)nrows + 1);
+        S.len.ensure((size_t)nrows + 1);
+        S.lead.ensure((size_t)nrows + 1);
+        S.orig.ensure((size_t)nrows + 1);
+        fixcnt.ensure((size_t)nrows + 1);
+        fixbuf.ensure(((size_t)nrows + 1) * SFIX);
+        fz_long_list.ensure((size_t)nrows + 1);
+        fz_rej_list.ensure((size_t)nrows + 1);
+        fz_work.ensure((size_t)2 * FZ_NWORK * FZ_WSTRIDE);
+        fz_cursor.ensure(2);
+        fz_counts.ensure(4);
+        fz_ctr.ensure(NCTR);
+        ctr.ensure(NCTR);
+        class_count.ensure(NCLASS);
+        last_fused = true;
+        if (nrows > 0) {
+            hipLaunchKernelGGL(k_gather_info, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, M.orig.p, rinfo.p);
+            HIPCHK(hipGetLastError());
+        }
+        {
+            static_assert(sizeof(RoundCounters) % 4 == 0, "cleared word by word");
+            const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), nwork = 2 * FZ_NWORK * FZ_WSTRIDE;
+            const int span = std::max(std::max(nctr_words, nwork), nrows + 1);
+            hipLaunchKernelGGL(k_fused_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, nrows, fz_work.p, nwork, fz_cursor.p, fz_counts.p, 4, (unsigned *)fz_ctr.p,
+                               nctr_words, fixcnt.p);
+            HIPCHK(hipGetLastError());
+        }
+        if (class_timing) HIPCHK(hipEventRecord(ev_fz[0], stream));
+        if (nrows > 0) {
+            FusedArgs a;
+            a.nrows = nrows;
+            a.slots = nullptr;
+            a.slot_count = nullptr;
+            a.rinfo = rinfo.p;
+            a.ent = M.ent.p;
+            a.pbits = pbits.p;
+            a.wcol = wcol.p;
+            a.buf = UPN.p;
+            a.Sent = S.ent.p;
+            a.scap = (u64d)scap;
+            a.scursor = fz_cursor.p;
+            a.Sstart = S.start.p;
+            a.Slen = S.len.p;
+            a.Slead = S.lead.p;
+            a.Sorig = S.orig.p;
+            a.fixbuf = fixbuf.p;
+            a.fixcnt = fixcnt.p;
+            a.long_list = nullptr; // (rows beyond the tables of the wave kernel: the general path)
+            a.long_count = fz_counts.p;
+            a.long_bound = 0;
+            a.rej_list = fz_rej_list.p;
+            a.rej_count = fz_counts.p + 1;
+            a.work = fz_work.p;
+            a.ctr = fz_ctr.p;
+            a.cls = NCLASS - 1; // (the statistics slot of the fix-up launch, which counts nothing there)
+            a.free_cols = free_cols;
+            a.F = F;
+            const size_t lds = fused_lds_bytes<FZ_LOGT>(FZ_WPB);
+            static int per_cu[16] = {0};
+            int dev = 0;
+            HIPCHK(hipGetDevice(&dev));
+            int &pc = per_cu[(dev & 7) * 2 + (F.small ? 1 : 0)];
+            if (!pc) {
+                int nb = 0;
+                if (F.small) {
+                    HIPCHK(hipFuncSetAttribute((const void *)k_schur_fused<FZ_LOGT, FZ_WPB, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_schur_fused<FZ_LOGT, FZ_WPB, true, false>, FZ_WPB * 64, lds));
+                } else {
+                    HIPCHK(hipFuncSetAttribute((const void *)k_schur_fused<FZ_LOGT, FZ_WPB, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_schur_fused<FZ_LOGT, FZ_WPB, false, false>, FZ_WPB * 64, lds));
+                }
+                pc = std::max(nb, 1);
+            }
+            // every wave takes blocks of FZ_B rows until none is left: as many workgroups as are resident, fewer for few rows
+            const int grid = std::max(1, std::min(cdiv(cdiv(nrows, FZ_B), FZ_WPB), num_cu * pc));
+            if (F.small) hipLaunchKernelGGL((k_schur_fused<FZ_LOGT, FZ_WPB, true, false>), dim3(grid), dim3(FZ_WPB * 64), lds, stream, a);
+            else hipLaunchKernelGGL((k_schur_fused<FZ_LOGT, FZ_WPB, false, false>), dim3(grid), dim3(FZ_WPB * 64), lds, stream, a);
+            HIPCHK(hipGetLastError());
+        }
+        if (class_timing) HIPCHK(hipEventRecord(ev_fz[1], stream));
+        if (nrows > 0) {
+            StreamFixArgs fa;
+            fa.nrows = nrows;
+            fa.fixcnt = fixcnt.p;
+            fa.fixbuf = fixbuf.p;
+            fa.sstart = S.start.p;
+            fa.Sent = S.ent.p;
+            fa.Slen = S.len.p;
+            fa.Slead = S.lead.p;
+            fa.ctr = fz_ctr.p;
+            fa.F = F;
+            hipLaunchKernelGGL(k_stream_fix, dim3(cdiv(nrows, 64)), dim3(256), 0, stream, fa);
+            HIPCHK(hipGetLastError());
+        }
+        if (class_timing) HIPCHK(hipEventRecord(ev_fz[2], stream));
+    }
+
+    // what the fused kernels did (synchronises): their statistics, rows left to the general path, space of S in use
+    void fetch_fused()
+    {
+        hfz = read_counters(fz_ctr.p);
+        int cnt[4] = {0, 0, 0, 0};
+        u64d cur = 0;
+        HIPCHK(hipMemcpyAsync(cnt, fz_counts.p, sizeof cnt, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&cur, fz_cursor.p, sizeof cur, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        fz_nlong = cnt[0];
+        fz_nrej = cnt[1];
+        fz_used = (i64)cur;
+        fz_rows = S.n - fz_nrej;
+        hctr = hfz;
+        memset(hclass_count, 0, sizeof hclass_count);
+    }
+    // the statistics of the whole step once the general path has run behind the fused kernels (synchronises)
+    void fetch_fused_and_fallback()
+    {
+        hfz = read_counters(fz_ctr.p);
+        fetch_counters(); // the general path's (throws on an exhausted pool / table)
+        hctr.nonempty_out += hfz.nonempty_out;
+        hctr.nnz_out += hfz.nnz_out;
+        hctr.stream_redo += hfz.stream_redo;
+        hctr.stream_fix += hfz.stream_fix;
+        hctr.class_ent[NCLASS - 1] = hfz.class_ent[NCLASS - 1];
+        hctr.class_seg[NCLASS - 1] = hfz.class_seg[NCLASS - 1];
+    }
+    // after any Schur step (synchronises)
+    bool fb_ran = false;
+    void fetch_step()
+    {
+        if (!last_fused) { fetch_counters(); return; }
+        if (fb_ran) { const int nr = fz_nrej; fetch_fused(); fz_nrej = nr; fz_rows = S.n - nr; fetch_fused_and_fallback(); }
+        else fetch_fused();
+    }
+
+    // the rows the fused step left (fz_nrej of them, known from fetch_fused or from an earlier run of the same step) through the
+    // general path: the plan along W / the multiplier lists, the hash-table and streaming classes; their Schur rows go behind
+    // those of the fused rows in S.ent (from `base` on) and under their own slots in S.  sync = false: pools and S are known to be
+    // large enough (a plan that has run this before), no host synchronisation.
+    i64 fb_pool = 1 << 16;
+    void fused_fallback(const DevMat &M, const int *rows, i64 base, bool sync)
+    {
+        const int nrej = fz_nrej;
+        fb_ran = false;
+        if (nrej <= 0) return;
+        fz_rej_rows.ensure((size_t)nrej + 1);
+        hipLaunchKernelGGL(k_rej_rows, dim3(cdiv(nrej, 256)), dim3(256), 0, stream, nrej, fz_rej_list.p, rows, fz_rej_rows.p);
+        HIPCHK(hipGetLastError());
+        // the general path writes S.start / len / lead / orig by ITS slots 0 .. nrej-1: give it arrays of its own, merge afterwards
+        auto swap_rows = [&]() { std::swap(S.start, fb_start); std::swap(S.len, fb_len); std::swap(S.lead, fb_lead); std::swap(S.orig, fb_orig); };
+        swap_rows();
+        const int keep_n = S.n;
+        const bool qk = quiet_known;
+        quiet_known = false;
+        gathered_n = -1;
+        base = (base + 15) & ~(i64)15;
+        s_ent_base = base;
+        try {
+            if (sync) {
+                const i64 tot = solve_phase(M, fz_rej_rows.p, nullptr, nrej, std::max<i64>(fb_pool, 64 * (i64)nrej));
+                if (tot < 0) throw EngineError("the rows left to the general path do not fit the device memory");
+                fb_pool = std::max<i64>(fb_pool, (i64)(pool_used() * 5 / 4) + 1024);
+                if ((i64)S.ent.n < base + tot + 1) {
+                    // (rare: the estimate the fused step was sized with was short) a larger S, the fused rows copied over
+                    DevBuf<int2> bigger;
+                    bigger.alloc((size_t)(base + tot + tot / 8 + 1));
+                    if (base > 0) HIPCHK(hipMemcpyAsync(bigger.p, S.ent.p, (size_t)std::min<i64>(base, (i64)S.ent.n) * sizeof(int2), hipMemcpyDeviceToDevice, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                    S.ent = std::move(bigger);
+                }
+            } else {
+                alloc_solve(nrej, fb_pool);
+                run_solve(M, fz_rej_rows.p, nullptr, nrej);
+                run_bounds(nrej);
+            }
+            run_scatter(M, fz_rej_rows.p, nrej);
+        } catch (...) {
+            s_ent_base = 0;
+            quiet_known = qk;
+            swap_rows();
+            throw;
+        }
+        s_ent_base = 0;
+        quiet_known = qk;
+        gathered_n = -1;
+        swap_rows();
+        S.n = keep_n;
+        last_fused = true;
+        fb_ran = true;
+        hipLaunchKernelGGL(k_merge_rej, dim3(cdiv(nrej, 256)), dim3(256), 0, stream, nrej, fz_rej_list.p, fb_start.p, fb_len.p, fb_lead.p, fb_orig.p, (i64d)base,
+                           S.start.p, S.len.p, S.lead.p, S.orig.p);
+        HIPCHK(hipGetLastError());
     }
 
     void fetch_counters()
@@ -1647,6 +1883,16 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
     st.stream_redo = R.hctr.stream_redo;
     st.ms_uinv = R.ms_uinv;
     st.ms_w = R.ms_w;
+    if (R.last_fused) {
+        if (R.class_timing && hipEventElapsedTime(&ms, R.ev_fz[0], R.ev_fz[1]) == hipSuccess) st.ms_fused = ms;
+        if (R.class_timing && hipEventElapsedTime(&ms, R.ev_fz[1], R.ev_fz[2]) == hipSuccess) st.ms_fused_fix = ms;
+        st.rows_fused = R.fz_rows;
+        st.ent_fused = (i64)R.hfz.class_ent[NCLASS - 1];
+        st.seg_fused = (i64)R.hfz.class_seg[NCLASS - 1];
+        st.rows_rejected = R.fz_nrej;
+        st.s_entries_used = R.fz_used;
+    }
+    st.ms_levels = R.ms_levels;
     if (R.use_w) {
         if (hipEventElapsedTime(&ms, R.ev[4], R.ev[1]) == hipSuccess) st.ms_wbuild = ms;
         st.w_levels = R.depth + 1;
@@ -2956,6 +3202,26 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         while (off < nnp || nnp == 0) {
             const int cnt = std::min(chunk, nnp - off);
             HIPCHK(hipEventRecord(R->ev[1], stream));
+            // The fused step (fused.hpp: plan + stream of a row in one kernel, S written compactly) when the round goes along W and the
+            // sample told how long the Schur rows are; the rows it leaves, and every round without W, take the general path: the
+            // solve (plan or multiplier lists, bounds), then the scatter classes.
+            const i64 fused_est = (R->fused_ok() && slots_per_row > 0) ? (i64)(slots_per_row * (double)cnt) + 16 * (i64)cnt : 0;
+            if (fused_est > 0 && fused_est <= max_slots) {
+                const i64 scap = R->fused_capacity(fused_est);
+                R->S.ent.ensure((size_t)scap + 1);
+                HIPCHK(hipEventRecord(R->ev[1], stream));
+                HIPCHK(hipEventRecord(R->ev[2], stream));
+                R->run_fused(*cur, R->np_rows.p + off, cnt, scap);
+                HIPCHK(hipEventRecord(R->ev[3], stream));
+                R->fetch_fused();
+                if (R->fz_nrej > 0) {
+                    R->fused_fallback(*cur, R->np_rows.p + off, scap, true);
+                    HIPCHK(hipEventRecord(R->ev[3], stream));
+                    R->fetch_fused_and_fallback();
+                }
+                goto schur_done;
+            }
+            {
             const i64 tot = R->solve_phase(*cur, R->np_rows.p + off, nullptr, cnt, std::max<i64>((i64)(rec_per_row * (double)cnt), 1 << 16), max_pool);
             if (tot < 0 || tot > max_slots) {
                 if (cnt <= 1) throw EngineError("one row of the Schur complement does not fit the device memory");
@@ -2968,6 +3234,8 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
             R->run_scatter(*cur, R->np_rows.p + off, cnt);
             HIPCHK(hipEventRecord(R->ev[3], stream));
             R->fetch_counters();
+            }
+        schur_done:
             if (want_L) collect_L_lists(HL, *R, *cur, off, cnt, (int)U.pivcol.size(), stream);
             {
                 float ms = 0;
@@ -3724,6 +3992,10 @@ struct spasm_amd_schur_plan {
     // the reference's trip counters of this round, counted once on the multiplier lists when the plan is made (the runs go
     // along the rows of W, where no list exists to count)
     u64d exact_applications = 0, exact_nnz_reduced = 0, exact_segments = 0;
+    // the fused step of this plan: capacity of S it is given, and how many rows it leaves to the general path (every run leaves the
+    // same rows: the dry run found out)
+    i64 fused_scap = 0;
+    int fused_nrej = 0;
 };
 
 namespace {
@@ -3777,6 +4049,19 @@ void plan_dry_run(spasm_amd_schur_plan *P, i64 pool_guess)
         R.quiet_known = true;
     }
     R.S.ent.ensure((size_t)std::max(tot, tot2) + 1);
+    if (R.fused_ok()) {
+        // the fused step once, with room to spare: how much of S it needs, which rows it leaves to the general path (whose
+        // pools are sized by running it for them once)
+        P->fused_scap = R.fused_capacity(std::max(tot, tot2) + 16 * (i64)R.nnp);
+        R.S.ent.ensure((size_t)P->fused_scap + 1);
+        R.run_fused(P->A, R.np_rows.p, R.nnp, P->fused_scap);
+        R.fetch_fused();
+        P->fused_nrej = R.fz_nrej;
+        if (R.fz_nrej > 0) {
+            R.fused_fallback(P->A, R.np_rows.p, P->fused_scap, true);
+            R.fetch_fused_and_fallback();
+        }
+    }
 }
 
 spasm_amd_shard *shard_create(const struct spasm_csr *A, int lo, int hi, int stride = 1)
@@ -3922,7 +4207,7 @@ spasm_amd_shard *plan_advance(spasm_amd_schur_plan *P, int *rows_out, i64 *nnz_o
     if (!P->ran) plan_run(P, P->R.stream);
     Round &R = P->R;
     hipStream_t s = R.stream;
-    R.fetch_counters(); // synchronises; throws on an exhausted pool / table
+    R.fetch_step(); // synchronises; throws on an exhausted pool / table
     const int n = P->A.n, nnp = R.nnp;
     std::unique_ptr<spasm_amd_shard> S2(new spasm_amd_shard());
     std::unique_ptr<spasm_amd_schur_plan> P2(new spasm_amd_schur_plan());
@@ -4033,11 +4318,20 @@ void plan_run(spasm_amd_schur_plan *P, hipStream_t s)
     if (R.use_w) R.build_w_levels(false);
     else if (R.use_uinv) R.prepare_uinv();
     HIPCHK(hipEventRecord(R.ev[1], s));
-    R.run_solve(P->A, R.np_rows.p, nullptr, R.nnp);
-    R.run_bounds(R.nnp);
-    HIPCHK(hipEventRecord(R.ev[2], s));
-    R.run_scatter(P->A, R.np_rows.p, R.nnp);
-    HIPCHK(hipEventRecord(R.ev[3], s));
+    if (R.fused_ok() && P->fused_scap > 0) {
+        // plan + stream of every row in one kernel (fused.hpp); the rows it leaves go through the general path behind it
+        HIPCHK(hipEventRecord(R.ev[2], s));
+        R.run_fused(P->A, R.np_rows.p, R.nnp, P->fused_scap);
+        R.fz_nrej = P->fused_nrej;
+        if (P->fused_nrej > 0) R.fused_fallback(P->A, R.np_rows.p, P->fused_scap, false);
+        HIPCHK(hipEventRecord(R.ev[3], s));
+    } else {
+        R.run_solve(P->A, R.np_rows.p, nullptr, R.nnp);
+        R.run_bounds(R.nnp);
+        HIPCHK(hipEventRecord(R.ev[2], s));
+        R.run_scatter(P->A, R.np_rows.p, R.nnp);
+        HIPCHK(hipEventRecord(R.ev[3], s));
+    }
     P->ran = true;
 }
 
@@ -4075,7 +4369,7 @@ struct spasm_csr *plan_fetch(spasm_amd_schur_plan *P, int *p_out)
     if (!P->ran) throw EngineError("spasm_amd_schur_plan_fetch: run the plan first");
     hipStream_t s = R.stream;
     const int n = R.nnp;
-    R.fetch_counters();
+    R.fetch_step();
     DevBuf<i64d> len64, ostart;
     len64.alloc((size_t)n + 1);
     ostart.alloc((size_t)n + 1);
@@ -4921,7 +5215,7 @@ SPASM_API int spasm_amd_schur_plan_stats(spasm_amd_schur_plan *plan, struct spas
 {
     try {
         if (!plan->ran) throw EngineError("run the plan first");
-        plan->R.fetch_counters();
+        plan->R.fetch_step();
         plan->R.hctr.applications = plan->exact_applications;
         plan->R.hctr.nnz_reduced = plan->exact_nnz_reduced;
         plan->R.hctr.segments = plan->exact_segments;
