@@ -279,6 +279,9 @@ struct Round {
     RoundCounters hfz;       // .. on the host
     bool last_fused = false; // the last Schur step went through run_fused
     DevBuf<int> fz_long_list, fz_rej_list, fz_rej_rows;
+    DevBuf<int4> fz_rec;     // per row slot: the two records of the fused kernels
+    DevBuf<FusedRare> fz_rare;
+    const int *fz_rare_lists[2] = {nullptr, nullptr}; // the list buffers fz_rare names (they may be reallocated for a larger round)
     DevBuf<i64d> fb_start;   // the general path's own row arrays while it works for the fused step
     DevBuf<int> fb_len, fb_lead, fb_orig;
     i64 fz_used = 0;         // entries of S handed out by the last fused step (incl. what its waves left of their blocks)
@@ -1506,7 +1509,12 @@ struct Round {
 
     // ---- (3 + 4, fused) the Schur rows of `nrows` rows of M in one pass over the rows (fused.hpp).  S.ent must hold `scap` entries.
     // No host synchronisation; afterwards fetch_fused() tells how many rows were left to the general path (fused_fallback()).
-    bool fused_ok() const { return use_fused && use_w && !force_lists && !want_idx && m < (1 << 24); }
+    // (the kernel reaches W, wcol and its row records through 32-bit byte offsets)
+    bool fused_ok() const
+    {
+        return use_fused && use_w && !force_lists && !want_idx && m < (1 << 24) && (u64d)(wbase + wcap + 64) * sizeof(int2) < 0xffffffffull &&
+               (u64d)m * sizeof(int4) < 0xf0000000ull;
+    }
     static constexpr int FZ_LOGT = 11, FZ_WPB = 4;
     // capacity of S the fused step wants for an estimated `entries` of Schur rows: every wave may leave a block unfinished
     i64 fused_capacity(i64 entries) const { return entries + entries / 50 + (i64)num_cu * 16 * (i64)FZ_SBLK + 64; }
@@ -1521,13 +1529,35 @@ struct Round {
         S.len.ensure((size_t)nrows + 1);
         S.lead.ensure((size_t)nrows + 1);
         S.orig.ensure((size_t)nrows + 1);
-        fixcnt.ensure((size_t)nrows + 1);
         fixbuf.ensure(((size_t)nrows + 1) * SFIX);
+        fz_rec.ensure(2 * ((size_t)nrows + 1));
         fz_long_list.ensure((size_t)nrows + 1);
         fz_rej_list.ensure((size_t)nrows + 1);
         fz_work.ensure((size_t)2 * FZ_NWORK * FZ_WSTRIDE);
         fz_cursor.ensure(2);
         fz_counts.ensure(4);
+        if (!fz_rare.p) {
+            fz_rare.ensure(1);
+            FusedRare h;
+            h.long_list = (fz_gint *)fz_long_list.p;
+            h.long_count = (fz_gint *)fz_counts.p;
+            h.rej_list = (fz_gint *)fz_rej_list.p;
+            h.rej_count = (fz_gint *)(fz_counts.p + 1);
+            HIPCHK(hipMemcpyAsync(fz_rare.p, &h, sizeof h, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            fz_rare_lists[0] = fz_long_list.p;
+            fz_rare_lists[1] = fz_rej_list.p;
+        } else if (fz_rare_lists[0] != fz_long_list.p || fz_rare_lists[1] != fz_rej_list.p) {
+            FusedRare h;
+            h.long_list = (fz_gint *)fz_long_list.p;
+            h.long_count = (fz_gint *)fz_counts.p;
+            h.rej_list = (fz_gint *)fz_rej_list.p;
+            h.rej_count = (fz_gint *)(fz_counts.p + 1);
+            HIPCHK(hipMemcpyAsync(fz_rare.p, &h, sizeof h, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            fz_rare_lists[0] = fz_long_list.p;
+            fz_rare_lists[1] = fz_rej_list.p;
+        }
         fz_ctr.ensure(NCTR);
         ctr.ensure(NCTR);
         class_count.ensure(NCLASS);
@@ -1541,7 +1571,7 @@ struct Round {
             const int nctr_words = (int)(NCTR * sizeof(RoundCounters) / 4), nwork = 2 * FZ_NWORK * FZ_WSTRIDE;
             const int span = std::max(std::max(nctr_words, nwork), nrows + 1);
             hipLaunchKernelGGL(k_fused_reset, dim3(cdiv(span, 256)), dim3(256), 0, stream, nrows, fz_work.p, nwork, fz_cursor.p, fz_counts.p, 4, (unsigned *)fz_ctr.p,
-                               nctr_words, fixcnt.p);
+                               nctr_words, fz_rec.p);
             HIPCHK(hipGetLastError());
         }
         if (class_timing) HIPCHK(hipEventRecord(ev_fz[0], stream));
@@ -1558,17 +1588,13 @@ struct Round {
             a.Sent = S.ent.p;
             a.scap = (u64d)scap;
             a.scursor = fz_cursor.p;
-            a.Sstart = S.start.p;
-            a.Slen = S.len.p;
-            a.Slead = S.lead.p;
-            a.Sorig = S.orig.p;
+            a.rec = fz_rec.p;
             a.fixbuf = fixbuf.p;
-            a.fixcnt = fixcnt.p;
-            a.long_list = nullptr; // (rows beyond the tables of the wave kernel: the general path)
-            a.long_count = fz_counts.p;
-            a.long_bound = 0;
-            a.rej_list = fz_rej_list.p;
-            a.rej_count = fz_counts.p + 1;
+            a.rare = fz_rare.p;
+            a.long_bound = 0; // (rows beyond the tables of the wave kernel: the general path)
+            a.buf_bytes = (unsigned)std::min<u64d>((u64d)UPN.n * sizeof(int2), 0xffffffffull);
+            a.pbits_bytes = (unsigned)std::min<u64d>((u64d)pbits.n * sizeof(unsigned), 0xffffffffull);
+            a.wcol_bytes = (unsigned)std::min<u64d>((u64d)wcol.n * sizeof(int4), 0xffffffffull);
             a.work = fz_work.p;
             a.ctr = fz_ctr.p;
             a.cls = NCLASS - 1; // (the statistics slot of the fix-up launch, which counts nothing there)
@@ -1598,17 +1624,19 @@ struct Round {
         }
         if (class_timing) HIPCHK(hipEventRecord(ev_fz[1], stream));
         if (nrows > 0) {
-            StreamFixArgs fa;
+            FusedFinishArgs fa;
             fa.nrows = nrows;
-            fa.fixcnt = fixcnt.p;
+            fa.rec = fz_rec.p;
+            fa.rinfo = rinfo.p;
             fa.fixbuf = fixbuf.p;
-            fa.sstart = S.start.p;
             fa.Sent = S.ent.p;
+            fa.Sstart = S.start.p;
             fa.Slen = S.len.p;
             fa.Slead = S.lead.p;
+            fa.Sorig = S.orig.p;
             fa.ctr = fz_ctr.p;
             fa.F = F;
-            hipLaunchKernelGGL(k_stream_fix, dim3(cdiv(nrows, 64)), dim3(256), 0, stream, fa);
+            hipLaunchKernelGGL(k_fused_finish, dim3(cdiv(nrows, 64)), dim3(256), 0, stream, fa);
             HIPCHK(hipGetLastError());
         }
         if (class_timing) HIPCHK(hipEventRecord(ev_fz[2], stream));

@@ -28,9 +28,24 @@ constexpr u64d FZ_SBLK = 16384;    // entries of S a wave takes from the cursor 
 constexpr int FZ_B = 8;            // row slots per block
 constexpr int FZ_MINLOGT = 8;     // (the third table then has 2^6 slots: slot + the 18 bits of the word still name the column)
 
+// what the kernel needs now and then (kept in device memory: the arguments it holds in registers all the time are few)
+// (pointers into GLOBAL memory, said so: through a pointer that was itself loaded from memory the compiler otherwise emits flat
+// instructions, and one flat access in flight makes every later wait for a load a wait for all loads)
+typedef __attribute__((address_space(1))) int fz_gint;
+struct FusedRare {
+    fz_gint *long_list;        // slots whose stream is beyond this launch's tables but within FusedArgs::long_bound
+    fz_gint *long_count;
+    fz_gint *rej_list;         // slots left to the general path
+    fz_gint *rej_count;
+};
+__device__ __forceinline__ void fz_list_append(fz_gint *list, fz_gint *count, int t)
+{
+    list[__hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = t;
+}
+
 struct FusedArgs {
     int nrows;                 // row slots of the round
-    const int *slots;          // NULL: the slots 0 .. nrows-1; else the slots to take (a list another launch left) ..
+    const int *slots;          // LIST launches: the slots to take (a list another launch left) ..
     const int *slot_count;     // .. and how many (device)
     const int4 *rinfo;         // per slot: {start (low, high), length, originating row} of the row's own entries
     const int2 *ent;
@@ -40,29 +55,23 @@ struct FusedArgs {
     int2 *Sent;
     u64d scap;                 // entries Sent holds
     u64d *scursor;
-    i64d *Sstart;
-    int *Slen;
-    int *Slead;
-    int *Sorig;
-    int2 *fixbuf;              // [slot][SFIX] duplicates found in the row, merged afterwards by k_stream_fix
-    int *fixcnt;
-    int *long_list;            // slots whose stream is beyond this launch's tables but within long_bound
-    int *long_count;
-    int long_bound;
-    int *rej_list;             // slots left to the general path
-    int *rej_count;
+    int4 *rec;                 // per slot two records: {start (low, high), length, leftmost column}, {duplicates (-1: the row was not taken), -, -, -}
+    int2 *fixbuf;              // [slot][SFIX] duplicates found in the row, merged afterwards by k_fused_finish
+    const FusedRare *rare;
     unsigned *work;            // FZ_NWORK block counters
     RoundCounters *ctr;
     int cls;                   // index for the per-class counters
     int free_cols;
+    int long_bound;            // rows with a stream beyond this launch's tables but within this go on rare->long_list (0: no such list)
+    unsigned buf_bytes, pbits_bytes, wcol_bytes; // sizes of buf / pbits / wcol (the kernel reaches them through 32-bit offsets)
     ZpField F;
 };
 
 // LDS of one wave: three tag tables of 2^LOGTMAX, half and a quarter of that, 64 B of counters, fix-up list, loser list
 template <int LOGTMAX> struct FzLds {
     static constexpr int WORDS = (1 << LOGTMAX) + (1 << (LOGTMAX - 1)) + (1 << (LOGTMAX - 2));
-    static constexpr size_t TABB = (size_t)4 * WORDS, MISCB = 64, FIXB = (size_t)SFIX * 8, LSTB = (size_t)SLCAP * 16;
-    static constexpr size_t SLOT = TABB + MISCB + FIXB + LSTB;
+    static constexpr size_t TABB = (size_t)4 * WORDS, MISCB = 64, FIXB = (size_t)SFIX * 8, LSTB = (size_t)SLCAP * 16, MARKB = 256;
+    static constexpr size_t SLOT = TABB + MISCB + FIXB + LSTB + MARKB;
 };
 __host__ __device__ constexpr int fz_cap(int logt) { return 5 << (logt - 3); } // a first table of 2^logt words at most 5/8 full
 template <int LOGTMAX> __host__ __device__ constexpr size_t fused_lds_bytes(int wpb) { return FzLds<LOGTMAX>::SLOT * (size_t)wpb; }
@@ -129,6 +138,13 @@ __device__ __forceinline__ u64d fz_pin(u64d v)
     asm volatile("" : "+v"(lo), "+v"(hi)::"memory");
     return ((u64d)hi << 32) | lo;
 }
+// an 8-byte load from a wave-uniform base + a 32-bit byte offset per lane (the form that needs no 64-bit address per lane)
+__device__ __forceinline__ int2 fz_load8(const int2 *ubase, unsigned byteoff) { return *(const int2 *)((const char *)ubase + byteoff); }
+// lane l of v becomes x (x, l scalar)
+__device__ __forceinline__ void fz_set_lane(int &v, int x, int l)
+{
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l) : "m0");
+}
 __device__ __forceinline__ int fz_lane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ i64d fz_lane_i64(i64d v, int l)
 {
@@ -136,7 +152,7 @@ __device__ __forceinline__ i64d fz_lane_i64(i64d v, int l)
 }
 
 // the plan of a row (all wave-uniform).  Its chunks -- at most 64 consecutive entries of a run of W each -- sit in a table of 64
-// lanes shared by the rows in flight: chunk j of the row in lane (cbase + j) & 63.
+// lanes shared by the rows in flight: chunk j of the row in lane (cb + j) & 63, padded with empty chunks to whole double groups.
 constexpr int FZ_MAXC = 32;        // chunks a row of the wave kernel may have: the double groups of two rows fit the 64 lanes
 struct FzPlan {
     int t;          // row slot; < 0: nothing to do (no row, or the row went on a list)
@@ -144,11 +160,19 @@ struct FzPlan {
     int bound;      // length of the stream
     int logt;
     int C;          // chunks
-    int cbase;      // lane of its first chunk
-    int nruns;
+    int cp;         // .. padded to whole double groups (at least one)
+    int cb;         // lane of its first chunk
+    int nr;         // runs
     u64d mN;        // lanes whose own entry sits on a non-pivot column
     i64d sbase;     // where the row starts in S
 };
+
+typedef int fz_v2i __attribute__((ext_vector_type(2)));
+typedef int fz_v4i __attribute__((ext_vector_type(4)));
+constexpr int FZ_RSRC = 0x00020000; // dword 3 of a raw buffer resource (gfx9 family)
+// a raw buffer over `bytes` bytes at p: accesses are base + a 32-bit scalar offset + a 32-bit lane offset, and what falls outside is
+// dropped (stores) / read as zero (loads)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fz_rsrc(const void *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, FZ_RSRC); }
 
 // LIST: the launch takes the slots of a list (a.slots, a.slot_count) instead of all of them
 template <int LOGTMAX, int WPB, bool SMALL, bool LIST>
@@ -160,18 +184,24 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
     constexpr int DG = 2 * Q; // a double group: group A in ringA, group B in ringB
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int lane = threadIdx.x & 63;
+    const int lane8 = lane << 3;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned char *base = s_raw + (size_t)wave * L::SLOT;
     unsigned *t1 = (unsigned *)base;
     int *misc = (int *)(base + L::TABB);
     int2 *fix = (int2 *)(base + L::TABB + L::MISCB);
     int4 *lst = (int4 *)(base + L::TABB + L::MISCB + L::FIXB);
+    int *mark = (int *)(base + L::TABB + L::MISCB + L::FIXB + L::LSTB); // 64 words: which run starts at a chunk
     const ZpField F = a.F;
     const int N = LIST ? *a.slot_count : a.nrows;
     const int nblk = (N + FZ_B - 1) / FZ_B;
+    const __amdgpu_buffer_rsrc_t r_buf = fz_rsrc(a.buf, a.buf_bytes), r_info = fz_rsrc(a.rinfo, (unsigned)a.nrows * 16u + 16u),
+                                 r_pb = fz_rsrc(a.pbits, a.pbits_bytes), r_wc = fz_rsrc(a.wcol, a.wcol_bytes),
+                                 r_rec = fz_rsrc(a.rec, (unsigned)a.nrows * 32u + 32u);
 
     for (int s = lane * 4; s < L::WORDS; s += 256) *(int4 *)(t1 + s) = make_int4(0, 0, 0, 0);
     if (lane < 16) misc[lane] = 0;
+    mark[lane] = -1;
     __builtin_amdgcn_wave_barrier();
 
     // ---- blocks of FZ_B consecutive row slots, from the counters: the lb-th block of counter x is block lb * FZ_NWORK + x
@@ -241,104 +271,131 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
         return (i64d)r;
     };
 
-    // ---- the chunk table (a lane per chunk): where the chunk starts in buf, the multiplier of its run, its stream position << 8 | entries
-    int T_off = 0, T_mul = 0, T_pn = 1;
+    // ---- the chunk table (a lane per chunk): byte offset of the chunk in buf; byte offset of its first entry in the row's stream;
+    // (stream position + 1) << 8 | entries (0: an empty chunk of the padding); the multiplier of its run
+    int T_ld = 0, T_st = 0, T_pn = 0, T_mul = 0;
 
-    // ---- the plan of row number s (its entries e, the lanes mP on pivot columns, their {-, length, offset, -} of W); its chunks go
-    // to the lanes from cbase on
-    auto make_plan = [&](int t, int ln, const int2 &e, u64d mP, const int4 &wc, int cbase) -> FzPlan {
+    // ---- the plan of a row: slot t, ln own entries e, the lanes mP on pivot columns with {length, offset} wc of their rows of W;
+    // its chunks go to the lanes from cb on
+    auto make_plan = [&](int t, int ln, const int2 &e, u64d mP, const fz_v2i &wc, int cb) -> FzPlan {
         FzPlan pl;
         pl.t = -1;
-        pl.nN = 0; pl.bound = 0; pl.logt = FZ_MINLOGT; pl.C = 0; pl.cbase = cbase & 63; pl.nruns = 0; pl.mN = 0; pl.sbase = 0;
-        if (t < 0) return pl;
-        const bool valid = lane < min(ln, 64);
-        const bool isP = (mP >> lane) & 1ull;
-        const int wl = isP ? wc.y : 0;
-        // what this kernel does not take: more than 64 own entries, a zero among them, a row of W that could not be built
-        const bool bad = ln > 64 || __ballot((valid && e.y == 0) || wl < 0) != 0;
-        const int nch = (max(wl, 0) + 63) >> 6;
-        int tot = 0, ctot = 0;
-        const int incl = team_incl_scan<64>(max(wl, 0), tot);
-        const int cincl = team_incl_scan<64>(nch, ctot);
-        const u64d mN = __ballot(valid && !isP);
-        const int nN = __popcll(mN);
-        const i64d bound = (i64d)nN + (i64d)tot;
-        bool tolong = false, rej = bad || bound > (i64d)a.free_cols;
-        if (!rej && (bound > (i64d)fz_cap(LOGTMAX) || ctot > FZ_MAXC)) {
-            if (a.long_list && bound <= (i64d)a.long_bound) tolong = true;
-            else rej = true;
-        }
-        i64d sb = 0;
-        if (!rej && !tolong) {
-            sb = take_s((int)bound);
-            if (sb < 0) rej = true;
-        }
-        if (rej || tolong) {
-            if (lane == 0) {
-                if (tolong) a.long_list[atomicAdd(a.long_count, 1)] = t;
-                else a.rej_list[atomicAdd(a.rej_count, 1)] = t;
+        pl.nN = 0; pl.bound = 0; pl.logt = FZ_MINLOGT; pl.C = 0; pl.cp = DG; pl.cb = cb & 63; pl.nr = 0; pl.mN = 0; pl.sbase = 0;
+        const int jl = (lane - cb) & 63; // the chunk this lane would hold
+        bool ok = t >= 0;
+        int nN = 0, bound = 0, ctot = 0, nch = 0, incl = 0, cincl = 0, wl = 0;
+        u64d mN = 0;
+        if (ok) {
+            const bool valid = lane < min(ln, 64);
+            const bool isP = (mP >> lane) & 1ull;
+            wl = isP ? wc.x : 0;
+            // what this kernel does not take: more than 64 own entries, a zero among them, a row of W that could not be built
+            const bool bad = ln > 64 || __ballot((valid && e.y == 0) || wl < 0) != 0;
+            wl = max(wl, 0);
+            nch = (wl + 63) >> 6;
+            int tot = 0;
+            incl = team_incl_scan<64>(wl, tot);
+            cincl = team_incl_scan<64>(nch, ctot);
+            mN = __ballot(valid && !isP);
+            nN = __popcll(mN);
+            const i64d b64 = (i64d)nN + (i64d)tot;
+            bool tolong = false, rej = bad || b64 > (i64d)a.free_cols;
+            if (!rej && (b64 > (i64d)fz_cap(LOGTMAX) || ctot > FZ_MAXC)) {
+                if (b64 <= (i64d)a.long_bound) tolong = true;
+                else rej = true;
             }
+            i64d sb = 0;
+            if (!rej && !tolong) {
+                sb = take_s((int)b64);
+                if (sb < 0) rej = true;
+            }
+            if (rej || tolong) {
+                if (lane == 0) {
+                    if (tolong) fz_list_append(a.rare->long_list, a.rare->long_count, t);
+                    else fz_list_append(a.rare->rej_list, a.rare->rej_count, t);
+                }
+                ok = false;
+            } else {
+                bound = (int)b64;
+                pl.sbase = sb;
+            }
+        }
+        if (!ok) {
+            // nothing to do for this row: one double group of empty chunks (it carries the requests of the row behind it)
+            if (jl < DG) { T_ld = 0; T_pn = 0; }
             return pl;
         }
         int logt = FZ_MINLOGT;
-        while (fz_cap(logt) < (int)bound) logt++;
+        while (fz_cap(logt) < bound) logt++;
         pl.t = t;
         pl.nN = nN;
-        pl.bound = (int)bound;
+        pl.bound = bound;
         pl.logt = logt;
         pl.C = ctot;
-        pl.nruns = __popcll(mP);
+        pl.cp = max(DG, (ctot + DG - 1) & ~(DG - 1));
+        pl.nr = __popcll(mP);
         pl.mN = mN;
-        pl.sbase = sb;
-        // the chunks: run by run, the lane of chunk j takes what chunk j is
-        const int cb0 = cincl - nch, rpos = nN + incl - max(wl, 0);
-        const int jl = (lane - cbase) & 63;
-        for (u64d m = mP; m != 0; m &= m - 1) {
-            const int l = __ffsll((long long)m) - 1;
-            const int cb = fz_lane_i32(cb0, l), nc = fz_lane_i32(nch, l), wo = fz_lane_i32(wc.z, l), w_l = fz_lane_i32(wl, l), mu = fz_lane_i32(e.y, l),
-                      rp = fz_lane_i32(rpos, l);
-            const int j = jl - cb;
-            if (j >= 0 && j < nc) {
-                T_off = wo + 64 * j;
-                T_mul = mu;
-                T_pn = ((rp + 64 * j) << 8) | min(64, w_l - 64 * j);
+        // the chunks.  Every run names itself at its first chunk (LDS), a prefix maximum tells every chunk its run, and the run's
+        // {offset, length, stream position, multiplier} come over by lane permutation.
+        const int cb0 = cincl - nch, rpos = nN + incl - wl;
+        if (nch > 0) mark[cb0] = lane;
+        __builtin_amdgcn_wave_barrier();
+        int run = mark[jl]; // (-1 where no run starts; chunk lanes beyond the row read marks of the padding: never set)
+        __builtin_amdgcn_wave_barrier();
+        if (nch > 0) mark[cb0] = -1;
+        if (jl >= ctot) run = -1;
+        // inclusive prefix maximum over jl = 0 .. 63: the lanes are rotated by cb, so go through the lane order of jl -- a rotation
+        // brings chunk jl to lane jl, the scan runs there, and the result is rotated back
+        {
+            const int src = (lane + cb) & 63; // lane holding chunk `lane`
+            int r = __builtin_amdgcn_ds_bpermute(src << 2, run);
+            r = max(r, __builtin_amdgcn_update_dpp(-1, r, 0x111, 0xf, 0xf, false));
+            r = max(r, __builtin_amdgcn_update_dpp(-1, r, 0x112, 0xf, 0xf, false));
+            r = max(r, __builtin_amdgcn_update_dpp(-1, r, 0x114, 0xf, 0xf, false));
+            r = max(r, __builtin_amdgcn_update_dpp(-1, r, 0x118, 0xf, 0xf, false));
+            r = max(r, __builtin_amdgcn_update_dpp(-1, r, 0x142, 0xa, 0xf, false));
+            r = max(r, __builtin_amdgcn_update_dpp(-1, r, 0x143, 0xc, 0xf, false));
+            run = __builtin_amdgcn_ds_bpermute(jl << 2, r);
+        }
+        {
+            const int ra = max(run, 0) << 2;
+            const int r_cb = __builtin_amdgcn_ds_bpermute(ra, cb0), r_wl = __builtin_amdgcn_ds_bpermute(ra, wl), r_wo = __builtin_amdgcn_ds_bpermute(ra, wc.y),
+                      r_rp = __builtin_amdgcn_ds_bpermute(ra, rpos), r_mu = __builtin_amdgcn_ds_bpermute(ra, e.y);
+            if (jl < pl.cp) {
+                const int jj = jl - r_cb;
+                const bool real = run >= 0 && jl < ctot; // (the prefix maximum ran on into the padding)
+                T_ld = real ? (r_wo + 64 * jj) << 3 : 0;
+                T_st = real ? (r_rp + 64 * jj) << 3 : 0;
+                T_pn = real ? ((r_rp + 64 * jj + 1) << 8) | min(64, r_wl - 64 * jj) : 0;
+                T_mul = r_mu;
             }
         }
-        if (lane == 0) a.Sstart[t] = sb;
         return pl;
     };
-    auto padded = [&](int C) { return max(DG, (C + DG - 1) & ~(DG - 1)); }; // every row takes a whole number of double groups, at least one
 
-    // ---- chunk loads.  The chunks of the rows form ONE stream: group A of a double group lives in ringA, group B in ringB, and
-    // while double group d is worked on the loads of double group d + 1 are issued -- of the same row, or the first one of the next
-    // row (whose plan is made before the current row starts).  Always Q loads per request, with clamped chunk numbers: a number of
-    // loads that depends on the row would make every wait for an older load a wait for all of them.
-    int2 ringA[Q], ringB[Q];
-    auto refill = [&](const FzPlan &cur, int cp, const FzPlan &nxt, int j0, int2 (&r)[Q]) {
+    // ---- chunk loads.  The chunks of the rows form ONE stream: every row takes a whole number of double groups (at least one),
+    // group A of a double group lives in ringA, group B in ringB, and while double group d is worked on the loads of double group
+    // d + 1 are issued -- of the same row, or the first one of the next row (whose plan is made before the current row starts, and
+    // whose chunks sit behind those of the current row in the table).  Always Q loads per request (an empty chunk reads the first
+    // entries of the buffer): a number of loads that depends on the row would make every wait for an older load a wait for all.
+    fz_v2i ringA[Q], ringB[Q];
+    auto refill = [&](int c0, fz_v2i (&r)[Q]) {
 #pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int j = j0 + q;
-            // chunk j of the current row, or chunk j - cp of the next one; beyond the last chunk: the last chunk again (a row without
-            // chunks: whatever its first lane holds -- offset 0, one entry, at the start)
-            const int g = j < cp ? cur.cbase + min(j, max(cur.C - 1, 0)) : nxt.cbase + min(j - cp, max(nxt.C - 1, 0));
-            const unsigned off = (unsigned)fz_lane_i32(T_off, g & 63);
-            const int n = fz_lane_i32(T_pn, g & 63) & 0xff;
-            r[q] = a.buf[(size_t)off + (unsigned)min(lane, max(n - 1, 0))];
-        }
+        for (int q = 0; q < Q; q++) r[q] = __builtin_amdgcn_raw_buffer_load_b64(r_buf, lane8, fz_lane_i32(T_ld, (c0 + q) & 63), 0);
     };
 
-    // ---- the stages.  I: {start, length, slot} of a row (slot < 0: no row) + its originating row; E: its entries, a lane each;
-    // PB: the word of pbits of every entry; WC: {-, length, offset, -} of the row of W of every entry on a pivot column
-    int4 I5 = make_int4(0, 0, 0, 0), I4 = I5;
+    // ---- the stages.  I: {start, length, originating row} of a row, T its slot (< 0: no row); E: its entries, a lane each;
+    // PB: the word of pbits of every entry; WC: {length, offset} of the row of W of every entry on a pivot column
+    fz_v4i I5 = {0, 0, 0, 0}, I4 = I5;
     int T5 = -1, T4 = -1, T3 = -1, T2 = -1, T1 = -1; // slots (scalar)
     int SL6 = 0, SL5 = 0;                            // LIST: the word of the list of row s + 6 / s + 5
     int L3 = 0, L2 = 0, L1 = 0;                      // lengths (scalar)
     int2 E4 = make_int2(0, 0), E3 = E4, E2 = E4, E1 = E4, E0 = E4;
     unsigned PB3 = 0, PB2 = 0;
-    int4 WC2 = make_int4(0, 0, 0, 0), WC1 = WC2;
+    fz_v2i WC2 = {0, 0}, WC1 = WC2;
     u64d mP2 = 0, mP1 = 0;
     FzPlan P0, P1;
-    P0.t = -1; P0.nN = 0; P0.bound = 0; P0.logt = FZ_MINLOGT; P0.C = 0; P0.cbase = 0; P0.nruns = 0; P0.mN = 0; P0.sbase = 0;
+    P0.t = -1; P0.nN = 0; P0.bound = 0; P0.logt = FZ_MINLOGT; P0.C = 0; P0.cp = DG; P0.cb = 0; P0.nr = 0; P0.mN = 0; P0.sbase = 0;
     u64d c_nnz = 0, c_seg = 0;
     int c_rows = 0, c_redo = 0;
     int s_blk0 = 0; // first row number of the current block
@@ -365,25 +422,22 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
                 SL6 = a.slots[max(i6, 0)];
                 T5 = i5 < N ? fz_sgpr(SL5) : -1;
             } else T5 = i5 < N ? i5 : -1;
-            I5 = a.rinfo[max(T5, 0)];
+            I5 = __builtin_amdgcn_raw_buffer_load_b128(r_info, 0, max(T5, 0) << 4, 0);
         }
         int L4 = 0;
         {
-            const i64d st4 = (i64d)(((u64d)(unsigned)fz_sgpr(I4.y) << 32) | (unsigned)fz_sgpr(I4.x));
+            const u64d st4 = ((u64d)(unsigned)fz_sgpr(I4.y) << 32) | (unsigned)fz_sgpr(I4.x);
             L4 = T4 < 0 ? 0 : fz_sgpr(I4.z);
-            E4 = a.ent[(T4 < 0 ? 0 : st4) + min(lane, max(min(L4, 64) - 1, 0))];
-            if (lane == 0 && T4 >= 0) a.Sorig[T4] = I4.w;
+            E4 = fz_load8(a.ent + (T4 < 0 ? 0 : st4), (unsigned)min(lane, max(min(L4, 64) - 1, 0)) << 3);
         }
-        PB3 = a.pbits[(unsigned)E3.x >> 5];
+        PB3 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r_pb, (int)(((unsigned)E3.x >> 5) << 2), 0, 0);
         {
-            const int l2 = L2;
-            const bool p2 = lane < min(l2, 64) && ((PB2 >> (E2.x & 31)) & 1u);
+            const bool p2 = lane < min(L2, 64) && ((PB2 >> (E2.x & 31)) & 1u);
             mP2 = __ballot(p2);
-            WC2 = a.wcol[p2 ? E2.x : 0];
+            WC2 = __builtin_amdgcn_raw_buffer_load_b64(r_wc, p2 ? (E2.x << 4) : 0, 4, 0); // {length, offset} of the column's record
         }
         // ---- the plan of row s + 1; its chunks go behind those of the current row
-        const int cp = padded(P0.C);
-        P1 = make_plan(T1, L1, E1, mP1, WC1, P0.cbase + cp);
+        P1 = make_plan(T1, L1, E1, mP1, WC1, P0.cb + P0.cp);
 
         // ---- the current row
         const bool live = P0.t >= 0;
@@ -392,14 +446,15 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
         tb.t[0] = t1;
         tb.t[1] = t1 + (1 << P0.logt);
         tb.t[2] = t1 + (1 << P0.logt) + (1 << (P0.logt - 1));
-        unsigned char *const rowp = (unsigned char *)(a.Sent + P0.sbase);
+        const __amdgpu_buffer_rsrc_t r_row = fz_rsrc(a.Sent + P0.sbase, (unsigned)P0.bound << 3);
         int mylead = INT_MAX;
         if (live) {
             // own entries on non-pivot columns: the front of the stream
             const bool isN = (P0.mN >> lane) & 1ull;
             if (isN) {
                 const int pos = __popcll(P0.mN & lanemask_lt());
-                __builtin_nontemporal_store(((long long)(unsigned)E0.y << 32) | (unsigned)E0.x, (long long *)(rowp + ((unsigned)pos << 3)));
+                const fz_v2i ev = {E0.x, E0.y};
+                __builtin_amdgcn_raw_buffer_store_b64(ev, r_row, pos << 3, 0, 2);
                 mylead = E0.x;
                 const int cc[1] = {E0.x}, pp[1] = {pos + 1};
                 unsigned oo[1], ll[1];
@@ -414,19 +469,20 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
         }
         // the runs, a double group at a time (a row without chunks still takes one: it carries the requests of the next row)
         {
-            auto do_group = [&](const int2 (&ring)[Q], int g0) {
-                int cc[Q], vv[Q], pp[Q];
+            auto do_group = [&](const fz_v2i (&ring)[Q], int c0) {
+                int cc[Q], vv[Q], pp[Q], st[Q];
                 bool act[Q];
                 unsigned oo[Q], left[Q], w1[Q];
                 unsigned *s1[Q];
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const int gq = (P0.cbase + min(g0 + q, max(P0.C - 1, 0))) & 63;
-                    const int pn = fz_lane_i32(T_pn, gq), mul = fz_lane_i32(T_mul, gq);
-                    act[q] = g0 + q < P0.C && lane < (pn & 0xff);
+                    const int g = (c0 + q) & 63;
+                    const int pn = fz_lane_i32(T_pn, g), mul = fz_lane_i32(T_mul, g);
+                    st[q] = fz_lane_i32(T_st, g);
+                    act[q] = lane < (pn & 0xff);
                     cc[q] = ring[q].x;
                     vv[q] = stream_mul<SMALL>(F, mul, ring[q].y);
-                    pp[q] = (int)((unsigned)pn >> 8) + lane + 1;
+                    pp[q] = (int)((unsigned)pn >> 8) + lane;
                     w1[q] = fz_want<0>(tb, cc[q], pp[q], s1[q]);
                     oo[q] = 0;
                 }
@@ -434,7 +490,8 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
                     if (act[q]) {
-                        __builtin_nontemporal_store(((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q], (long long *)(rowp + ((unsigned)(pp[q] - 1) << 3)));
+                        const fz_v2i ev = {cc[q], vv[q]};
+                        __builtin_amdgcn_raw_buffer_store_b64(ev, r_row, lane8, st[q], 2);
                         mylead = min(mylead, cc[q]);
                         oo[q] = atomicCAS(s1[q], 0u, w1[q]);
                     }
@@ -450,11 +507,20 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
                     for (int q = 0; q < Q; q++) stream_report(stream_outcome(left[q]), oo[q], act[q], cc[q], vv[q], pp[q], misc, fix, FCAP, lst);
                 }
             };
-            for (int g0 = 0; g0 < cp; g0 += DG) {
-                if (g0 < P0.C) do_group(ringA, g0);
-                refill(P0, cp, P1, g0 + DG, ringA);
-                if (g0 + Q < P0.C) do_group(ringB, g0 + Q);
-                refill(P0, cp, P1, g0 + DG + Q, ringB);
+            // (a group that is all padding still "uses" its loads: the registers are about to be loaded again, and the compiler
+            // then waits for exactly these loads instead of for everything in flight)
+            auto touch = [&](const fz_v2i (&ring)[Q]) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) asm volatile("" ::"v"(ring[q].x), "v"(ring[q].y));
+            };
+            for (int g0 = 0; g0 < P0.cp; g0 += DG) {
+                const int c0 = P0.cb + g0;
+                if (g0 < P0.C) do_group(ringA, c0);
+                else touch(ringA);
+                refill(c0 + DG, ringA);
+                if (g0 + Q < P0.C) do_group(ringB, c0 + Q);
+                else touch(ringB);
+                refill(c0 + DG + Q, ringB);
             }
         }
 
@@ -483,18 +549,19 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
             redo = redo || nfix > FCAP;
             if (redo) {
                 // too many duplicate columns for the lists: the general path takes the row (its space in S stays unused)
-                if (lane == 0) a.rej_list[atomicAdd(a.rej_count, 1)] = t_cur;
+                if (lane == 0) fz_list_append(a.rare->rej_list, a.rare->rej_count, t_cur);
                 c_redo += 1;
             } else {
                 if (lane < nfix) a.fixbuf[(size_t)t_cur * SFIX + lane] = fix[lane];
+                // the row's record: {where it starts (low, high), its length (duplicates still in), leftmost column}, {duplicates}
                 if (lane == 0) {
-                    a.Slen[t_cur] = E; // duplicates are merged by k_stream_fix, which corrects the length then
-                    a.Slead[t_cur] = E > 0 ? lead_out : INT_MAX;
-                    a.fixcnt[t_cur] = nfix;
+                    const fz_v4i r0 = {(int)(unsigned)(u64d)P0.sbase, (int)(unsigned)((u64d)P0.sbase >> 32), E, E > 0 ? lead_out : INT_MAX};
+                    __builtin_amdgcn_raw_buffer_store_b128(r0, r_rec, 0, t_cur << 5, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(nfix, r_rec, 16, t_cur << 5, 0);
                 }
                 c_nnz += (u64d)E;
                 c_rows += E > 0;
-                c_seg += 1 + (u64d)P0.nruns;
+                c_seg += 1 + (u64d)P0.nr;
             }
             // reset what the row used of the tables, and the counters
             const int words = 7 << (P0.logt - 2);
@@ -547,16 +614,80 @@ __global__ void k_gather_info(int n, const int *__restrict__ rows, const i64d *_
     rinfo[t] = make_int4((int)(unsigned)st, (int)(unsigned)(st >> 32), len[row], orig[row]);
 }
 
-// what a fused step starts from: block counters, the cursor of S, the list counts, the statistics, no duplicates in any row
+// what a fused step starts from: block counters, the cursor of S, the list counts, the statistics, no row taken yet
 __global__ void k_fused_reset(int nrows, unsigned *__restrict__ work, int nwork_words, u64d *__restrict__ cursor, int *__restrict__ counts, int ncounts,
-                              unsigned *__restrict__ ctr_words, int nctr_words, int *__restrict__ fixcnt)
+                              unsigned *__restrict__ ctr_words, int nctr_words, int4 *__restrict__ rec)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < nwork_words) work[t] = 0;
     if (t == 0) *cursor = 0;
     if (t < ncounts) counts[t] = 0;
     if (t < nctr_words) ctr_words[t] = 0;
-    if (t <= nrows) fixcnt[t] = 0;
+    if (t < nrows) rec[2 * (size_t)t + 1] = make_int4(-1, 0, 0, 0);
+}
+
+// Behind the fused kernels: the duplicates they found are merged row by row (stream_fixup of stream.hpp: a wave looks at 16 row
+// slots and works through those that have any), and the rows' records become the arrays the rest of the engine reads
+// (start / length / leftmost column / originating row per slot).  Slots no fused kernel took are left alone: the general path
+// fills them in.
+struct FusedFinishArgs {
+    int nrows;
+    const int4 *rec;
+    const int4 *rinfo;
+    const int2 *fixbuf;
+    int2 *Sent;
+    i64d *Sstart;
+    int *Slen;
+    int *Slead;
+    int *Sorig;
+    RoundCounters *ctr;
+    ZpField F;
+};
+__global__ __launch_bounds__(256) void k_fused_finish(FusedFinishArgs a)
+{
+    __shared__ int s_scratch[4][8 * SFIX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t0 = (blockIdx.x * 4 + wave) * 16;
+    if (t0 >= a.nrows) return;
+    const bool mine = lane < 16 && t0 + lane < a.nrows;
+    int4 r0 = make_int4(0, 0, 0, INT_MAX);
+    int nfix = -1;
+    if (mine) {
+        nfix = a.rec[2 * (size_t)(t0 + lane) + 1].x;
+        if (nfix >= 0) r0 = a.rec[2 * (size_t)(t0 + lane)];
+    }
+    u64d m = __ballot(nfix > 0);
+    u64d holes = 0;
+    int emptied = 0, merged = 0;
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int t = t0 + l;
+        const int n = __builtin_amdgcn_readlane(nfix, l);
+        const int E = __builtin_amdgcn_readlane(r0.z, l);
+        int lead = __builtin_amdgcn_readlane(r0.w, l);
+        const i64d st = (i64d)(((u64d)(unsigned)__builtin_amdgcn_readlane(r0.y, l) << 32) | (unsigned)__builtin_amdgcn_readlane(r0.x, l));
+        const int n_out = stream_fixup<SFIX>(a.F, a.fixbuf + (size_t)t * SFIX, n, s_scratch[wave], (u64d *)(a.Sent + st), E, &lead);
+        if (lane == l) {
+            r0.z = n_out;
+            r0.w = n_out > 0 ? lead : INT_MAX;
+        }
+        holes += (u64d)(E - n_out);
+        emptied += (n_out == 0 && E > 0);
+        merged += n;
+    }
+    if (mine && nfix >= 0) {
+        const int t = t0 + lane;
+        a.Sstart[t] = (i64d)(((u64d)(unsigned)r0.y << 32) | (unsigned)r0.x);
+        a.Slen[t] = r0.z;
+        a.Slead[t] = r0.w;
+        a.Sorig[t] = a.rinfo[t].w;
+    }
+    if (lane == 0 && merged) {
+        atomicAdd(&ctr_shard(a.ctr)->nnz_out, (u64d)0 - holes); // (mod 2^64: the fused kernels counted the stream lengths)
+        if (emptied) atomicAdd(&ctr_shard(a.ctr)->nonempty_out, -emptied);
+        atomicAdd(&ctr_shard(a.ctr)->stream_fix, merged);
+    }
 }
 
 // the rows the general path took for the fused step, back under their slots (their entries lie behind those of the fused rows)
