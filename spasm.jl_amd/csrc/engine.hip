@@ -270,7 +270,7 @@ struct Round {
     i64 s_capacity = 0;      // entries S.ent can hold (sum of bounds at the time it was sized)
     i64 s_ent_base = 0;      // where the rows of run_scatter start in S.ent (behind the rows of the fused step, when it left any to the general path)
     // ---- the fused Schur step (fused.hpp): plan + stream of a row in one kernel, S written compactly from one cursor
-    bool use_fused = true;   // SPASM_AMD_FUSED=0: k_wplan + k_bin + the streaming classes instead
+    bool use_fused = false;  // SPASM_AMD_FUSED=1: on.  Off by default: as measured in round 4 it does not beat k_wplan + k_bin + the streaming classes
     DevBuf<int4> rinfo;      // per row slot: {start, length, originating row}
     DevBuf<unsigned> fz_work;
     DevBuf<u64d> fz_cursor;
@@ -278,7 +278,8 @@ struct Round {
     DevBuf<RoundCounters> fz_ctr; // statistics of the fused kernels (the general path clears its own when it runs behind them)
     RoundCounters hfz;       // .. on the host
     bool last_fused = false; // the last Schur step went through run_fused
-    DevBuf<int> fz_long_list, fz_rej_list, fz_rej_rows;
+    DevBuf<int> fz_long_list, fz_gen_list, fz_rej_list, fz_rej_rows, fz_flag, fz_pos;
+    Scanner fz_scan;         // (its own scratch: the general path scans on another stream meanwhile)
     DevBuf<int4> fz_rec;     // per row slot: the two records of the fused kernels
     DevBuf<FusedRare> fz_rare;
     const int *fz_rare_lists[2] = {nullptr, nullptr}; // the list buffers fz_rare names (they may be reallocated for a larger round)
@@ -1515,15 +1516,32 @@ struct Round {
         return use_fused && use_w && !force_lists && !want_idx && m < (1 << 24) && (u64d)(wbase + wcap + 64) * sizeof(int2) < 0xffffffffull &&
                (u64d)m * sizeof(int4) < 0xf0000000ull;
     }
-    static constexpr int FZ_LOGT = 11, FZ_WPB = 4;
+    static constexpr int FZ_LOGT = 11, FZ_WPB = 5;
     // capacity of S the fused step wants for an estimated `entries` of Schur rows: every wave may leave a block unfinished
     i64 fused_capacity(i64 entries) const { return entries + entries / 50 + (i64)num_cu * 16 * (i64)FZ_SBLK + 64; }
-    void run_fused(const DevMat &M, const int *rows, int nrows, i64 scap)
+    // The step: (1) every row is classified (k_fused_classify: the fused kernel's, or the general path's); (2) the fused kernel
+    // takes its list on the round's stream while (3) the general path -- the plan along W / the multiplier lists, the hash-table
+    // and streaming classes -- takes the other list on a stream of its own, its Schur rows behind `scap` in S.ent; (4) the finish
+    // kernel merges the duplicates of the fused rows and writes the row arrays, the general rows are put under their slots.
+    // known = false: the list sizes are read back after (1) (one host synchronisation) and the general path sizes its pools as it
+    // goes (more of them, on its own stream: the fused kernel runs meanwhile); S.ent grows when the general rows need more than the
+    // caller gave.  known = true (a plan that has run the step before): no host synchronisation at all.
+    // Returns false when the round is not one for the fused kernel (it would take less than half of the rows): nothing was done.
+    int fz_nfused = 0, fz_ngeneral = 0;
+    int fz_nleft = 0;        // known = true: rows the fused kernel takes up and leaves (too many duplicate columns), as an earlier run of the step saw
+    i64 fb_pool_left = 1 << 16;
+    i64 fz_general_bound = 0;
+    hipStream_t fb_stream = nullptr;
+    hipEvent_t ev_fb_fork = nullptr, ev_fb_join = nullptr;
+    DevBuf<int2> fb_fixbuf;
+    DevBuf<int> fb_fixcnt;
+    bool run_fused(const DevMat &M, const int *rows, int nrows, i64 scap, bool known)
     {
         S.n = nrows;
         S.m = m;
         nlaunch = 0;
         fb_ran = false;
+        left_ran = false;
         rinfo.ensure((size_t)nrows + 1);
         S.start.ensure((size_t)nrows + 1);
         S.len.ensure((size_t)nrows + 1);
@@ -1531,25 +1549,18 @@ struct Round {
         S.orig.ensure((size_t)nrows + 1);
         fixbuf.ensure(((size_t)nrows + 1) * SFIX);
         fz_rec.ensure(2 * ((size_t)nrows + 1));
-        fz_long_list.ensure((size_t)nrows + 1);
+        fz_long_list.ensure((size_t)nrows + 1); // (the fused kernel's list)
+        fz_gen_list.ensure((size_t)nrows + 1);
+        fz_flag.ensure((size_t)nrows + 2);
+        fz_pos.ensure((size_t)nrows + 2);
         fz_rej_list.ensure((size_t)nrows + 1);
         fz_work.ensure((size_t)2 * FZ_NWORK * FZ_WSTRIDE);
         fz_cursor.ensure(2);
         fz_counts.ensure(4);
-        if (!fz_rare.p) {
+        if (!fz_rare.p || fz_rare_lists[0] != fz_long_list.p || fz_rare_lists[1] != fz_rej_list.p) {
             fz_rare.ensure(1);
             FusedRare h;
-            h.long_list = (fz_gint *)fz_long_list.p;
-            h.long_count = (fz_gint *)fz_counts.p;
-            h.rej_list = (fz_gint *)fz_rej_list.p;
-            h.rej_count = (fz_gint *)(fz_counts.p + 1);
-            HIPCHK(hipMemcpyAsync(fz_rare.p, &h, sizeof h, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            fz_rare_lists[0] = fz_long_list.p;
-            fz_rare_lists[1] = fz_rej_list.p;
-        } else if (fz_rare_lists[0] != fz_long_list.p || fz_rare_lists[1] != fz_rej_list.p) {
-            FusedRare h;
-            h.long_list = (fz_gint *)fz_long_list.p;
+            h.long_list = nullptr; // (no launch with larger tables: rows beyond the fused kernel's go to the general path)
             h.long_count = (fz_gint *)fz_counts.p;
             h.rej_list = (fz_gint *)fz_rej_list.p;
             h.rej_count = (fz_gint *)(fz_counts.p + 1);
@@ -1561,7 +1572,11 @@ struct Round {
         fz_ctr.ensure(NCTR);
         ctr.ensure(NCTR);
         class_count.ensure(NCLASS);
-        last_fused = true;
+        if (!fb_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&fb_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ev_fb_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_fb_join, hipEventDisableTiming));
+        }
         if (nrows > 0) {
             hipLaunchKernelGGL(k_gather_info, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, M.orig.p, rinfo.p);
             HIPCHK(hipGetLastError());
@@ -1574,12 +1589,47 @@ struct Round {
                                nctr_words, fz_rec.p);
             HIPCHK(hipGetLastError());
         }
-        if (class_timing) HIPCHK(hipEventRecord(ev_fz[0], stream));
         if (nrows > 0) {
+            ClassifyArgs c;
+            c.nrows = nrows;
+            c.rinfo = rinfo.p;
+            c.ent = M.ent.p;
+            c.pbits = pbits.p;
+            c.wcol = wcol.p;
+            c.flag = fz_flag.p;
+            c.general_bound = fz_cursor.p + 1;
+            c.cap = fz_cap(FZ_LOGT);
+            c.free_cols = free_cols;
+            hipLaunchKernelGGL(k_fused_classify, dim3(cdiv(((i64)nrows + 1) * 16, 256)), dim3(256), 0, stream, c);
+            HIPCHK(hipGetLastError());
+            // (lists in slot order: the general path's pools are cut into regions by workgroup, and a plan sizes them on one run for all)
+            fz_scan.exclusive(fz_flag.p, fz_pos.p, (size_t)nrows + 1, stream);
+            hipLaunchKernelGGL(k_fused_lists, dim3(cdiv((i64)nrows + 1, 256)), dim3(256), 0, stream, nrows, fz_flag.p, fz_pos.p, fz_long_list.p, fz_gen_list.p, fz_counts.p);
+            HIPCHK(hipGetLastError());
+        }
+        if (!ev_classified) HIPCHK(hipEventCreateWithFlags(&ev_classified, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_classified, stream));
+        if (!known) {
+            int cnt[4] = {0, 0, 0, 0};
+            u64d cur[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(cnt, fz_counts.p, sizeof cnt, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(cur, fz_cursor.p, sizeof cur, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            fz_nfused = cnt[2];
+            fz_ngeneral = cnt[3];
+            fz_general_bound = (i64)cur[1];
+            if (fz_nfused < nrows / 2) return false; // (rows of hundreds of entries, later rounds: the general path is the path)
+            // room for the general rows behind the fused ones, before anything runs (S.ent must not move under a running kernel)
+            S.ent.ensure((size_t)(scap + fz_general_bound + fz_general_bound / 8 + 16 * (i64)fz_ngeneral + 1024));
+        }
+        last_fused = true;
+        fz_scap = scap;
+        if (class_timing) HIPCHK(hipEventRecord(ev_fz[0], stream));
+        if (fz_nfused > 0) {
             FusedArgs a;
             a.nrows = nrows;
-            a.slots = nullptr;
-            a.slot_count = nullptr;
+            a.slots = fz_long_list.p;
+            a.slot_count = fz_counts.p + 2;
             a.rinfo = rinfo.p;
             a.ent = M.ent.p;
             a.pbits = pbits.p;
@@ -1591,7 +1641,13 @@ struct Round {
             a.rec = fz_rec.p;
             a.fixbuf = fixbuf.p;
             a.rare = fz_rare.p;
-            a.long_bound = 0; // (rows beyond the tables of the wave kernel: the general path)
+            a.long_bound = 0;
+            a.stamps = nullptr;
+#ifdef SPASM_STAMPS
+            stamps.ensure(NCLASS * 2 * NSTAMP);
+            HIPCHK(hipMemsetAsync(stamps.p, 0, NCLASS * 2 * NSTAMP * sizeof(u64d), stream));
+            a.stamps = stamps.p;
+#endif
             a.buf_bytes = (unsigned)std::min<u64d>((u64d)UPN.n * sizeof(int2), 0xffffffffull);
             a.pbits_bytes = (unsigned)std::min<u64d>((u64d)pbits.n * sizeof(unsigned), 0xffffffffull);
             a.wcol_bytes = (unsigned)std::min<u64d>((u64d)wcol.n * sizeof(int4), 0xffffffffull);
@@ -1608,18 +1664,18 @@ struct Round {
             if (!pc) {
                 int nb = 0;
                 if (F.small) {
-                    HIPCHK(hipFuncSetAttribute((const void *)k_schur_fused<FZ_LOGT, FZ_WPB, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_schur_fused<FZ_LOGT, FZ_WPB, true, false>, FZ_WPB * 64, lds));
+                    HIPCHK(hipFuncSetAttribute((const void *)k_schur_fused<FZ_LOGT, FZ_WPB, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_schur_fused<FZ_LOGT, FZ_WPB, true, true>, FZ_WPB * 64, lds));
                 } else {
-                    HIPCHK(hipFuncSetAttribute((const void *)k_schur_fused<FZ_LOGT, FZ_WPB, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_schur_fused<FZ_LOGT, FZ_WPB, false, false>, FZ_WPB * 64, lds));
+                    HIPCHK(hipFuncSetAttribute((const void *)k_schur_fused<FZ_LOGT, FZ_WPB, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_schur_fused<FZ_LOGT, FZ_WPB, false, true>, FZ_WPB * 64, lds));
                 }
                 pc = std::max(nb, 1);
             }
             // every wave takes blocks of FZ_B rows until none is left: as many workgroups as are resident, fewer for few rows
-            const int grid = std::max(1, std::min(cdiv(cdiv(nrows, FZ_B), FZ_WPB), num_cu * pc));
-            if (F.small) hipLaunchKernelGGL((k_schur_fused<FZ_LOGT, FZ_WPB, true, false>), dim3(grid), dim3(FZ_WPB * 64), lds, stream, a);
-            else hipLaunchKernelGGL((k_schur_fused<FZ_LOGT, FZ_WPB, false, false>), dim3(grid), dim3(FZ_WPB * 64), lds, stream, a);
+            const int grid = std::max(1, std::min(cdiv(cdiv(fz_nfused, FZ_B), FZ_WPB), num_cu * pc));
+            if (F.small) hipLaunchKernelGGL((k_schur_fused<FZ_LOGT, FZ_WPB, true, true>), dim3(grid), dim3(FZ_WPB * 64), lds, stream, a);
+            else hipLaunchKernelGGL((k_schur_fused<FZ_LOGT, FZ_WPB, false, true>), dim3(grid), dim3(FZ_WPB * 64), lds, stream, a);
             HIPCHK(hipGetLastError());
         }
         if (class_timing) HIPCHK(hipEventRecord(ev_fz[1], stream));
@@ -1640,6 +1696,52 @@ struct Round {
             HIPCHK(hipGetLastError());
         }
         if (class_timing) HIPCHK(hipEventRecord(ev_fz[2], stream));
+        // the general path beside them (its launches were not queued before the fused kernel's: the host may have to wait for its
+        // sizes, and the fused kernel runs meanwhile)
+        if (fz_ngeneral > 0) {
+            // (it only needs the lists: it waits for the classification, not for the launches queued behind it)
+            hipStream_t keep = stream;
+            HIPCHK(hipStreamWaitEvent(fb_stream, ev_classified, 0));
+            stream = fb_stream;
+            try {
+                general_rows(M, rows, fz_gen_list.p, fz_ngeneral, scap, !known);
+            } catch (...) {
+                stream = keep;
+                throw;
+            }
+            stream = keep;
+            HIPCHK(hipEventRecord(ev_fb_join, fb_stream));
+            HIPCHK(hipStreamWaitEvent(stream, ev_fb_join, 0));
+            hipLaunchKernelGGL(k_merge_rej, dim3(cdiv(fz_ngeneral, 256)), dim3(256), 0, stream, fz_ngeneral, fz_gen_list.p, fb_start.p, fb_len.p, fb_lead.p, fb_orig.p,
+                               (i64d)fb_base, S.start.p, S.len.p, S.lead.p, S.orig.p);
+            HIPCHK(hipGetLastError());
+            fb_ran = true;
+        }
+        if (known && fz_nleft > 0) {
+            // the rows the fused kernel leaves (the same every time, in any order): through the general path behind everything else
+            const i64 base = fz_ngeneral > 0 ? fb_base + fb_tot + 16 : scap;
+            const i64 keep_pool = fb_pool, keep_tot = fb_tot, keep_base = fb_base;
+            fb_pool = fb_pool_left;
+            ctr_left.ensure(NCTR);
+            class_count_left.ensure(NCLASS);
+            std::swap(ctr, ctr_left); std::swap(class_count, class_count_left);
+            try {
+                general_rows(M, rows, fz_rej_list.p, fz_nleft, base, false);
+            } catch (...) {
+                std::swap(ctr, ctr_left); std::swap(class_count, class_count_left);
+                fb_pool = keep_pool;
+                throw;
+            }
+            std::swap(ctr, ctr_left); std::swap(class_count, class_count_left);
+            fb_pool = keep_pool;
+            left_ran = true;
+            hipLaunchKernelGGL(k_merge_rej, dim3(cdiv(fz_nleft, 256)), dim3(256), 0, stream, fz_nleft, fz_rej_list.p, fb_start.p, fb_len.p, fb_lead.p, fb_orig.p, (i64d)fb_base,
+                               S.start.p, S.len.p, S.lead.p, S.orig.p);
+            HIPCHK(hipGetLastError());
+            fb_tot = keep_tot;
+            fb_base = keep_base;
+        }
+        return true;
     }
 
     // what the fused kernels did (synchronises): their statistics, rows left to the general path, space of S in use
@@ -1652,90 +1754,147 @@ struct Round {
         HIPCHK(hipMemcpyAsync(&cur, fz_cursor.p, sizeof cur, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         fz_nlong = cnt[0];
-        fz_nrej = cnt[1];
+        fz_nrej = cnt[1]; // rows the fused kernel took up and had to leave (too many duplicate columns, no room in S)
         fz_used = (i64)cur;
-        fz_rows = S.n - fz_nrej;
+        fz_rows = fz_nfused - fz_nrej;
         hctr = hfz;
         memset(hclass_count, 0, sizeof hclass_count);
+#ifdef SPASM_STAMPS
+        {
+            std::vector<u64d> h(2 * NSTAMP);
+            HIPCHK(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(u64d), hipMemcpyDeviceToHost));
+            static const char *names[6] = {"stages", "plan", "own", "groups", "rowend", "rotate"};
+            const double waves = (double)h[NSTAMP], nr = (double)std::max(fz_rows, 1);
+            fprintf(stderr, "[stamps] fused: rows %d waves %.0f: cycles per row:", fz_rows, waves);
+            for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nr);
+            fprintf(stderr, "\n");
+        }
+#endif
     }
-    // the statistics of the whole step once the general path has run behind the fused kernels (synchronises)
-    void fetch_fused_and_fallback()
+    // the statistics of a pass of the general path (its counters `from`, its class counts) on top of what hctr holds (synchronises)
+    void add_general(const RoundCounters *from, const int *class_count_dev)
     {
-        hfz = read_counters(fz_ctr.p);
-        fetch_counters(); // the general path's (throws on an exhausted pool / table)
-        hctr.nonempty_out += hfz.nonempty_out;
-        hctr.nnz_out += hfz.nnz_out;
-        hctr.stream_redo += hfz.stream_redo;
-        hctr.stream_fix += hfz.stream_fix;
-        hctr.class_ent[NCLASS - 1] = hfz.class_ent[NCLASS - 1];
-        hctr.class_seg[NCLASS - 1] = hfz.class_seg[NCLASS - 1];
+        const RoundCounters g = read_counters(from);
+        int cc[NCLASS];
+        HIPCHK(hipMemcpyAsync(cc, class_count_dev, NCLASS * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (g.lpool_overflow) throw EngineError("multiplier pool exhausted");
+        if (g.scatter_overflow) throw EngineError("a hash table of the scatter kernel filled up (internal bound violated)");
+        hctr.applications += g.applications;
+        hctr.nnz_reduced += g.nnz_reduced;
+        hctr.segments += g.segments;
+        hctr.nonempty_out += g.nonempty_out;
+        hctr.nnz_out += g.nnz_out;
+        hctr.stream_redo += g.stream_redo;
+        hctr.stream_fix += g.stream_fix;
+        for (int c = 0; c < NCLASS - 1; c++) { hctr.class_ent[c] += g.class_ent[c]; hctr.class_seg[c] += g.class_seg[c]; }
+        for (int c = 0; c < NCLASS; c++) hclass_count[c] += cc[c];
     }
     // after any Schur step (synchronises)
-    bool fb_ran = false;
+    bool fb_ran = false, left_ran = false;
+    DevBuf<RoundCounters> ctr_left;  // the counters / class counts of the pass over the rows the fused kernel left
+    DevBuf<int> class_count_left;
     void fetch_step()
     {
         if (!last_fused) { fetch_counters(); return; }
-        if (fb_ran) { const int nr = fz_nrej; fetch_fused(); fz_nrej = nr; fz_rows = S.n - nr; fetch_fused_and_fallback(); }
-        else fetch_fused();
+        fetch_fused();
+        if (fb_ran) add_general(ctr.p, class_count.p);
+        if (left_ran) add_general(ctr_left.p, class_count_left.p);
     }
 
-    // the rows the fused step left (fz_nrej of them, known from fetch_fused or from an earlier run of the same step) through the
-    // general path: the plan along W / the multiplier lists, the hash-table and streaming classes; their Schur rows go behind
-    // those of the fused rows in S.ent (from `base` on) and under their own slots in S.  sync = false: pools and S are known to be
-    // large enough (a plan that has run this before), no host synchronisation.
-    i64 fb_pool = 1 << 16;
-    void fused_fallback(const DevMat &M, const int *rows, i64 base, bool sync)
+    // `n` row slots (list `slots`) through the general path on the current `stream`: the plan along W / the multiplier lists, the
+    // hash-table and streaming classes; their Schur rows go into S.ent from `base` on and, for now, under the general path's own
+    // slot numbers 0 .. n-1 in fb_start / fb_len / fb_lead / fb_orig (k_merge_rej puts them under their slots).  sync = false: pools
+    // and S are known to be large enough (a plan that has run this before), no host synchronisation.
+    i64 fb_pool = 1 << 16, fb_base = 0, fb_tot = 0, fb_left_tot = 0;
+    i64 fz_scap = 0;
+    hipEvent_t ev_classified = nullptr;
+    void general_rows(const DevMat &M, const int *rows, const int *slots, int n, i64 base, bool sync)
     {
-        const int nrej = fz_nrej;
-        fb_ran = false;
-        if (nrej <= 0) return;
-        fz_rej_rows.ensure((size_t)nrej + 1);
-        hipLaunchKernelGGL(k_rej_rows, dim3(cdiv(nrej, 256)), dim3(256), 0, stream, nrej, fz_rej_list.p, rows, fz_rej_rows.p);
+        fz_rej_rows.ensure((size_t)n + 1);
+        hipLaunchKernelGGL(k_rej_rows, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, slots, rows, fz_rej_rows.p);
         HIPCHK(hipGetLastError());
-        // the general path writes S.start / len / lead / orig by ITS slots 0 .. nrej-1: give it arrays of its own, merge afterwards
-        auto swap_rows = [&]() { std::swap(S.start, fb_start); std::swap(S.len, fb_len); std::swap(S.lead, fb_lead); std::swap(S.orig, fb_orig); };
+        // the general path writes S.start / len / lead / orig, fixbuf / fixcnt by ITS slots 0 .. n-1: arrays of its own
+        auto swap_rows = [&]() {
+            std::swap(S.start, fb_start); std::swap(S.len, fb_len); std::swap(S.lead, fb_lead); std::swap(S.orig, fb_orig);
+            std::swap(fixbuf, fb_fixbuf); std::swap(fixcnt, fb_fixcnt);
+        };
         swap_rows();
         const int keep_n = S.n;
-        const bool qk = quiet_known;
+        const bool qk = quiet_known, lf = last_fused;
         quiet_known = false;
         gathered_n = -1;
         base = (base + 15) & ~(i64)15;
         s_ent_base = base;
+        fb_base = base;
         try {
             if (sync) {
-                const i64 tot = solve_phase(M, fz_rej_rows.p, nullptr, nrej, std::max<i64>(fb_pool, 64 * (i64)nrej));
+                const i64 tot = solve_phase(M, fz_rej_rows.p, nullptr, n, std::max<i64>(fb_pool, 64 * (i64)n));
                 if (tot < 0) throw EngineError("the rows left to the general path do not fit the device memory");
                 fb_pool = std::max<i64>(fb_pool, (i64)(pool_used() * 5 / 4) + 1024);
+                fb_tot = tot;
+                if (getenv("SPASM_AMD_FZDEBUG")) fprintf(stderr, "[fused] general rows %d: pool %lld records (used %llu, regions %d), %lld entries of S from %lld, S holds %zu\n", n, (long long)fb_pool, (unsigned long long)pool_used(), npool_active, (long long)tot, (long long)base, S.ent.n);
                 if ((i64)S.ent.n < base + tot + 1) {
-                    // (rare: the estimate the fused step was sized with was short) a larger S, the fused rows copied over
+                    // (rare: the classification could not work out the streams of all rows) a larger S, once nothing writes the old one
+                    HIPCHK(hipDeviceSynchronize());
                     DevBuf<int2> bigger;
                     bigger.alloc((size_t)(base + tot + tot / 8 + 1));
-                    if (base > 0) HIPCHK(hipMemcpyAsync(bigger.p, S.ent.p, (size_t)std::min<i64>(base, (i64)S.ent.n) * sizeof(int2), hipMemcpyDeviceToDevice, stream));
-                    HIPCHK(hipStreamSynchronize(stream));
-                    S.ent = std::move(bigger);
+                    if (base > 0) HIPCHK(hipMemcpy(bigger.p, S.ent.p, (size_t)std::min<i64>(base, (i64)S.ent.n) * sizeof(int2), hipMemcpyDeviceToDevice));
+                    S.ent = std::move(bigger); // (the rows already written keep their places: S.start holds offsets)
                 }
             } else {
-                alloc_solve(nrej, fb_pool);
-                run_solve(M, fz_rej_rows.p, nullptr, nrej);
-                run_bounds(nrej);
+                alloc_solve(n, fb_pool);
+                run_solve(M, fz_rej_rows.p, nullptr, n);
+                run_bounds(n);
+                if (getenv("SPASM_AMD_FZDEBUG")) { const RoundCounters c = read_counters(); fprintf(stderr, "[fused] general rows %d (no sync): pool %lld, used %llu, regions %d, region cap %llu, overflow %d, rejects %d\n", n, (long long)fb_pool, (unsigned long long)pool_used(), npool_active, (unsigned long long)region_cap, c.lpool_overflow, c.wplan_reject); }
             }
-            run_scatter(M, fz_rej_rows.p, nrej);
+            run_scatter(M, fz_rej_rows.p, n);
         } catch (...) {
             s_ent_base = 0;
             quiet_known = qk;
+            last_fused = lf;
             swap_rows();
             throw;
         }
         s_ent_base = 0;
         quiet_known = qk;
+        last_fused = lf;
         gathered_n = -1;
         swap_rows();
         S.n = keep_n;
-        last_fused = true;
-        fb_ran = true;
-        hipLaunchKernelGGL(k_merge_rej, dim3(cdiv(nrej, 256)), dim3(256), 0, stream, nrej, fz_rej_list.p, fb_start.p, fb_len.p, fb_lead.p, fb_orig.p, (i64d)base,
+    }
+
+    // rows the fused kernel took up and had to leave (fetch_fused counted them: too many duplicate columns for its lists, or no room
+    // left in S): through the general path, behind everything else in S.ent.  Synchronises; their statistics are added to hctr.
+    void fused_leftovers(const DevMat &M, const int *rows)
+    {
+        if (fz_nrej <= 0) return;
+        const i64 base = fb_ran ? fb_base + fb_tot + 16 : fz_scap;
+        HIPCHK(hipStreamSynchronize(stream));
+        const i64 keep_pool = fb_pool, keep_tot = fb_tot, keep_base = fb_base;
+        fb_pool = 1 << 16;
+        ctr_left.ensure(NCTR);
+        class_count_left.ensure(NCLASS);
+        std::swap(ctr, ctr_left); std::swap(class_count, class_count_left);
+        try {
+            general_rows(M, rows, fz_rej_list.p, fz_nrej, base, true);
+        } catch (...) {
+            std::swap(ctr, ctr_left); std::swap(class_count, class_count_left);
+            fb_pool = keep_pool;
+            throw;
+        }
+        std::swap(ctr, ctr_left); std::swap(class_count, class_count_left);
+        fb_pool_left = 4 * fb_pool; // (a plan runs these rows again, in another order: room to spare)
+        fb_left_tot = fb_tot;
+        fb_pool = keep_pool;
+        hipLaunchKernelGGL(k_merge_rej, dim3(cdiv(fz_nrej, 256)), dim3(256), 0, stream, fz_nrej, fz_rej_list.p, fb_start.p, fb_len.p, fb_lead.p, fb_orig.p, (i64d)fb_base,
                            S.start.p, S.len.p, S.lead.p, S.orig.p);
         HIPCHK(hipGetLastError());
+        fb_tot = keep_tot;
+        fb_base = keep_base;
+        left_ran = true;
+        add_general(ctr_left.p, class_count_left.p);
+        last_fused = true;
     }
 
     void fetch_counters()
@@ -3239,15 +3398,12 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
                 R->S.ent.ensure((size_t)scap + 1);
                 HIPCHK(hipEventRecord(R->ev[1], stream));
                 HIPCHK(hipEventRecord(R->ev[2], stream));
-                R->run_fused(*cur, R->np_rows.p + off, cnt, scap);
-                HIPCHK(hipEventRecord(R->ev[3], stream));
-                R->fetch_fused();
-                if (R->fz_nrej > 0) {
-                    R->fused_fallback(*cur, R->np_rows.p + off, scap, true);
+                if (R->run_fused(*cur, R->np_rows.p + off, cnt, scap, false)) {
                     HIPCHK(hipEventRecord(R->ev[3], stream));
-                    R->fetch_fused_and_fallback();
+                    R->fetch_step();
+                    R->fused_leftovers(*cur, R->np_rows.p + off);
+                    goto schur_done;
                 }
-                goto schur_done;
             }
             {
             const i64 tot = R->solve_phase(*cur, R->np_rows.p + off, nullptr, cnt, std::max<i64>((i64)(rec_per_row * (double)cnt), 1 << 16), max_pool);
@@ -4078,16 +4234,23 @@ void plan_dry_run(spasm_amd_schur_plan *P, i64 pool_guess)
     }
     R.S.ent.ensure((size_t)std::max(tot, tot2) + 1);
     if (R.fused_ok()) {
-        // the fused step once, with room to spare: how much of S it needs, which rows it leaves to the general path (whose
-        // pools are sized by running it for them once)
+        // the fused step once, with room to spare: which rows it takes, what the general path needs for the others (its pools are
+        // sized by running it for them), whether every row the fused kernel takes up also comes out of it
         P->fused_scap = R.fused_capacity(std::max(tot, tot2) + 16 * (i64)R.nnp);
         R.S.ent.ensure((size_t)P->fused_scap + 1);
-        R.run_fused(P->A, R.np_rows.p, R.nnp, P->fused_scap);
-        R.fetch_fused();
-        P->fused_nrej = R.fz_nrej;
-        if (R.fz_nrej > 0) {
-            R.fused_fallback(P->A, R.np_rows.p, P->fused_scap, true);
-            R.fetch_fused_and_fallback();
+        if (!R.run_fused(P->A, R.np_rows.p, R.nnp, P->fused_scap, false)) P->fused_scap = 0;
+        else {
+            R.fetch_step();
+            R.fz_nleft = R.fz_nrej;
+            R.fused_leftovers(P->A, R.np_rows.p);
+            // (S must hold them too, every time)
+            const i64 need = (R.fz_ngeneral > 0 ? R.fb_base + R.fb_tot + 16 : P->fused_scap) + 2 * R.fb_left_tot + 1024;
+            if (R.fz_nleft > 0 && (i64)R.S.ent.n < need) R.S.ent.ensure((size_t)need);
+        }
+        if (P->fused_scap == 0) {
+            // (not a round for the fused kernel: the general path for all rows, its pools sized again -- the attempt left them sized for few)
+            R.last_fused = false;
+            (void)R.solve_phase(P->A, R.np_rows.p, nullptr, R.nnp, pool_guess);
         }
     }
 }
@@ -4349,9 +4512,7 @@ void plan_run(spasm_amd_schur_plan *P, hipStream_t s)
     if (R.fused_ok() && P->fused_scap > 0) {
         // plan + stream of every row in one kernel (fused.hpp); the rows it leaves go through the general path behind it
         HIPCHK(hipEventRecord(R.ev[2], s));
-        R.run_fused(P->A, R.np_rows.p, R.nnp, P->fused_scap);
-        R.fz_nrej = P->fused_nrej;
-        if (P->fused_nrej > 0) R.fused_fallback(P->A, R.np_rows.p, P->fused_scap, false);
+        (void)R.run_fused(P->A, R.np_rows.p, R.nnp, P->fused_scap, true);
         HIPCHK(hipEventRecord(R.ev[3], s));
     } else {
         R.run_solve(P->A, R.np_rows.p, nullptr, R.nnp);

@@ -64,6 +64,7 @@ struct FusedArgs {
     int free_cols;
     int long_bound;            // rows with a stream beyond this launch's tables but within this go on rare->long_list (0: no such list)
     unsigned buf_bytes, pbits_bytes, wcol_bytes; // sizes of buf / pbits / wcol (the kernel reaches them through 32-bit offsets)
+    u64d *stamps;              // diagnostic build only: NSTAMP cycle sums + the wave count
     ZpField F;
 };
 
@@ -271,6 +272,27 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
         return (i64d)r;
     };
 
+    // ---- rows this launch does not take: their slots are collected 64 at a time (a lane each) and go on their list with ONE
+    // atomic per 64 -- a round leaves up to a third of its rows, and that many returning atomics on one word would take
+    // milliseconds (11 ns each, one after the other)
+    int rejq = 0, longq = 0, nrejq = 0, nlongq = 0;
+    auto flush = [&](int &q, int &n, fz_gint *list, fz_gint *count) {
+        if (n == 0) return;
+        int at = 0;
+        if (lane == 0) at = __hip_atomic_fetch_add(count, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        at = fz_sgpr(at);
+        if (lane < n) list[at + lane] = q;
+        n = 0;
+    };
+    auto push_rej = [&](int t) {
+        fz_set_lane(rejq, t, nrejq);
+        if (++nrejq == 64) flush(rejq, nrejq, a.rare->rej_list, a.rare->rej_count);
+    };
+    auto push_long = [&](int t) {
+        fz_set_lane(longq, t, nlongq);
+        if (++nlongq == 64) flush(longq, nlongq, a.rare->long_list, a.rare->long_count);
+    };
+
     // ---- the chunk table (a lane per chunk): byte offset of the chunk in buf; byte offset of its first entry in the row's stream;
     // (stream position + 1) << 8 | entries (0: an empty chunk of the padding); the multiplier of its run
     int T_ld = 0, T_st = 0, T_pn = 0, T_mul = 0;
@@ -310,10 +332,8 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
                 if (sb < 0) rej = true;
             }
             if (rej || tolong) {
-                if (lane == 0) {
-                    if (tolong) fz_list_append(a.rare->long_list, a.rare->long_count, t);
-                    else fz_list_append(a.rare->rej_list, a.rare->rej_count, t);
-                }
+                if (tolong) push_long(t);
+                else push_rej(t);
                 ok = false;
             } else {
                 bound = (int)b64;
@@ -400,6 +420,10 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
     int c_rows = 0, c_redo = 0;
     int s_blk0 = 0; // first row number of the current block
 
+#ifdef SPASM_STAMPS
+    u64d st_sum[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64d st_last = stamp_now();
+#endif
     // (the first five passes only fill the stages: row 0 is the current row at s = 0)
     for (int s = LIST ? -6 : -5; s < s_limit; s++) {
         // ---- blocks: when a block starts the one after the next is asked for (the answer is taken at the end of this pass)
@@ -436,9 +460,11 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
             mP2 = __ballot(p2);
             WC2 = __builtin_amdgcn_raw_buffer_load_b64(r_wc, p2 ? (E2.x << 4) : 0, 4, 0); // {length, offset} of the column's record
         }
+        STAMP(0); // blocks, stage loads
         // ---- the plan of row s + 1; its chunks go behind those of the current row
         P1 = make_plan(T1, L1, E1, mP1, WC1, P0.cb + P0.cp);
 
+        STAMP(1); // plan
         // ---- the current row
         const bool live = P0.t >= 0;
         FzTab tb;
@@ -467,6 +493,7 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
                 stream_report(stream_outcome(ll[0]), oo[0], true, E0.x, E0.y, pos + 1, misc, fix, FCAP, lst);
             }
         }
+        STAMP(2); // own entries
         // the runs, a double group at a time (a row without chunks still takes one: it carries the requests of the next row)
         {
             auto do_group = [&](const fz_v2i (&ring)[Q], int c0) {
@@ -524,6 +551,7 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
             }
         }
 
+        STAMP(3); // groups + requests
         // ---- end of the row: leftmost column, losers of all tables, duplicates
         if (live) {
             const int lead_out = wave_min_i32(mylead);
@@ -549,7 +577,7 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
             redo = redo || nfix > FCAP;
             if (redo) {
                 // too many duplicate columns for the lists: the general path takes the row (its space in S stays unused)
-                if (lane == 0) fz_list_append(a.rare->rej_list, a.rare->rej_count, t_cur);
+                push_rej(t_cur);
                 c_redo += 1;
             } else {
                 if (lane < nfix) a.fixbuf[(size_t)t_cur * SFIX + lane] = fix[lane];
@@ -570,6 +598,7 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
             __builtin_amdgcn_wave_barrier();
         }
 
+        STAMP(4); // end of the row
         // ---- the block asked for at the top of this pass
         if (asking) {
             g_new = resolve(asked);
@@ -587,7 +616,16 @@ __global__ __launch_bounds__(WPB * 64) void k_schur_fused(FusedArgs a)
         PB2 = PB3;
         WC1 = WC2;
         mP1 = mP2;
+        STAMP(5); // block answer, rotation (waits for the stage loads)
     }
+#ifdef SPASM_STAMPS
+    if (lane == 0 && a.stamps) {
+        for (int i = 0; i < NSTAMP; i++) atomicAdd(&a.stamps[i], st_sum[i]);
+        atomicAdd(&a.stamps[NSTAMP], 1ull);
+    }
+#endif
+    flush(rejq, nrejq, a.rare->rej_list, a.rare->rej_count);
+    flush(longq, nlongq, a.rare->long_list, a.rare->long_count);
     if (lane == 0) {
         if (c_nnz) atomicAdd(&ctr_shard(a.ctr)->nnz_out, c_nnz);
         if (c_rows) atomicAdd(&ctr_shard(a.ctr)->nonempty_out, c_rows);
@@ -620,7 +658,7 @@ __global__ void k_fused_reset(int nrows, unsigned *__restrict__ work, int nwork_
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < nwork_words) work[t] = 0;
-    if (t == 0) *cursor = 0;
+    if (t == 0) { cursor[0] = 0; cursor[1] = 0; }
     if (t < ncounts) counts[t] = 0;
     if (t < nctr_words) ctr_words[t] = 0;
     if (t < nrows) rec[2 * (size_t)t + 1] = make_int4(-1, 0, 0, 0);
@@ -708,4 +746,75 @@ __global__ void k_rej_rows(int nrej, const int *__restrict__ rej, const int *__r
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nrej) out[i] = rows ? rows[rej[i]] : rej[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Which rows the fused kernel takes, decided before it starts: a team of 16 lanes reads a row's entries, their pivot bits and the
+// lengths of the rows of W they name -- the length of the row's stream and its chunks follow -- and the slot goes on the list of
+// the fused kernel or on the list of the general path.  With the lists known up front the two paths run side by side (the general
+// path's rows are few and long: behind the fused kernel they would be a tail of their own), and the fused kernel meets no row it
+// has to turn away.
+// ------------------------------------------------------------------------------------------------
+struct ClassifyArgs {
+    int nrows;
+    const int4 *rinfo;
+    const int2 *ent;
+    const unsigned *pbits;
+    const int4 *wcol;
+    int *flag;                 // out, per slot (+ one 0 behind the last): 1 = the fused kernel takes the row
+    u64d *general_bound;       // sum of the stream lengths of the general rows (those it could work out: rows of up to 64 entries)
+    int cap;                   // longest stream the fused kernel takes
+    int free_cols;
+};
+__global__ __launch_bounds__(256) void k_fused_classify(ClassifyArgs a)
+{
+    constexpr int TEAM = 16;
+    __shared__ u64d s_gb;
+    if (threadIdx.x == 0) s_gb = 0;
+    __syncthreads();
+    const int tl = threadIdx.x % TEAM;
+    const int t = (int)((blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
+    if (t < a.nrows) {
+        const int4 inf = a.rinfo[t];
+        const i64d st = (i64d)(((u64d)(unsigned)inf.y << 32) | (unsigned)inf.x);
+        const int ln = inf.z;
+        long long tot = 0;
+        int C = 0, nN = 0;
+        bool bad = ln > 64;
+        for (int k0 = 0; k0 < ln && !bad; k0 += TEAM) {
+            const int k = k0 + tl;
+            const bool valid = k < ln;
+            int2 e = make_int2(0, 1);
+            if (valid) e = a.ent[st + k];
+            const bool isP = valid && ((a.pbits[(unsigned)e.x >> 5] >> (e.x & 31)) & 1u);
+            int wl = 0;
+            if (isP) wl = a.wcol[e.x].y;
+            bad |= team_ballot<TEAM>((valid && e.y == 0) || wl < 0) != 0;
+            int s1, s2;
+            (void)team_incl_scan<TEAM>(max(wl, 0), s1);
+            (void)team_incl_scan<TEAM>((max(wl, 0) + 63) >> 6, s2);
+            tot += s1;
+            C += s2;
+            nN += __popcll(team_ballot<TEAM>(valid && !isP));
+        }
+        const long long bound = (long long)nN + tot;
+        const bool fused = !bad && bound <= (long long)a.cap && bound <= (long long)a.free_cols && C <= FZ_MAXC;
+        if (tl == 0) {
+            a.flag[t] = fused ? 1 : 0;
+            if (!fused) atomicAdd(&s_gb, (u64d)bound);
+        }
+    } else if (t == a.nrows && tl == 0) a.flag[t] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_gb) atomicAdd(a.general_bound, s_gb);
+}
+// the two lists, in slot order, from the flags and their exclusive prefix sums (pos[nrows] = rows of the fused kernel)
+__global__ void k_fused_lists(int nrows, const int *__restrict__ flag, const int *__restrict__ pos, int *__restrict__ fused_list, int *__restrict__ general_list,
+                              int *__restrict__ counts)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nrows) {
+        if (flag[t]) fused_list[pos[t]] = t;
+        else general_list[t - pos[t]] = t;
+    }
+    if (t == nrows) { counts[2] = pos[nrows]; counts[3] = nrows - pos[nrows]; }
 }
