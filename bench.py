@@ -3,9 +3,13 @@
 
 One "step" = one pass of the hot path over the synthetic matrix: the WHOLE Schur step of the round, as the reference's
 spasm_schur does it (src/SpaSM.jl:761-762, the per-row solve :694-713 is inside): W = -(I + U_PP)^-1 U_PN rebuilt from the
-round's pivot rows U level by level, the plan of every non-pivot row, the streaming scatter -- with the matrix, U and all
-work buffers already resident in HBM.  Nothing the step needs is cached from one step to the next except U itself (the
-output of the pivot search, spasm_pivots_extract_structural, which is not part of the metric).
+round's pivot rows U level by level (every launch of every level, as a round makes them: nothing is skipped because an earlier
+step found a list empty, no statistics are left out), the plan of every non-pivot row, the streaming scatter -- with the matrix,
+U and all work buffers already resident in HBM.  Carried from step to step, and said so: U itself and the levels of its pivot
+graph (the output of the pivot search and its bookkeeping, spasm_pivots_extract_structural: not part of the metric; `levels_ms`
+reports the levels on their own), the sizes of the work buffers, and the knowledge that no row of THIS round needs the
+multiplier-list fallbacks (four or five launches that would find their lists empty).  `echelonize_round0` is the same step timed
+inside a real spasm_echelonize of the same matrix, where nothing is carried.
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run).
 With N GPUs (one process per GPU) the non-pivot rows are dealt to the ranks (rank r: rows r, r + N, ...; BASELINE config 4,
 strong scaling: the matrix is fixed); every rank elects the same pivots and holds the same U, rows never move.  For N > 1 every rank uploads only its row block and the round's pivot rows are exchanged once in
@@ -226,7 +230,9 @@ def main():
             "round_ms": {"w_build": round(d["ms_wbuild"], 4), "plan": round(d["ms_solve"], 4), "scatter": round(d["ms_scatter"], 4)},
             "w": {"levels": d["w_levels"], "entries": d["w_entries"], "long_rows": d["w_long_rows"]},
             # once per round, outside the step: the levels of the pivot graph (part of the pivot bookkeeping) + sizing + first build
-            "levels_and_first_w_build_ms": round(d["ms_w"], 4),
+            # (wall times with their host synchronisations; the allocation of the build's buffers -- once per plan -- on its own)
+            "levels_and_first_w_build_ms": round(d["ms_w"] - d.get("ms_w_sizing", 0.0), 4),
+            "w_buffer_sizing_and_allocation_ms": round(d.get("ms_w_sizing", 0.0), 4),
             "per_class_ms": {"hash": [round(x, 4) for x in d["ms_class"][:8]], "stream": [round(x, 4) for x in d["ms_class"][8:15]]},
             "per_class_rows": {"hash": d["rows_class"][:8], "stream": d["rows_class"][8:15]},
             "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"], "stream_fix_ms": round(d["ms_class"][15], 4),
@@ -283,6 +289,24 @@ def main():
             "roofline": roofline,
             "setup_s": {"generate": round(t_gen, 2), "upload_elect_buildU": round(t_setup, 2)},
         }
+        if world == 1:
+            # the same Schur step inside a real spasm_echelonize (src/SpaSM.jl:863): one sparse round, leftmost pivots as in the plan,
+            # no finish (enable_dense = enable_GPLU = 0: "Cannot finish", U = the round's pivot rows).  Device time of the W build, of
+            # the plan of the rows (with the host synchronisation that reads the total of the bounds) and of the scatter, from the
+            # events the round records; levels_ms = the levels of the pivot graph, density_probe_ms = the sample of 2048 rows that
+            # sizes the pools (spasm_schur_estimate_density's place in the round)
+            try:
+                lib.spasm_amd_schur_plan_free(plan)
+                plan = None
+                S.echelonize(A, max_round=1, enable_dense=False, enable_GPLU=False, enable_greedy_pivot_search=False)
+                r0 = S.last_rounds()[0]
+                e0 = r0["ms_wbuild"] + r0["ms_solve"] + r0["ms_scatter"]
+                out["echelonize_round0"] = {"ms": round(e0, 4), "w_build": round(r0["ms_wbuild"], 4), "plan": round(r0["ms_solve"], 4),
+                                            "scatter": round(r0["ms_scatter"], 4), "levels_ms": round(r0["ms_levels"], 4),
+                                            "w_levels_sizing_first_build_wall_ms": round(r0["ms_w"], 4), "w_buffer_sizing_and_allocation_ms": round(r0.get("ms_w_sizing", 0.0), 4), "pivots_and_probe_ms": round(r0["ms_pivots"], 4),
+                                            "nnz_out": r0["nnz_out"], "over_bench_step": round(e0 / ms_per_step, 3) if ms_per_step > 0 else None}
+            except Exception as exc:  # noqa: BLE001 - reported, not required
+                out["echelonize_round0"] = {"error": repr(exc)}
         if exchange is not None:
             out["pivot_row_exchange_rank0"] = exchange
         if world == 1 and not args.no_cpu_baseline:
@@ -291,7 +315,7 @@ def main():
 
     if engine is not None:
         engine.close()
-    else:
+    elif plan is not None:
         lib.spasm_amd_schur_plan_free(plan)
     if world > 1:
         dist.destroy_process_group()

@@ -272,6 +272,7 @@ struct spasm_amd_round_stats {
     i64 rows_rejected;
     i64 s_entries_used;
     double ms_levels;     /* the levels of the pivot graph (relaxation + sort), once per round: part of ms_w */
+    double ms_w_sizing;   /* of ms_w: the device-memory query and the allocation of the buffers of the W build (wall time) */
 };
 
 typedef struct spasm_amd_schur_plan spasm_amd_schur_plan;

@@ -119,6 +119,7 @@ class RoundStats(C.Structure):  # struct spasm_amd_round_stats (engine extension
         ("rows_rejected", C.c_int64),
         ("s_entries_used", C.c_int64),
         ("ms_levels", C.c_double),
+        ("ms_w_sizing", C.c_double),
     ]
 
     def as_dict(self):

@@ -117,13 +117,29 @@ inline size_t scatter_lds_bytes(const ScatterClass &c, bool small)
     return c.tpr == 64 ? (table + retry) * (size_t)c.wpb : table + retry * (size_t)c.wpb;
 }
 
+// function attributes (the opt-in to more than 64 KB of dynamic LDS) are per DEVICE: a process that drives several devices
+// (spasm_amd_echelonize_multi) sets them on each
+constexpr int kMaxDev = 64;
+inline int current_device()
+{
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    return dev & (kMaxDev - 1);
+}
+
+template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW = 1> void init_scatter(size_t lds)
+{
+    static bool attr_done[kMaxDev] = {false};
+    bool &done = attr_done[current_device()];
+    if (!done) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_scatter<LOGT, TPR, WPB, MAXR, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+}
 template <int LOGT, int TPR, int WPB, int MAXR, bool SMALL, int MINW = 1> void launch_scatter(const ScatterArgs &a, int grid, size_t lds, hipStream_t s)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_scatter<LOGT, TPR, WPB, MAXR, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    init_scatter<LOGT, TPR, WPB, MAXR, SMALL, MINW>(lds);
+    if (grid <= 0) return; // (warm-up call: attributes only)
     hipLaunchKernelGGL((k_scatter<LOGT, TPR, WPB, MAXR, SMALL, MINW>), dim3(grid), dim3(WPB * 64), lds, s, a);
     HIPCHK(hipGetLastError());
 }
@@ -146,13 +162,15 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
 // from the start would do its share after everybody else (the LDS bound alone can be above what the registers admit)
 template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1> void launch_wstream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
-    static int per_cu = 0;
+    static int per_cu_dev[kMaxDev] = {0};
+    int &per_cu = per_cu_dev[current_device()];
     if (!per_cu) {
         HIPCHK(hipFuncSetAttribute((const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>, WPB * 64, lds));
         per_cu = std::max(nb, 1);
     }
+    if (nrows <= 0) return; // (warm-up call: attributes and occupancy only)
     const int rows_per_block = TPR == 64 ? WPB : 1;
     const int grid = std::max(1, std::min((nrows + rows_per_block - 1) / rows_per_block, num_cu * per_cu));
     hipLaunchKernelGGL((k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>), dim3(grid), dim3(WPB * 64), lds, s, a);
@@ -232,7 +250,8 @@ struct Round {
     DevBuf<u64d> own_ctr;           // its bump counters
     DevBuf<u64d> wstate, wblk;      // cursor + statistics of the build; the blocks its waves carve rows from
     DevBuf<int> wmid_list, wbig_list, wbig_count; // rows the wave kernel leaves to the workgroup kernels; counts [2 * level + {0: medium, 1: large}]
-    std::vector<int> wbig_at;       // the counts of the first build of this U: later builds skip the launches without rows
+    std::vector<int> wbig_at;       // rows the workgroup kernels built per level and tier (statistics: SPASM_AMD_WDEBUG, plans)
+    bool want_w_row_stats = false;  // plans read them (spasm_amd_round_stats::w_long_rows)
     DevBuf<WLevRec> lev_recs;       // the pivot rows in level order, as the level kernels read them
     DevBuf<unsigned> lev0_sz, lev0_off; // level 0: lengths rounded up to 16, and their prefix sums = the rows' places in W
     DevBuf<u64d> lev0_ent;
@@ -326,6 +345,11 @@ struct Round {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : ev_cls) if (e) (void)hipEventDestroy(e);
         for (auto &e : ev_fz) if (e) (void)hipEventDestroy(e);
+        for (auto &e : ev_w) if (e) (void)hipEventDestroy(e);
+        if (fb_stream) (void)hipStreamDestroy(fb_stream);
+        if (ev_fb_fork) (void)hipEventDestroy(ev_fb_fork);
+        if (ev_fb_join) (void)hipEventDestroy(ev_fb_join);
+        if (ev_classified) (void)hipEventDestroy(ev_classified);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         for (auto &e : lane_ev) if (e) (void)hipEventDestroy(e);
@@ -659,10 +683,11 @@ struct Round {
             b.s.retry_count = &ctr.p->solve_overflow;
             b.s.overflow_list = nullptr;
             b.s.overflow_count = nullptr;
-            static bool attr_done = false;
-            if (!attr_done) {
+            static bool attr_done[kMaxDev] = {false};
+            bool &done = attr_done[current_device()];
+            if (!done) {
                 HIPCHK(hipFuncSetAttribute((const void *)k_solve_big<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                attr_done = true;
+                done = true;
             }
             const int per_cu = (int)std::max<size_t>(1, (size_t)(160 * 1024) / (lds_dense + 64));
             hipLaunchKernelGGL((k_solve_big<true, 256>), dim3(std::min(big_blocks, num_cu * per_cu)), dim3(256), lds_dense, stream, b);
@@ -691,6 +716,7 @@ struct Round {
     // expected_rows = rows the solve will process: building Uinv costs npiv chain solves, so it pays only for more rows than that
     double ms_uinv = 0, ms_w = 0;   // wall time of the last prepare_uinv / prepare_w, host synchronisations included
     double ms_levels = 0;           // of ms_w: the levels of the pivot graph (build_levels)
+    double ms_w_sizing = 0;         // of ms_w: sizing the [U_PN | own | W] buffer and allocating what the build needs
 
     void prepare_uinv(i64 expected_rows = ((i64)1 << 62))
     {
@@ -847,31 +873,29 @@ struct Round {
         hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(WMAXLEV + 4 <= 256 ? 256 : 512), 0, stream, WMAXLEV + 3, npiv, lev_start_d.p);
         hipLaunchKernelGGL(k_lev_starts, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, lev_keys.p, lev_start_d.p, WMAXLEV + 1);
         HIPCHK(hipGetLastError());
+        // what follows needs nothing from the host: the records in level order, the places of level 0 (rows that are copied) in W --
+        // ONE read-back at the end
+        lev_recs.ensure((size_t)npiv + 1);
+        hipLaunchKernelGGL(k_lev_recs, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, lev_order.p, uhdr.p, pivcol.p, lev_recs.p);
+        lev0_sz.ensure((size_t)npiv + 2);
+        lev0_off.ensure((size_t)npiv + 2);
+        lev0_ent.ensure(1);
+        HIPCHK(hipMemsetAsync(lev0_ent.p, 0, sizeof(u64d), stream));
+        hipLaunchKernelGGL(k_lev0_sizes, dim3(cdiv((i64)npiv + 1, 256)), dim3(256), 0, stream, npiv, lev_start_d.p + 1, lev_recs.p, lev0_sz.p, lev0_ent.p);
+        HIPCHK(hipGetLastError());
+        scan.exclusive(lev0_sz.p, lev0_off.p, (size_t)npiv + 1, stream);
         lev_start.assign(WMAXLEV + 3, npiv);
         int deepest = 0;
+        unsigned tot0 = 0;
+        u64d ent0 = 0;
         HIPCHK(hipMemcpyAsync(lev_start.data(), lev_start_d.p, (WMAXLEV + 3) * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(&deepest, lev_keys.p + (npiv - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&tot0, lev0_off.p + npiv, sizeof tot0, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&ent0, lev0_ent.p, sizeof ent0, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (deepest > WMAXLEV) return;
         depth = deepest;
         lev_start[(size_t)depth + 1] = npiv;
-        lev_recs.ensure((size_t)npiv + 1);
-        hipLaunchKernelGGL(k_lev_recs, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, lev_order.p, uhdr.p, pivcol.p, lev_recs.p);
-        HIPCHK(hipGetLastError());
-        // level 0 (rows that are copied): their places in W, once per U
-        const int cnt0 = lev_start[1];
-        lev0_sz.ensure((size_t)cnt0 + 1);
-        lev0_off.ensure((size_t)cnt0 + 1);
-        lev0_ent.ensure(1);
-        HIPCHK(hipMemsetAsync(lev0_ent.p, 0, sizeof(u64d), stream));
-        hipLaunchKernelGGL(k_lev0_sizes, dim3(cdiv((i64)cnt0 + 1, 256)), dim3(256), 0, stream, cnt0, lev_recs.p, lev0_sz.p, lev0_ent.p);
-        HIPCHK(hipGetLastError());
-        scan.exclusive(lev0_sz.p, lev0_off.p, (size_t)cnt0 + 1, stream);
-        unsigned tot0 = 0;
-        u64d ent0 = 0;
-        HIPCHK(hipMemcpyAsync(&tot0, lev0_off.p + cnt0, sizeof tot0, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(&ent0, lev0_ent.p, sizeof ent0, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
         lev0_total = tot0;
         lev0_entries = (i64)ent0;
     }
@@ -885,8 +909,11 @@ struct Round {
     // with the medium table -- with the largest one when the level has no more rows than the chip has CUs.
     // first: the build that follows build_U, every launch is made and the caller notes the list counts (wbig_at); later builds of
     // the same U skip the launches whose lists were empty.
-    void build_w_levels(bool first)
+    hipEvent_t ev_w[2] = {nullptr, nullptr}; // around the level launches of the last W build
+    void build_w_levels()
     {
+        if (!ev_w[0]) for (auto &e : ev_w) HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipEventRecord(ev_w[0], stream));
         const int nblk_words = 2 * wblk_slots();
         const int ncount_words = 2 * (depth + 2) * WL_NSUB * WL_SUBSTRIDE;
         hipLaunchKernelGGL(k_wbuild_reset, dim3(cdiv(std::max(nblk_words, ncount_words), 256)), dim3(256), 0, stream, wstate.p, wblk.p, nblk_words,
@@ -920,7 +947,6 @@ struct Round {
         a.wcap = (u64d)wcap;
         a.wblk = wblk.p;
         a.F = F;
-        a.stats = first ? 1 : 0;
         a.list_stride = npiv;
         auto launch_wg = [&](int tier, int grid) {
             a.tslots = tier ? big_slots : wl_mid_slots();
@@ -942,7 +968,9 @@ struct Round {
             const int cnt = lev_start[(size_t)L + 1] - lev_start[(size_t)L];
             if (cnt <= 0) continue;
             int *const mid_count = wbig_count.p + (size_t)(2 * L) * WL_NSUB * WL_SUBSTRIDE, *const big_count = wbig_count.p + (size_t)(2 * L + 1) * WL_NSUB * WL_SUBSTRIDE;
-            const int known_mid = first ? -1 : wbig_at[(size_t)(2 * L)], known_big = first ? -1 : wbig_at[(size_t)(2 * L + 1)];
+            // (every tier launch is made, with the grid of a full list: how many rows a list holds is only known on the device, and the
+            // build runs once per round -- a launch whose list is empty costs a few microseconds)
+            const int known_mid = -1, known_big = -1;
             a.cnt = cnt;
             a.rec_base = lev_start[(size_t)L];
             a.mid_list = wmid_list.p;
@@ -982,6 +1010,7 @@ struct Round {
             }
         }
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ev_w[1], stream));
     }
 
     // Decides whether this round goes along W, sizes the [U_PN | own | W] buffer and builds W once (synchronises: the outcome of
@@ -994,6 +1023,7 @@ struct Round {
         use_w = false;
         wtotal = 0;
         ms_levels = 0;
+        ms_w_sizing = 0;
         if (!use_stream || force_lists || want_idx || m >= (1 << 24) || npiv == 0 || expected_rows < 2 * (i64)npiv) return;
         {
             HIPCHK(hipStreamSynchronize(stream));
@@ -1003,6 +1033,7 @@ struct Round {
             ms_levels = 1e3 * (spasm_wtime() - t0);
         }
         if (depth < 0) return;
+        const double t_sizing0 = spasm_wtime();
         // room for the rows' own entries: what they have, half as much again for uneven regions, and a block per team of the plan kernel
         const i64 own_room = ((own_entries + own_entries / 2 + (i64)num_cu * 16 * 16 * 256 + NPOOL) + 15) & ~(i64)15;
         own_base = (utotal + 15) & ~(i64)15;
@@ -1039,14 +1070,26 @@ struct Round {
         hipLaunchKernelGGL(k_pbits, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, qinv_r.p, pbits.p);
         HIPCHK(hipGetLastError());
         wbig_at.assign((size_t)2 * (depth + 2), 0);
-        build_w_levels(true);
+        {
+            // (wall time of the sizing: the device-memory query and whatever had to be allocated -- once per Round for rounds of one size)
+            HIPCHK(hipStreamSynchronize(stream));
+            ms_w_sizing = 1e3 * (spasm_wtime() - t_sizing0);
+        }
+        build_w_levels();
+        hipLaunchKernelGGL(k_wstats, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, wrow.p, wstate.p);
+        HIPCHK(hipGetLastError());
         u64d ws[WS_WORDS];
         HIPCHK(hipMemcpyAsync(ws, wstate.p, sizeof ws, hipMemcpyDeviceToHost, stream));
-        std::vector<int> parts((size_t)2 * (depth + 1) * WL_NSUB * WL_SUBSTRIDE);
-        HIPCHK(hipMemcpyAsync(parts.data(), wbig_count.p, parts.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+        const bool wdebug = getenv("SPASM_AMD_WDEBUG") != nullptr || want_w_row_stats;
+        std::vector<int> parts;
+        if (wdebug) { // (how many rows the workgroup kernels built, level by level: a statistic, 280 KB over PCIe)
+            parts.resize((size_t)2 * (depth + 1) * WL_NSUB * WL_SUBSTRIDE);
+            HIPCHK(hipMemcpyAsync(parts.data(), wbig_count.p, parts.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+        }
         HIPCHK(hipStreamSynchronize(stream));
-        for (int k = 0; k < 2 * (depth + 1); k++)
-            for (int sb = 0; sb < WL_NSUB; sb++) wbig_at[(size_t)k] += parts[((size_t)k * WL_NSUB + sb) * WL_SUBSTRIDE];
+        if (wdebug)
+            for (int k = 0; k < 2 * (depth + 1); k++)
+                for (int sb = 0; sb < WL_NSUB; sb++) wbig_at[(size_t)k] += parts[((size_t)k * WL_NSUB + sb) * WL_SUBSTRIDE];
         if (ws[WS_ERROR]) throw EngineError("a hash table of the W build filled up (internal bound violated)");
         if (getenv("SPASM_AMD_WDEBUG")) {
             fprintf(stderr, "[wlevel] npiv %d depth %d entries %llu cursor %llu unavailable %llu long rows %llu; rows per level (medium, large):", npiv, depth,
@@ -1059,7 +1102,8 @@ struct Round {
         if (ws[WS_UNAVAIL] * 64 > (u64d)npiv) return;
         wtotal = (i64)std::min<u64d>(ws[WS_CURSOR], (u64d)cap);
         w_entries = (i64)ws[WS_ENTRIES] + lev0_entries;
-        w_long_rows = (i64)ws[WS_BIGROWS];
+        w_long_rows = 0;
+        for (int k = 0; k < 2 * (depth + 1); k++) w_long_rows += wbig_at[(size_t)k];
         own_total = own_room;
         use_w = true;
     }
@@ -1112,12 +1156,10 @@ struct Round {
         }
         rstart.ensure((size_t)nrows + 1);
         rlen.ensure((size_t)nrows + 1);
-        // (a plan reduces the same rows of the same matrix every time: their (start, length) pairs are gathered once)
-        if (!(quiet_known && gathered_n == nrows)) {
-            hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, rstart.p, rlen.p);
-            HIPCHK(hipGetLastError());
-            gathered_n = nrows;
-        }
+        // (every step: a round gathers them once, and a plan's step is a round's)
+        hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(nrows, 256)), dim3(256), 0, stream, nrows, rows, M.start.p, M.len.p, rstart.p, rlen.p);
+        HIPCHK(hipGetLastError());
+        gathered_n = nrows;
         if (wmode) {
             wreject_list.ensure((size_t)nrows + 1);
             WPlanArgs wp;
@@ -1282,6 +1324,65 @@ struct Round {
         return tot;
     }
 
+    // ---- what the scatter needs once per Round: its streams and events, the opt-in of its kernels to large LDS, the scratch of the
+    // last-resort kernel.  Done on the first scatter -- or, by a round, in front of its timed step (warm_scatter): a hipMalloc of
+    // gigabytes or the creation of six streams between two launches of the step is milliseconds of an idle device.
+    static int n_lanes() { static const int v = [] { const char *e = getenv("SPASM_AMD_STREAM_LANES"); return std::min(4, std::max(1, e ? atoi(e) : 2)); }(); return v; }
+    static int n_twins() { static const int v = [] { const char *e = getenv("SPASM_AMD_TWIN_STREAMS"); return std::min(4, std::max(1, e ? atoi(e) : 2)); }(); return v; }
+    void ensure_streams()
+    {
+        if (!side) {
+            HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        if (!ev_cls_done[0]) for (auto &e : ev_cls_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (int l = 1; l < n_lanes(); l++)
+            if (!lane_s[l]) {
+                HIPCHK(hipStreamCreateWithFlags(&lane_s[l], hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&lane_ev[l], hipEventDisableTiming));
+            }
+        for (int t = 0; t < n_twins() - 1; t++)
+            if (!twin_s[t]) {
+                HIPCHK(hipStreamCreateWithFlags(&twin_s[t], hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&twin_ev[t], hipEventDisableTiming));
+            }
+    }
+    void ensure_big_scatter(hipStream_t s)
+    {
+        if (bigsc_m == m) return;
+        const i64 per = std::max<i64>((i64)m, 1) * 13; // bytes per workgroup: 8 accumulator + 4 list + bitmap
+        // rows in flight are its throughput; its rows are the handful beyond every LDS table: 2 GiB of scratch at most
+        bigsc_blocks = (int)std::max<i64>(1, std::min<i64>((i64)num_cu * 8, ((i64)2 << 30) / per));
+        bigsc_m = m;
+        const size_t nw = ((size_t)std::max(m, 1) + 31) / 32;
+        sc_xdense.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));
+        sc_bitmap.alloc((size_t)bigsc_blocks * nw);
+        sc_touched.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));
+        sc_xdense.zero(s);
+        sc_bitmap.zero(s);
+    }
+    void warm_scatter()
+    {
+        ensure_streams();
+        ensure_big_scatter(stream);
+        ScatterArgs a;
+        memset(&a, 0, sizeof a);
+        StreamArgs sa;
+        memset(&sa, 0, sizeof sa);
+        const int nhash = F.small ? kNumHashClasses : kNumHashClasses - 1;
+        for (int c = 0; c < nhash; c++) {
+            const size_t lds = scatter_lds_bytes(kClasses[c], F.small);
+            if (F.small) launch_scatter_class<true>(c, a, 0, lds, stream);
+            else launch_scatter_class<false>(c, a, 0, lds, stream);
+        }
+        for (int c = 0; c < std::min(nhash, kNumStreamClasses); c++) {
+            const size_t lds = stream_lds_bytes(stream_logt(c), stream_tpr(c), stream_wpb(c));
+            if (F.small) launch_stream_class<true>(c, sa, 0, num_cu, lds, stream);
+            else launch_stream_class<false>(c, sa, 0, num_cu, lds, stream);
+        }
+    }
+
     void run_scatter(const DevMat &M, const int *rows, int nrows)
     {
         const int4 *recs = Lpool.p;
@@ -1360,11 +1461,7 @@ struct Round {
         const int first_side = 6;
         const bool use_side = !class_timing && (nhash > first_side || streaming);
         if (use_side) {
-            if (!side) {
-                HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-            }
+            ensure_streams();
             HIPCHK(hipEventRecord(ev_fork, stream));
             HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
         }
@@ -1418,17 +1515,7 @@ struct Round {
         };
         auto launch_big = [&](hipStream_t s) {
             // rows that fit no LDS table: the last class, through the global-memory kernel
-            if (bigsc_m != m) {
-                const i64 per = std::max<i64>((i64)m, 1) * 13; // bytes per workgroup: 8 accumulator + 4 list + bitmap
-                bigsc_blocks = (int)std::max<i64>(1, std::min<i64>((i64)num_cu * 8, ((i64)16 << 30) / per)); // rows in flight are its throughput
-                bigsc_m = m;
-                const size_t nw = ((size_t)std::max(m, 1) + 31) / 32;
-                sc_xdense.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));
-                sc_bitmap.alloc((size_t)bigsc_blocks * nw);
-                sc_touched.alloc((size_t)bigsc_blocks * (size_t)std::max(m, 1));
-                sc_xdense.zero(s);
-                sc_bitmap.zero(s);
-            }
+            ensure_big_scatter(s);
             mark(NHASHMAX - 1, s);
             BigScatterArgs bb;
             bb.s = a;
@@ -1446,27 +1533,15 @@ struct Round {
         if (use_side && streaming) {
             // the streaming kernels on the main stream, longest rows first; the hash-table kernel of a class -- it only gets what its
             // streaming twin hands back -- follows that twin on the side stream, beside the streaming kernels of the shorter rows
-            if (!ev_cls_done[0]) for (auto &e : ev_cls_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             // several lanes: the streaming kernels go round-robin over a few streams, so that the workgroups of the next classes
             // fill the chip while the last ones of a class drain (config 3: 2.68 ms per step on one lane, 2.38 on two)
-            static const int lanes = [] { const char *e = getenv("SPASM_AMD_STREAM_LANES"); return std::min(4, std::max(1, e ? atoi(e) : 2)); }();
-            for (int l = 1; l < lanes; l++) {
-                if (!lane_s[l]) {
-                    HIPCHK(hipStreamCreateWithFlags(&lane_s[l], hipStreamNonBlocking));
-                    HIPCHK(hipEventCreateWithFlags(&lane_ev[l], hipEventDisableTiming));
-                }
-                HIPCHK(hipStreamWaitEvent(lane_s[l], ev_fork, 0));
-            }
+            const int lanes = n_lanes();
+            for (int l = 1; l < lanes; l++) HIPCHK(hipStreamWaitEvent(lane_s[l], ev_fork, 0));
             // the hash-table twins (a handful of rows each: 20 - 50 us of one or two workgroups whatever the shard size) run two
             // abreast on streams of their own: chained on one stream they were 0.15 ms of a 0.6 ms step of a 1/8 shard
             // (HIP multiplexes streams over four hardware queues: with more than four streams in play a twin waiting for its event
             // blocks the streaming kernels queued behind it -- 2.4 -> 3.0 ms per step with six streams; four it is)
-            static const int ntwin = [] { const char *e = getenv("SPASM_AMD_TWIN_STREAMS"); return std::min(4, std::max(1, e ? atoi(e) : 2)); }();
-            for (int t = 0; t < ntwin - 1; t++)
-                if (!twin_s[t]) {
-                    HIPCHK(hipStreamCreateWithFlags(&twin_s[t], hipStreamNonBlocking));
-                    HIPCHK(hipEventCreateWithFlags(&twin_ev[t], hipEventDisableTiming));
-                }
+            const int ntwin = n_twins();
             for (int c = nhash - 1; c >= 0; c--) {
                 const int l = (nhash - 1 - c) % lanes;
                 hipStream_t lane = l ? lane_s[l] : stream;
@@ -2080,8 +2155,9 @@ void fill_stats(spasm_amd_round_stats &st, const Round &R, int round, int rows_i
         st.s_entries_used = R.fz_used;
     }
     st.ms_levels = R.ms_levels;
+    st.ms_w_sizing = R.ms_w_sizing;
     if (R.use_w) {
-        if (hipEventElapsedTime(&ms, R.ev[4], R.ev[1]) == hipSuccess) st.ms_wbuild = ms;
+        if (R.ev_w[0] && hipEventElapsedTime(&ms, R.ev_w[0], R.ev_w[1]) == hipSuccess) st.ms_wbuild = ms;
         st.w_levels = R.depth + 1;
         st.w_entries = R.w_entries;
         st.w_long_rows = R.w_long_rows;
@@ -2418,7 +2494,8 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     HIPCHK(hipMemsetAsync(seq.p, 0xff, (size_t)Rp * sizeof(int), s));
     HIPCHK(hipMemsetAsync(pivrow_of_col.p, 0xff, ((size_t)C + 1) * sizeof(int), s));
     const size_t lds = inlds ? (size_t)chunk * DP_W * (size_t)xbytes : 0;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDev] = {false}; // (per device, and per element type: this function is a template)
+    bool &attr_done = attr_done_dev[current_device()];
     if (!attr_done) {
         HIPCHK(hipFuncSetAttribute((const void *)k_panel_lu<true, 1024, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
         HIPCHK(hipFuncSetAttribute((const void *)k_panel_follow<1024, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456 - (int)sizeof(int) * (DP_W * DP_W + DP_W) - 1024));
@@ -3221,6 +3298,11 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     // the trip counters of the round statistics (applications, nnz_reduced, read_bytes) count multiplier-list entries: they are
     // exact only when the rounds keep to the lists, which costs about a third more time per round
     if (const char *e = getenv("SPASM_AMD_ROUND_STATS")) R->force_lists = atoi(e) != 0;
+    // (no event pair around every scatter class: with them the classes run one after the other on one stream -- the two lanes and
+    // the twins' side streams are what the benchmark's step has, and a round is to cost what that step costs.  The per-class times
+    // of the round statistics are then zero; SPASM_AMD_CLASS_TIMING=1 brings them back.)
+    R->class_timing = false;
+    if (const char *e = getenv("SPASM_AMD_CLASS_TIMING")) R->class_timing = atoi(e) != 0;
     // echelonize_opts.L (reference src/SpaSM.jl:331): keep the multipliers.  They only exist as lists on the sparse path, so the
     // rounds keep to the lists (with the pivot index of every record) and the dense finish is not used.
     const bool want_L = opts->L;
@@ -3388,6 +3470,11 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
         dw.reset();
         while (off < nnp || nnp == 0) {
             const int cnt = std::min(chunk, nnp - off);
+            // (what the step allocates is allocated here, in front of the timed step: the record pool, the per-row arrays, and S as the
+            // sample sized it -- a 4 GB hipMalloc between two kernels of the step is milliseconds of an idle device)
+            R->alloc_solve(cnt, std::min<i64>(std::max<i64>((i64)(rec_per_row * (double)cnt), 1 << 16), max_pool));
+            R->warm_scatter();
+            if (slots_per_row > 0) R->S.ent.ensure((size_t)std::min<double>((double)max_slots, 1.05 * slots_per_row * (double)cnt) + 1024);
             HIPCHK(hipEventRecord(R->ev[1], stream));
             // The fused step (fused.hpp: plan + stream of a row in one kernel, S written compactly) when the round goes along W and the
             // sample told how long the Schur rows are; the rows it leaves, and every round without W, take the general path: the
@@ -4204,6 +4291,7 @@ namespace {
 void plan_prepare(spasm_amd_schur_plan *P)
 {
     Round &R = P->R;
+    R.want_w_row_stats = true;
     R.prepare_w((i64)1 << 62, P->nnz_in);
     if (R.use_w) { R.use_uinv = false; R.ms_uinv = 0; }
     else R.prepare_uinv();
@@ -4506,7 +4594,7 @@ void plan_run(spasm_amd_schur_plan *P, hipStream_t s)
     // the whole Schur step of the round (reference spasm_schur, src/SpaSM.jl:761-762: the per-row solve is inside it): W from
     // U, the plan of every row, the scatter.  ev[4] .. ev[1] = the W build.
     HIPCHK(hipEventRecord(R.ev[4], s));
-    if (R.use_w) R.build_w_levels(false);
+    if (R.use_w) R.build_w_levels();
     else if (R.use_uinv) R.prepare_uinv();
     HIPCHK(hipEventRecord(R.ev[1], s));
     if (R.fused_ok() && P->fused_scap > 0) {

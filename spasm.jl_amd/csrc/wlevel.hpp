@@ -95,6 +95,20 @@ __global__ void k_wbuild_reset(u64d *__restrict__ wstate, u64d *__restrict__ wbl
     if (t < nlev) big_count[t] = 0;
 }
 
+// statistics of a finished build, from the rows' {offset, length} records: entries of W, rows that could not be built
+__global__ void k_wstats(int npiv, const int2 *__restrict__ wrow, u64d *__restrict__ wstate)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    long long len = q < npiv ? (long long)wrow[q].y : 0;
+    const u64d un = __ballot(len < 0);
+    len = len < 0 ? 0 : len;
+    for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o);
+    if ((threadIdx.x & 63) == 0) {
+        if (len) atomicAdd(wstate + WS_ENTRIES, (u64d)len);
+        if (un) atomicAdd(wstate + WS_UNAVAIL, (u64d)__popcll(un));
+    }
+}
+
 // a pivot row as the level kernels want it, in level order: one 32-byte record instead of order[] -> uhdr[] -> pivcol[]
 struct __attribute__((aligned(32))) WLevRec {
     int q;        // pivot index
@@ -143,7 +157,6 @@ struct WLevelArgs {
     const int *count;
     int tslots;                // workgroup kernel: slots of its table (a power of two)
     int blk_base;              // workgroup kernel: its first slot in wblk
-    int stats;                 // keep the statistics words (first build)
     ZpField F;
 };
 
@@ -252,12 +265,14 @@ __device__ __forceinline__ bool wl_consume(lds_vint *cd_off, lds_vint *cd_len, l
 // (rounded up to 16), computed once per U (k_lev0_sizes + scan): the copy needs no allocation and no table, a team of 16 lanes
 // per row.  The cursor of a build starts behind them.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_lev0_sizes(int cnt, const WLevRec *__restrict__ recs, unsigned *__restrict__ sz, u64d *__restrict__ entries)
+__global__ void k_lev0_sizes(int npiv, const int *__restrict__ cnt_dev, const WLevRec *__restrict__ recs, unsigned *__restrict__ sz, u64d *__restrict__ entries)
 {
+    // (over all npiv rows in level order: those behind level 0 take no room; the level's size is still on the device here)
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cnt = *cnt_dev;
     int npn = 0;
     if (r < cnt) { npn = recs[r].npn; sz[r] = (unsigned)((npn + 15) & ~15); }
-    if (r == cnt) sz[r] = 0;
+    else if (r <= npiv) sz[r] = 0;
     for (int o = 32; o > 0; o >>= 1) npn += __shfl_xor(npn, o);
     if ((threadIdx.x & 63) == 0 && npn) atomicAdd(entries, (u64d)npn);
 }
@@ -459,11 +474,8 @@ __global__ __launch_bounds__(256) void k_wlevel_wave(WLevelArgs a)
     if (lane == 0) {
         a.wblk[2 * wslot] = bpos;
         a.wblk[2 * wslot + 1] = bend;
-        if (a.stats) {
-            if (c_ent) atomicAdd(a.wstate + WS_ENTRIES, c_ent);
-            if (c_unavail) atomicAdd(a.wstate + WS_UNAVAIL, (u64d)c_unavail);
-            if (c_big) atomicAdd(a.wstate + WS_BIGROWS, (u64d)c_big);
-        }
+        (void)c_ent; (void)c_unavail; (void)c_big; // (statistics: k_wstats works them out of wrow[] after the build -- tens of thousands of
+                                                   // waves adding to three words at the end of every level kernel cost 0.7 ms of a 2 ms build)
         if (c_err) atomicAdd(a.wstate + WS_ERROR, (u64d)c_err);
     }
 }
@@ -660,10 +672,6 @@ __global__ __launch_bounds__(NT) void k_wlevel_wg(WLevelArgs a)
             const int len = avail ? n_out : -1;
             a.wrow[q] = make_int2((int)out_off, len);
             a.wcol[pc] = make_int4(q, len, (int)out_off, 0);
-            if (a.stats) {
-                if (avail) atomicAdd(a.wstate + WS_ENTRIES, (u64d)n_out);
-                else atomicAdd(a.wstate + WS_UNAVAIL, 1ull);
-            }
         }
         __syncthreads();
         R0 = R1; R1 = R2;
