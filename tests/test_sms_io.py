@@ -52,3 +52,40 @@ def test_large_random_roundtrip(S, tmp_path):
     S.save(path, A)
     B = S.load(path, prime=65521)
     assert B.shape == A.shape and B.rows() == A.rows()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SMS file -> engine, end to end on the GPU.  tests/golden/runtests_matrix.sms is the matrix of the
+# reference's own tests, m = sparse([1,1,3,3],[1,2,3,4],[1,2,3,4]) (test/runtests.jl:3), byte for byte as the reference's
+# writer puts it out (src/SpaSM.jl:1029-1042: header "rows cols M", one "i j v" line per entry in findnz order -- column
+# by column --, 1-based, terminator "0 0 0").  A reader takes the file as the matrix it names (libspasm's
+# spasm_triplet_load, :498-512); SpaSM.jl's CSR(::SparseMatrixCSC) hands libspasm the TRANSPOSE (:941-968), which is why
+# runtests.jl's `sm` is the transpose of what the file says and its golden kernels (:20-23) pair up as below.
+# ---------------------------------------------------------------------------------------------------------------------
+GOLDEN_SMS = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "runtests_matrix.sms")
+
+
+def test_reference_writer_format_fixture(S):
+    text = open(GOLDEN_SMS).read()
+    assert text == "3 4 M\n1 1 1\n1 2 2\n3 3 3\n3 4 4\n0 0 0\n"
+    A = S.load(GOLDEN_SMS, prime=42013)
+    assert A.shape == (3, 4) and A.rows() == [[(0, 1), (1, 2)], [], [(2, 3), (3, 4)]]
+
+
+@pytest.mark.gpu
+def test_sms_file_through_the_engine_to_the_golden_kernels(S, tmp_path):
+    p = 42013
+    A = S.load(GOLDEN_SMS, prime=p)  # the matrix the file names = transpose(sm) of runtests.jl
+    fact = S.echelonize(A)
+    assert fact.r == 2
+    K = S.kernel(fact)
+    # test/runtests.jl:23: sparse(kernel(transpose(sm))) == sparse([1,2,3,4],[1,1,2,2],[2,42012,28010,42012])
+    assert [[(c, v % p) for c, v in r] for r in K.rows()] == [[(0, 2), (1, 42012)], [(2, 28010), (3, 42012)]]
+    # and sm itself (what CSR(m) hands to libspasm): runtests.jl:21, sparse([2],[1],[42012],3,1)
+    sm = S.transpose(A)
+    Ks = S.kernel(S.echelonize(sm))
+    assert [[(c, v % p) for c, v in r] for r in Ks.rows()] == [[(1, 42012)]]
+    # written back by the engine's writer, the file reads the same
+    out = tmp_path / "again.sms"
+    S.save(out, A)
+    assert S.load(out, prime=p).rows() == A.rows()
