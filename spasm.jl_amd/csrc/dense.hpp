@@ -956,15 +956,23 @@ __global__ __launch_bounds__(256) void k_tall_gather_cols(int nrows, const int *
     for (int j = threadIdx.x; j < (int)ldo; j += 256) out[(i64d)i * ldo + j] = j < ncols ? D[src + cols[j]] : (DT)0;
 }
 
-// out[i][j0 + j] = D[i][cols[j] - col_off], j < ncols: the columns cols[0 .. ncols) of a slab of D that starts at column col_off
+// out[i][j0 + j] += D[i][cols[j] - col_off] (mod p), j < ncols: the columns cols[0 .. ncols) of a slab of D that starts at column
+// col_off.  ADDED, not stored: with the source in several column slabs the GEMMs of the slabs before this one have already
+// subtracted their share of d_P Z from these columns of the residual (storing dropped it: the residuals then kept parts of the
+// row space they should have lost, and the rank came out too high -- found with a matrix of planted rank, tools/planted_rank.py).
 template <typename DT>
-__global__ __launch_bounds__(256) void k_tall_gather_slab(int nrows, const DT *__restrict__ D, i64d ldc, const int *__restrict__ cols, int ncols, int col_off,
+__global__ __launch_bounds__(256) void k_tall_gather_slab(int nrows, const DT *__restrict__ D, i64d ldc, const int *__restrict__ cols, int ncols, int col_off, ZpField F,
                                                           DT *__restrict__ out, i64d ldo, int j0)
 {
     const int i = blockIdx.x;
     if (i >= nrows) return;
     const i64d src = (i64d)i * ldc - col_off;
-    for (int j = threadIdx.x; j < ncols; j += 256) out[(i64d)i * ldo + j0 + j] = D[src + cols[j]];
+    for (int j = threadIdx.x; j < ncols; j += 256) {
+        int v = (int)out[(i64d)i * ldo + j0 + j] + (int)D[src + cols[j]];
+        if (v > (int)F.halfp) v -= (int)F.p;
+        else if (v < (int)F.mhalfp) v += (int)F.p;
+        out[(i64d)i * ldo + j0 + j] = (DT)v;
+    }
 }
 
 // back substitution inside a block of nb <= 64 pivots (rows t0 .. t0 + nb of Z, pivot rows prow[t], pivot columns pcol[t]):

@@ -202,7 +202,7 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
             tf2 += spasm_wtime() - tc;
             DT *Tb = T.p + (size_t)off * (size_t)ldz;
             if (fb > fa) {
-                hipLaunchKernelGGL((k_tall_gather_slab<DT>), dim3(cnt), dim3(256), 0, s, cnt, Db.p, (i64d)w, fcol.p + fa, fb - fa, (int)s0, Tb, (i64d)ldz, fa);
+                hipLaunchKernelGGL((k_tall_gather_slab<DT>), dim3(cnt), dim3(256), 0, s, cnt, Db.p, (i64d)w, fcol.p + fa, fb - fa, (int)s0, F, Tb, (i64d)ldz, fa);
                 HIPCHK(hipGetLastError());
             }
             for (int c0 = pa; c0 < pb; c0 += W.KB)

@@ -2501,6 +2501,23 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
         HIPCHK(hipFuncSetAttribute((const void *)k_panel_follow<1024, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456 - (int)sizeof(int) * (DP_W * DP_W + DP_W) - 1024));
         attr_done = true;
     }
+    // The panel kernel's own grid barrier needs every workgroup of a launch resident at once (a plain launch does not check it, as
+    // the cooperative launch did): ask the runtime how many fit and refuse cleanly instead of spinning into the barrier's timeout.
+    {
+        auto fits = [&](const void *fn, int wgs, size_t dyn, const char *what) {
+            int per_cu = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 1024, dyn));
+            if ((i64)wgs > (i64)per_cu * num_cu)
+                throw EngineError(std::string("dense finish: the ") + what + " panel kernel needs " + std::to_string(wgs) + " resident workgroups, the device holds " +
+                                  std::to_string((i64)per_cu * num_cu));
+        };
+        const void *fn_lds = (const void *)k_panel_lu<true, 1024, DT>, *fn_glb = (const void *)k_panel_lu<false, 1024, DT>;
+        if (tall) {
+            fits(fn_lds, G_res, (size_t)res_chunk * DP_W * (size_t)xbytes, "LDS-resident");
+            fits(fn_glb, G, 0, "in-place");
+        } else
+            fits(inlds ? fn_lds : fn_glb, G, lds, inlds ? "LDS-resident" : "in-place");
+    }
     const char *glds_env = getenv("SPASM_AMD_GEMM_GLDS"); // A/B: the 256 x 256 LDS-DMA kernel for the large one-digit updates
     const bool glds_tile = glds_env && atoi(glds_env) != 0;
     if constexpr (std::is_same<DT, signed char>::value) {
@@ -2554,8 +2571,12 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
                 unsigned long long *a_stamps = stamps.p;
                 void *args[] = {&a_Rp, &a_chunk, &a_w, &a_c0, &a_F, &a_P, &a_seq, &a_pc, &a_info, &a_sy, &a_cand, &a_st, &a_inv, &a_stamps};
                 const void *fn_lds = (const void *)k_panel_lu<true, 1024, DT>, *fn_glb = (const void *)k_panel_lu<false, 1024, DT>;
-                // A PLAIN launch: G <= one workgroup per CU (LDS-bound), nothing else runs on the stream's device, so the grid is
-                // resident as a whole and the kernel's own barrier (dense.hpp: panel_grid_barrier, bounded spins) is enough.
+                // A PLAIN launch: G <= one workgroup per CU (checked against the runtime's occupancy figure above), so the grid is
+                // resident as a whole once it has started and the kernel's own barrier (dense.hpp: panel_grid_barrier, bounded
+                // spins) is enough.  The U streamer's kernels (scan, k_dense_count, k_dense_emit, k_split_ent on its stream s2) do
+                // run beside it: they are short, use no LDS to speak of and end on their own, so they can delay the start of a
+                // panel workgroup, never hold one out for good; two ELIMINATIONS on one device at once can (each takes a share of
+                // the CUs and waits for the rest): ranks that share a device take turns (sharded.py: the replicated finish and dshard_candidates).
                 // hipLaunchCooperativeKernel bought nothing but its launch-time size check, cost ~17 us per panel, and its dedicated
                 // HSA queue made every rocprofv3-profiled process die in exit(): libamdhip64's exit handler tears that queue down
                 // inside libhsa-runtime64 after rocprofiler-sdk has finalised its queue interception (tools/segv_probe.sh,

@@ -301,13 +301,25 @@ def dense_round_sharded(eng, free_cols, sparsity_threshold, group=None, force=Fa
         Cn, KB, ldc, elem, nd, cb = Cn.value, KB.value, ldc.value, elem.value, nd.value, cb.value
         cand = torch.empty(cb, dtype=torch.uint8, device=eng.device)
         npp, cnt, first = C.c_int32(0), (C.c_int32 * world)(), (C.c_int32 * world)()
+        # Ranks that SHARE a device (rehearsals on a one-GPU box) take turns in the one step that launches the panel kernel over the
+        # shard's rows: it is a persistent grid with its own barrier, and two of them from different processes cannot both be resident
+        # on one device.  (The election among the stacked candidates is one workgroup: no turn needed.)  One device per rank: no barrier.
+        shared = world > 1 and torch.cuda.is_available() and torch.cuda.device_count() < world
         for b0 in range(0, Cn, KB):
             b1 = min(b0 + KB, Cn)
             _chk(lib.spasm_amd_dshard_block_begin(ds), "spasm_amd_dshard_block_begin")
             q = 0
             for c0 in range(b0, b1, 64):
                 w = min(c0 + 64, b1) - c0
-                _chk(lib.spasm_amd_dshard_candidates(ds, c0, w, C.c_void_p(cand.data_ptr())), "spasm_amd_dshard_candidates")
+                if shared:
+                    rc = 0
+                    for turn in range(world):
+                        if turn == rank:
+                            rc = lib.spasm_amd_dshard_candidates(ds, c0, w, C.c_void_p(cand.data_ptr()))
+                        dist.barrier(group=group)
+                    _chk(rc, "spasm_amd_dshard_candidates")
+                else:
+                    _chk(lib.spasm_amd_dshard_candidates(ds, c0, w, C.c_void_p(cand.data_ptr())), "spasm_amd_dshard_candidates")
                 if world > 1:
                     cdev = _collective_device(cand, group)
                     outs = [torch.empty_like(cdev) for _ in range(world)]

@@ -12,7 +12,7 @@ leading column lies to the RIGHT of their own (their leftmost entry stays a colu
 them, as it finds the shifts of a Macaulay matrix); the other rows mix in anything, so their pivots are only found by elimination --
 the dense tail of BASELINE config 5.
 
-    python tools/planted_rank.py [scale=25] [--rank-only] [--keep=0.85] [--n=rows --m=columns]
+    python tools/planted_rank.py [scale=25] [--rank-only] [--keep=0.85] [--n=rows --m=columns] [--opt=field=value]
                                                   # 5M x 2M over scale (or n x m), rank 0.99 * columns, through the C ABI
 """
 import os
@@ -103,6 +103,11 @@ if __name__ == "__main__":
             n = int(a[4:])
         if a.startswith("--m="):
             m, n0 = int(a[4:]), int(0.99 * int(a[4:]))
+    opts = {}
+    for a in sys.argv:
+        if a.startswith("--opt="):  # --opt=sparsity_threshold=0.0 : a field of echelonize_opts
+            k, v = a[6:].split("=")
+            opts[k] = float(v) if "." in v else int(v)
     t0 = time.time()
     A = planted(n, m, n0, keep=keep)
     print(f"planted {n} x {m}, rank {n0} by construction, nnz {A.nnz} in {time.time() - t0:.1f}s", flush=True)
@@ -110,10 +115,10 @@ if __name__ == "__main__":
     del A
     t0 = time.time()
     if "--rank-only" in sys.argv:
-        r = S.rank(M, rank_only=True, verbose=("-v" in sys.argv))
+        r = S.rank(M, rank_only=True, verbose=("-v" in sys.argv), **opts)
         print(f"spasm_amd_rank: {r} in {time.time() - t0:.2f}s -> {'OK' if r == n0 else 'MISMATCH'} (want {n0})", flush=True)
     else:
-        f = S.echelonize(M, verbose=("-v" in sys.argv))
+        f = S.echelonize(M, verbose=("-v" in sys.argv), **opts)
         r = f.r
         print(f"spasm_echelonize: rank {r} in {time.time() - t0:.2f}s -> {'OK' if r == n0 else 'MISMATCH'} (want {n0})", flush=True)
     sys.exit(0 if r == n0 else 1)
