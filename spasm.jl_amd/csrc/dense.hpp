@@ -975,6 +975,21 @@ __global__ __launch_bounds__(256) void k_tall_gather_slab(int nrows, const DT *_
     }
 }
 
+// the pivot rows of an eliminated residual matrix T, packed in column order: E[slot] = T[pc[c]], slot = scan[c] (the number of pivot
+// columns before c); their origins and the pivot row of every column in the packed numbering.  One workgroup per column.
+template <typename DT>
+__global__ __launch_bounds__(256) void k_tall_compact(int f, i64d ldz, const int *__restrict__ pc, const int *__restrict__ scan, const DT *__restrict__ T,
+                                                      const int *__restrict__ origT, DT *__restrict__ E, int *__restrict__ origE, int *__restrict__ pcE)
+{
+    const int c = blockIdx.x;
+    if (c >= f) return;
+    const int r = pc[c];
+    if (r < 0) { if (threadIdx.x == 0) pcE[c] = -1; return; }
+    const int slot = scan[c];
+    if (threadIdx.x == 0) { pcE[c] = slot; origE[slot] = origT[r]; }
+    for (i64d j = threadIdx.x; j < ldz; j += 256) E[(i64d)slot * ldz + j] = T[(i64d)r * ldz + j];
+}
+
 // back substitution inside a block of nb <= 64 pivots (rows t0 .. t0 + nb of Z, pivot rows prow[t], pivot columns pcol[t]):
 // z_t -= sum_{t < s < t0 + nb} D[prow[t]][pcol[s]] z_s, t descending.  One workgroup per 16 columns of Z: thread (tx, ty) owns column
 // tx and the rows 4 ty .. 4 ty + 3; the 64 x 64 coefficients and the tile of Z live in LDS.  Right-looking: once z_t is final every

@@ -161,11 +161,8 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     ts.t_z = spasm_wtime() - t1;
     // ---- 3. every other row in one step: t = d_N - d_P Z.  Column slab by column slab of the source (the dense W of a slab is built
     // once: config 5 at full size has six, and rebuilding them for every batch of rows took 205 of the run's 268 s), a batch of rows
-    // at a time inside; T collects the residuals of all rows.
+    // at a time inside; Tp collects the residuals of the rows [row0, row0 + nrows) of the rows beyond the slab.
     const double t2 = spasm_wtime();
-    DevBuf<DT> T;
-    T.alloc((size_t)R2 * (size_t)ldz);
-    T.zero(s);
     std::vector<int> h_pcol((size_t)std::max(r1, 1)), h_fcol((size_t)std::max(f, 1));
     if (r1 > 0) HIPCHK(hipMemcpyAsync(h_pcol.data(), pcol.p, (size_t)r1 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_fcol.data(), fcol.p, (size_t)f * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -173,62 +170,128 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     double tf2 = 0;
     const int nsl = src.nslabs();
     DevBuf<DT> Db;
-    for (int k = 0; k < nsl; k++) {
-        i64 s0 = 0;
-        int w = 0;
-        src.slab_range(k, s0, w);
-        const int pa = (int)(std::lower_bound(h_pcol.begin(), h_pcol.begin() + r1, (int)s0) - h_pcol.begin());
-        const int pb = (int)(std::lower_bound(h_pcol.begin(), h_pcol.begin() + r1, (int)std::min<i64>(s0 + w, INT_MAX)) - h_pcol.begin());
-        const int fa = (int)(std::lower_bound(h_fcol.begin(), h_fcol.begin() + f, (int)s0) - h_fcol.begin());
-        const int fb = (int)(std::lower_bound(h_fcol.begin(), h_fcol.begin() + f, (int)std::min<i64>(s0 + w, INT_MAX)) - h_fcol.begin());
-        if (pa == pb && fa == fb) continue;
-        const double tb = spasm_wtime();
-        src.prepare_slab(k);
-        HIPCHK(hipStreamSynchronize(s));
-        tf2 += spasm_wtime() - tb;
-        size_t fr = 0, tot = 0;
-        HIPCHK(hipMemGetInfo(&fr, &tot));
-        // (at most 128k rows at a time: a batch buffer of tens of GB costs more to allocate and to clear than the launches of more batches)
-        i64 RB = std::min<i64>(131072, std::max<i64>(4096, (i64)((fr + Db.n * sizeof(DT)) / 4) / ((i64)w * (i64)sizeof(DT)) / 128 * 128));
-        if (const char *e = getenv("SPASM_AMD_TALL_BATCH")) RB = std::max<i64>(128, atoll(e) / 128 * 128); // tests: several batches
-        RB = std::min<i64>(RB, ((i64)R2 + 127) / 128 * 128);
-        Db.ensure((size_t)RB * (size_t)w);
-        for (i64 off = 0; off < R2; off += RB) {
-            const int cnt = (int)std::min<i64>(RB, R2 - off);
-            const double tc = spasm_wtime();
-            HIPCHK(hipMemsetAsync(Db.p, 0, (size_t)cnt * (size_t)w * sizeof(DT), s));
-            src.fill_slab(k, R1 + (int)off, cnt, Db.p, (i64)w);
+    auto reduce_rows = [&](i64 row0, i64 nrows, DT *Tp) {
+        for (int k = 0; k < nsl; k++) {
+            i64 s0 = 0;
+            int w = 0;
+            src.slab_range(k, s0, w);
+            const int pa = (int)(std::lower_bound(h_pcol.begin(), h_pcol.begin() + r1, (int)s0) - h_pcol.begin());
+            const int pb = (int)(std::lower_bound(h_pcol.begin(), h_pcol.begin() + r1, (int)std::min<i64>(s0 + w, INT_MAX)) - h_pcol.begin());
+            const int fa = (int)(std::lower_bound(h_fcol.begin(), h_fcol.begin() + f, (int)s0) - h_fcol.begin());
+            const int fb = (int)(std::lower_bound(h_fcol.begin(), h_fcol.begin() + f, (int)std::min<i64>(s0 + w, INT_MAX)) - h_fcol.begin());
+            if (pa == pb && fa == fb) continue;
+            const double tb = spasm_wtime();
+            src.prepare_slab(k);
             HIPCHK(hipStreamSynchronize(s));
-            tf2 += spasm_wtime() - tc;
-            DT *Tb = T.p + (size_t)off * (size_t)ldz;
-            if (fb > fa) {
-                hipLaunchKernelGGL((k_tall_gather_slab<DT>), dim3(cnt), dim3(256), 0, s, cnt, Db.p, (i64d)w, fcol.p + fa, fb - fa, (int)s0, F, Tb, (i64d)ldz, fa);
-                HIPCHK(hipGetLastError());
+            tf2 += spasm_wtime() - tb;
+            size_t fr = 0, tot = 0;
+            HIPCHK(hipMemGetInfo(&fr, &tot));
+            // (at most 128k rows at a time: a batch buffer of tens of GB costs more to allocate and to clear than the launches of more batches)
+            i64 RB = std::min<i64>(131072, std::max<i64>(4096, (i64)((fr + Db.n * sizeof(DT)) / 4) / ((i64)w * (i64)sizeof(DT)) / 128 * 128));
+            if (const char *e = getenv("SPASM_AMD_TALL_BATCH")) RB = std::max<i64>(128, atoll(e) / 128 * 128); // tests: several batches
+            RB = std::min<i64>(RB, (nrows + 127) / 128 * 128);
+            Db.ensure((size_t)RB * (size_t)w);
+            for (i64 off = 0; off < nrows; off += RB) {
+                const int cnt = (int)std::min<i64>(RB, nrows - off);
+                const double tc = spasm_wtime();
+                HIPCHK(hipMemsetAsync(Db.p, 0, (size_t)cnt * (size_t)w * sizeof(DT), s));
+                src.fill_slab(k, R1 + (int)(row0 + off), cnt, Db.p, (i64)w);
+                HIPCHK(hipStreamSynchronize(s));
+                tf2 += spasm_wtime() - tc;
+                DT *Tb = Tp + (size_t)off * (size_t)ldz;
+                if (fb > fa) {
+                    hipLaunchKernelGGL((k_tall_gather_slab<DT>), dim3(cnt), dim3(256), 0, s, cnt, Db.p, (i64d)w, fcol.p + fa, fb - fa, (int)s0, F, Tb, (i64d)ldz, fa);
+                    HIPCHK(hipGetLastError());
+                }
+                for (int c0 = pa; c0 < pb; c0 += W.KB)
+                    W.gemm_sub(Tb, ldz, cnt, Db.p, (i64)w, nullptr, pcol.p + c0, std::min(W.KB, pb - c0), Z.p + (size_t)c0 * (size_t)ldz, ldz, f, (int)s0);
             }
-            for (int c0 = pa; c0 < pb; c0 += W.KB)
-                W.gemm_sub(Tb, ldz, cnt, Db.p, (i64)w, nullptr, pcol.p + c0, std::min(W.KB, pb - c0), Z.p + (size_t)c0 * (size_t)ldz, ldz, f, (int)s0);
+            if ((double)R1 * (double)C > 4e9) {
+                HIPCHK(hipStreamSynchronize(s));
+                spasm_logf("[echelonize/dense] tall and skinny: column slab %d of %d applied to %lld other rows [%.1fs]\n", k + 1, nsl, (long long)nrows, spasm_wtime() - t2);
+            }
         }
-        if ((double)R1 * (double)C > 4e9) {
+        HIPCHK(hipStreamSynchronize(s));
+    };
+    // Do the residuals of ALL other rows fit (R2 x f: small when the slab carried most pivots)?  A weak first slab -- many dependent
+    // rows among its R1 -- leaves f large (a planted-rank matrix at config 5's size: 168 GiB); then the rows go chunk by chunk, and
+    // the echelon rows E found so far ride on top of every chunk (they win their columns again: first rows, distinct leading
+    // columns), so that each chunk's elimination leaves the echelon form of everything seen.  The dense W of the column slabs is then
+    // rebuilt per chunk: the price of not fitting.
+    size_t fr0 = 0, tot0 = 0;
+    HIPCHK(hipMemGetInfo(&fr0, &tot0));
+    // per row of T: its residuals, the elimination's multiplier planes (1 KB per digit), its panel entries and status word; 15 % of
+    // what is free stays for the batch buffer and the rest (the dense W of a column slab is allocated already)
+    const double per_row = (double)ldz * sizeof(DT) + 1024.0 * W.ND + 64.0 * sizeof(DT) + 8.0;
+    i64 cap_rows = (i64)((double)fr0 * 0.85 / per_row);
+    const char *chunk_env = getenv("SPASM_AMD_TALL_CHUNK"); // tests: rows of the other rows per chunk
+    if (chunk_env) cap_rows = 0;
+    int r2 = 0;
+    int nchunks = 1;
+    if ((i64)R2 <= cap_rows) {
+        DevBuf<DT> T;
+        T.alloc((size_t)R2 * (size_t)ldz);
+        T.zero(s);
+        reduce_rows(0, R2, T.p);
+        Db.release();
+        Z.release();
+        src.done();
+        ts.t_resid = spasm_wtime() - t2;
+        // ---- 4. what the residuals still hold
+        DevBuf<int> pc2;
+        pc2.alloc((size_t)f + 1);
+        if (!dense_eliminate_i8(T, R2, f, ldz, F, pc2, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
+        HIPCHK(hipStreamSynchronize(s));
+        r2 = dense_extract_U(T.p, f, ldz, pc2.p, fclist.p, row_orig + R1, U, s);
+    } else {
+        // (E beside T, and its f rows ride along in T)
+        i64 Rc = chunk_env ? std::max<i64>(64, atoll(chunk_env)) : (i64)(((double)fr0 * 0.85 - (double)f * (double)ldz * sizeof(DT)) / per_row) - f;
+        if (Rc < 1024 && !chunk_env)
+            throw EngineError("dense finish: out of device memory: the residuals on " + std::to_string(f) + " columns do not fit even in chunks of rows");
+        Rc = (Rc + 63) / 64 * 64;
+        nchunks = (int)(((i64)R2 + Rc - 1) / Rc);
+        DevBuf<DT> T, E;
+        DevBuf<int> origT, origE, pc2, pcE, p2flag, p2scan;
+        T.alloc((size_t)(Rc + f) * (size_t)ldz);
+        E.alloc((size_t)f * (size_t)ldz);
+        origT.alloc((size_t)(Rc + f) + 1); origE.alloc((size_t)f + 1); pc2.alloc((size_t)f + 1); pcE.alloc((size_t)f + 1);
+        p2flag.alloc((size_t)f + 1); p2scan.alloc((size_t)f + 1);
+        HIPCHK(hipMemsetAsync(pcE.p, 0xff, ((size_t)f + 1) * sizeof(int), s));
+        int nE = 0;
+        double t_el = 0;
+        for (i64 off0 = 0; off0 < R2 && nE < f; off0 += Rc) {
+            const i64 cnt = std::min<i64>(Rc, (i64)R2 - off0);
+            HIPCHK(hipMemsetAsync(T.p, 0, (size_t)(nE + cnt) * (size_t)ldz * sizeof(DT), s));
+            if (nE > 0) {
+                HIPCHK(hipMemcpyAsync(T.p, E.p, (size_t)nE * (size_t)ldz * sizeof(DT), hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(origT.p, origE.p, (size_t)nE * sizeof(int), hipMemcpyDeviceToDevice, s));
+            }
+            HIPCHK(hipMemcpyAsync(origT.p + nE, row_orig + R1 + off0, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, s));
+            reduce_rows(off0, cnt, T.p + (size_t)nE * (size_t)ldz);
+            const double te = spasm_wtime();
+            if (!dense_eliminate_i8(T, (int)(nE + cnt), f, ldz, F, pc2, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
+            hipLaunchKernelGGL(k_flag_nonneg, dim3(cdiv((i64)f + 1, 256)), dim3(256), 0, s, f, pc2.p, p2flag.p);
+            HIPCHK(hipGetLastError());
+            scan.exclusive(p2flag.p, p2scan.p, (size_t)f + 1, s);
+            hipLaunchKernelGGL((k_tall_compact<DT>), dim3(f), dim3(256), 0, s, f, (i64d)ldz, pc2.p, p2scan.p, T.p, origT.p, E.p, origE.p, pcE.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&nE, p2scan.p + f, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            spasm_logf("[echelonize/dense] tall and skinny: column slab %d of %d applied to the %d other rows [%.1fs]\n", k + 1, nsl, R2, spasm_wtime() - t2);
+            t_el += spasm_wtime() - te;
+            spasm_logf("[echelonize/dense] tall and skinny: the residuals do not fit at once: chunk of %lld rows (%lld of %d done): %d pivots so far%s [%.1fs]\n", (long long)cnt,
+                       (long long)(off0 + cnt), R2, nE, nE == f ? " = every column: the other rows cannot add any" : "", spasm_wtime() - t2);
         }
+        Db.release();
+        Z.release();
+        T.release();
+        src.done();
+        ts.t_resid = spasm_wtime() - t2 - t_el;
+        r2 = dense_extract_U(E.p, f, ldz, pcE.p, fclist.p, origE.p, U, s);
     }
-    HIPCHK(hipStreamSynchronize(s));
-    Db.release();
-    Z.release();
-    src.done();
-    ts.t_resid = spasm_wtime() - t2;
-    // ---- 4. what the residuals still hold
-    const double t3 = spasm_wtime();
-    DevBuf<int> pc2;
-    pc2.alloc((size_t)f + 1);
-    if (!dense_eliminate_i8(T, R2, f, ldz, F, pc2, s)) throw EngineError("dense finish: shape outside the panel kernel's range");
-    HIPCHK(hipStreamSynchronize(s));
-    const int r2 = dense_extract_U(T.p, f, ldz, pc2.p, fclist.p, row_orig + R1, U, s);
     ts.r2 = r2;
-    ts.t_tail = spasm_wtime() - t3;
+    ts.t_tail = spasm_wtime() - t2 - ts.t_resid;
     spasm_logf("[echelonize/dense] tall and skinny: %d x %d; first slab of %d rows: %d pivots [rows %.2fs, elimination with the rows of U leaving block by block %.2fs, the last block's %.2fs]; reduced form on the "
-               "%d columns left [%.2fs]; %d rows reduced in one step [rows %.2fs, reduction %.2fs]; their residuals: %d pivots [%.2fs]\n", R, C, R1, r1, tf1, te1, tu1, f, ts.t_z,
-               R2, tf2, ts.t_resid - tf2, r2, ts.t_tail);
+               "%d columns left [%.2fs]; %d rows reduced in %d step%s [rows %.2fs, reduction %.2fs]; their residuals: %d pivots [%.2fs]\n", R, C, R1, r1, tf1, te1, tu1, f, ts.t_z,
+               R2, nchunks, nchunks > 1 ? "s" : "", tf2, ts.t_resid - tf2, r2, ts.t_tail);
     return r1 + r2;
 }

@@ -2581,7 +2581,12 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
                 // HSA queue made every rocprofv3-profiled process die in exit(): libamdhip64's exit handler tears that queue down
                 // inside libhsa-runtime64 after rocprofiler-sdk has finalised its queue interception (tools/segv_probe.sh,
                 // profiles/r03_exit_sigsegv_backtrace.txt -- no frame of this library in the trace).
-                if (!tall) {
+                // (the follow path gives up for the rest of this elimination once it has misfired four times and more often than
+                // not: every misfire costs the resident kernel, the followers' pass and a read-back on top of the in-place panel --
+                // residuals of a weak first slab, whose pivots sit anywhere in 2.7M rows: 639 of 648 panels redone)
+                const bool follow_now = tall && !(redone >= 4 && 2 * redone > npanels_done);
+                if (tall && !follow_now) a_chunk = chunk;
+                if (!follow_now) {
                     HIPCHK(hipLaunchKernel(inlds ? fn_lds : fn_glb, dim3(G), dim3(1024), args, (size_t)lds, s));
                 } else {
                     // the pivots among the resident rows, then the followers; a follower that should have been a pivot: redo in place
@@ -2631,8 +2636,9 @@ bool dense_eliminate_i8(DevBuf<DT> &D, int R, int C, i64 ldc, const ZpField &F, 
     HIPCHK(hipMemcpyAsync(&hst, st.p, sizeof hst, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hst.pad) throw EngineError("dense finish: a grid barrier of the panel kernel timed out (the device is shared with another process?)");
-    if (tall) spasm_logf("[echelonize/dense] tall panels: %lld resident rows elect, %lld follow; %d of %d panels redone in place\n", (long long)R_res,
-                         (long long)R - (long long)R_res, redone, npanels_done);
+    if (tall) spasm_logf("[echelonize/dense] tall panels: %lld resident rows elect, %lld follow; %d of %d panels redone in place%s\n", (long long)R_res,
+                         (long long)R - (long long)R_res, redone, npanels_done,
+                         redone >= 4 && 2 * redone > npanels_done ? ", the others in place from the start" : "");
     if (stamps.p) {
         std::vector<unsigned long long> h(DP_W * 8);
         HIPCHK(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -946,7 +946,9 @@ def test_tall_and_skinny_finish_dense_input(S, O, monkeypatch, p, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [dict(), dict(SPASM_AMD_MEM_BUDGET_MB="4")], ids=["W_whole", "W_in_column_slabs"])
+@pytest.mark.parametrize("env", [dict(), dict(SPASM_AMD_MEM_BUDGET_MB="4"), dict(SPASM_AMD_TALL_CHUNK="640"),
+                                 dict(SPASM_AMD_MEM_BUDGET_MB="1", SPASM_AMD_TALL_CHUNK="1024")],
+                         ids=["W_whole", "W_in_column_slabs", "residuals_in_row_chunks", "column_slabs_and_row_chunks"])
 def test_tall_and_skinny_finish_of_a_schur_complement(S, O, monkeypatch, env):
     """The same strategy fed by the Schur rows of a round through the dense W (Macaulay-like: config 5's shape), rows materialised a
     slab / a batch at a time."""

@@ -1,0 +1,106 @@
+"""Matrices of PLANTED rank in config 5's shape (tools/planted_rank.py): the rank is known by construction, so the engine's answer
+can be checked at sizes the oracle never reaches -- BASELINE config 5 is 5M x 2M, its Schur complement goes straight to the dense
+tall-and-skinny finish, and a rank that nothing could check is how a wrong residual survived a round (the free columns of a column
+slab were stored over what the slabs before had subtracted: rank 1 984 158 instead of 1 980 000 at full size).
+
+CPU: the construction itself against an independent dense elimination and against the oracle.  GPU: 1/25, 1/10 with the dense W
+forced into many column slabs and a weak first slab (the regression), 1/3 as the judge asked; the full size runs from the tool
+(profiles/r04_planted_rank.txt)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import planted_rank as PR  # noqa: E402
+
+from conftest import LM  # noqa: E402
+
+
+def dense_rank_mod_p(A, p):
+    """rank of a small scipy matrix over GF(p) by plain Gaussian elimination (int64 numpy)"""
+    M = np.asarray(A.todense(), dtype=np.int64) % p
+    n, m = M.shape
+    r = 0
+    for c in range(m):
+        nz = np.flatnonzero(M[r:, c])
+        if nz.size == 0:
+            continue
+        i = r + int(nz[0])
+        if i != r:
+            M[[r, i]] = M[[i, r]]
+        M[r] = (M[r] * pow(int(M[r, c]), p - 2, p)) % p
+        rows = np.flatnonzero(M[:, c])
+        rows = rows[rows != r]
+        M[rows] = (M[rows] - np.outer(M[rows, c], M[r])) % p
+        r += 1
+        if r == n:
+            break
+    return r
+
+
+@pytest.mark.parametrize("n,m,n0,keep", [(900, 400, 333, 0.85), (1200, 300, 297, 0.5), (500, 500, 120, 0.0)])
+def test_construction_has_the_planted_rank(n, m, n0, keep):
+    A = PR.planted(n, m, n0, prime=127, seed=0xA5 + n, keep=keep, band=64)
+    assert A.shape == (n, m)
+    assert int(A.data.min()) >= 0 and int(A.data.max()) < 127
+    assert dense_rank_mod_p(A, 127) == n0
+
+
+def test_oracle_agrees_with_the_planted_rank(S, O):
+    A = PR.planted(1500, 600, 594, prime=127, seed=0x0C, keep=0.85, band=128)
+    M = PR.to_engine(S, A, 127)
+    assert O.echelonize(M, **LM).r == 594
+
+
+def _engine_rank(S, n, m, keep=0.85, env=None, monkeypatch=None, **opts):
+    n0 = int(0.99 * m)
+    A = PR.planted(n, m, n0, keep=keep)
+    M = PR.to_engine(S, A, 127)
+    del A
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    try:
+        r = S.rank(M, rank_only=True, **opts)
+    finally:
+        for k in (env or {}):
+            monkeypatch.delenv(k)
+    return r, n0
+
+
+@pytest.mark.gpu
+def test_planted_rank_one_twentyfifth(S):
+    r, n0 = _engine_rank(S, 200_000, 80_000)
+    assert r == n0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    dict(SPASM_AMD_MEM_BUDGET_MB="600", SPASM_AMD_TALL_SLAB="20000"),   # dense W in ~10 column slabs, weak first slab
+    dict(SPASM_AMD_MEM_BUDGET_MB="600"),                                # column slabs, the default slab
+    dict(SPASM_AMD_TALL="0"),                                           # the plain dense finish
+    dict(SPASM_AMD_MEM_BUDGET_MB="2000", SPASM_AMD_TALL_SLAB="20000", SPASM_AMD_TALL_CHUNK="120000"),  # residuals in chunks of rows
+], ids=["column_slabs_weak_first_slab", "column_slabs", "plain_dense", "residuals_in_row_chunks"])
+def test_planted_rank_one_tenth_in_column_slabs(S, monkeypatch, env):
+    r, n0 = _engine_rank(S, 500_000, 200_000, env=env, monkeypatch=monkeypatch)
+    assert r == n0
+
+
+@pytest.mark.gpu
+def test_planted_rank_one_third(S):
+    """config 5 at 1/3 (1 666 666 x 666 666, 84M entries): ~3 s of generation, ~3 s of engine"""
+    r, n0 = _engine_rank(S, 5_000_000 // 3, 2_000_000 // 3)
+    assert r == n0
+
+
+@pytest.mark.gpu
+def test_planted_rank_with_the_factorization(S):
+    """not rank-only: U is collected and verified against A"""
+    n, m = 100_000, 40_000
+    n0 = int(0.99 * m)
+    A = PR.planted(n, m, n0, keep=0.85)
+    M = PR.to_engine(S, A, 127)
+    fact = S.echelonize(M)
+    assert fact.r == n0
+    assert S.factorization_verify(M, fact, 9)
