@@ -162,7 +162,11 @@ bool spasm_factorization_verify(const struct spasm_csr *A, const struct spasm_lu
  * only has A: r rows i[] and r columns j[] whose r x r submatrix C is non-singular, shown by a vector y with y * C == x for a
  * challenge x the prover cannot choose -- x is drawn from SHA-256(hash, prime, r, i, j) (Fiat-Shamir; `hash` is the 32-byte digest
  * of the matrix file as spasm_triplet_load computes it): if C were singular a random x would lie in its row space with probability
- * <= 1/p.  Verification is host-side and O(nnz(A)); together with spasm_factorization_verify (rank(A) <= r) it pins the rank.
+ * <= 1/p -- PER CHALLENGE.  The struct SpaSM.jl mirrors holds one (x, y) pair, so that is all one certificate carries: a prover who
+ * may retry (other rows, other columns, another order -- each choice hashes to a new x) gets a singular C accepted after about p
+ * attempts, which is cheap for p = 127 or 65521.  The certificate is therefore evidence against ERRORS (a wrong rank out of a faulty
+ * run), not against an adversarial prover with a small prime; that needs k challenges with p^k >= 2^64, i.e. another struct.
+ * Verification is host-side and O(nnz(A)); together with spasm_factorization_verify (rank(A) <= r) it pins the rank.
  * Creation takes the pivotal rows and the pivot columns of `fact` and solves y * C == x on the device (C is echelonized with L,
  * then spasm_solve).  libspasm's on-disk format is not in the reference tree: save/load use a text format of their own
  * ("spasm-amd rank certificate v1", then r, prime, the hash in hex and r lines "i j x y"). ---- */

@@ -399,6 +399,16 @@ extern "C" SPASM_API bool spasm_rank_certificate_load(void *file, struct spasm_r
     int r = 0;
     long long prime = 0;
     if (fscanf(f, "%d %lld", &r, &prime) != 2 || r < 0) return false;
+    {
+        // r comes from the file: every one of its r lines takes 8 bytes at least ("i j x y\n"), so a count the rest of the file
+        // cannot hold is refused before anything is allocated for it
+        const long at = ftell(f);
+        if (at >= 0 && fseek(f, 0, SEEK_END) == 0) {
+            const long end = ftell(f);
+            if (fseek(f, at, SEEK_SET) != 0) return false;
+            if (end >= at && (long long)r * 8 > (long long)(end - at) + 8) return false;
+        }
+    }
     char hex[80];
     if (fscanf(f, "%79s", hex) != 1 || strlen(hex) != 64) return false;
     for (int k = 0; k < 32; k++) {

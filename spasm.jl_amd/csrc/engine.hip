@@ -3310,6 +3310,21 @@ struct spasm_lu *do_echelonize(const struct spasm_csr *A, struct echelonize_opts
     const double t0 = spasm_wtime();
     spasm_logf("[echelonize] Start on %d x %d matrix with %lld nnz\n", n, m, (long long)spasm_nnz(A));
     g_last_rounds.clear();
+    // Fields of echelonize_opts (reference src/SpaSM.jl:332, :339, :340, :342) this engine has no use for say so when they are set
+    // away from spasm_echelonize_init_opts' values: they tune libspasm's dense strategies (rows per dense block of its FFPACK
+    // calls; when its randomized low-rank mode starts and with which row weights) and the completion of L -- the dense finish
+    // here is one exact blocked elimination (panels of 64 columns, blocks of 1024), which has no such knobs, and L holds the
+    // multipliers of the pivotal and the eliminated rows as the rounds produced them.  The result does not depend on them.
+    {
+        struct echelonize_opts d0;
+        spasm_echelonize_init_opts(&d0);
+        if (opts->dense_block_size != d0.dense_block_size)
+            spasm_logf("[echelonize] option dense_block_size = %d ignored (the dense finish works in panels of 64 columns and blocks of 1024)\n", opts->dense_block_size);
+        if (opts->low_rank_ratio != d0.low_rank_ratio || opts->low_rank_start_weight != d0.low_rank_start_weight)
+            spasm_logf("[echelonize] options low_rank_ratio = %g / low_rank_start_weight = %g ignored (no randomized low-rank mode: the "
+                       "tall-and-skinny finish reduces every row exactly)\n", opts->low_rank_ratio, opts->low_rank_start_weight);
+        if (opts->complete != d0.complete) spasm_logf("[echelonize] option complete = %d ignored (L is returned as the rounds produced it; LU.complete stays false)\n", (int)opts->complete);
+    }
 
     hipStream_t stream = nullptr;
     HostU U;

@@ -204,3 +204,28 @@ def test_round0_pivots_without_the_cycle_free_search(S, O, monkeypatch, name, ki
     assert (r0["npiv"], r0["npiv_open"], r0["npiv_greedy"]) == (len(want), nopen, 0)
     assert pivots_of_first_round(fact, len(want)) == want
     assert pivots_of_first_round(olu, len(want)) == want
+
+
+def test_option_fields_without_an_equivalent_say_so(S, O):
+    """dense_block_size, low_rank_ratio, low_rank_start_weight and complete (reference src/SpaSM.jl:332, :339, :340, :342) tune
+    libspasm's dense strategies; the engine has no equivalent, so it says "ignored" once per call when they leave their defaults,
+    and the result is the one the defaults give."""
+    import ctypes as C
+
+    A = S.synth_csr(1, 400, 300, row_nnz=5, prime=42013, seed=0x09)
+    lines = []
+    cb = S.api._LOGFUNC(lambda s: lines.append(s.decode()) or 0)
+    slot = C.c_void_p.in_dll(S._abi.lib(), "logcallback")
+    prev = slot.value
+    slot.value = C.cast(cb, C.c_void_p).value
+    try:
+        base = S.echelonize(A, verbose=True)
+        assert not any("ignored" in x for x in lines), lines
+        del lines[:]
+        fact = S.echelonize(A, verbose=True, dense_block_size=64, low_rank_ratio=0.9, complete=True)
+    finally:
+        slot.value = prev
+    said = [x for x in lines if "ignored" in x]
+    assert len(said) == 3 and "dense_block_size = 64" in said[0] and "low_rank_ratio = 0.9" in said[1] and "complete = 1" in said[2], lines
+    assert fact.r == base.r == O.echelonize(A).r
+    assert np.asarray(fact.qinv).tolist() == np.asarray(base.qinv).tolist()

@@ -107,3 +107,12 @@ def test_certificate_created_on_the_device_verifies(S, O, tmp_path, kind, n, m, 
     assert S.certificate_rank_verify(B, digest, again)
     # rank(A) <= r is the other half: the reference's self-check of the factorization
     assert S.factorization_verify(B, fact, 9)
+
+
+def test_load_refuses_a_row_count_the_file_cannot_hold(S, tmp_path):
+    """r is read from the file: a count that the rest of the file has no room for is refused before memory is set aside for it"""
+    path = tmp_path / "huge.txt"
+    with open(path, "w") as f:
+        f.write("spasm-amd rank certificate v1\n%d %d\n%s\n" % (2_000_000_000, 42013, "00" * 32))
+        f.write("0 0 1 1\n")
+    assert S.rank_certificate_load(path) is None
