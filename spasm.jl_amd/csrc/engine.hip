@@ -4171,14 +4171,113 @@ struct spasm_csr *do_gesv(const struct spasm_lu *fact, const struct spasm_csr *B
 
 // first / step: only the free columns number first, first + step, ... (in ascending column order) get their kernel vector:
 // the unit of the multi-GPU kernel step (free columns are independent)
+struct spasm_csr *do_kernel_core(const struct spasm_csr *U, const int *qinv, int first, int step);
+
+// The part of U a kernel basis needs.  The kernel vector of free column j is -e_j + sum_a y_a e_{pivcol(a)} with
+//        y_a = U[a][j] - sum_{b != a} U[a][pivcol(b)] y_b,
+// so y_a can only be non-zero when row a holds an entry on a (selected) free column or on the pivot column of a row b that can:
+// the rows outside that closure have y = 0 for every free column and drop out, with the pivot columns they own (qinv = -2 below:
+// neither free nor a pivot of what is left).  For the factorizations whose U does not fit the device as one round (config 5 at
+// 1/3: 5.5e9 entries; the round's U has 32-bit offsets) the closure is what is solved instead -- a few rows when the kernel
+// vectors are sparse, all of U when they are not (then the limit stands).  Host side, all threads: one pass for the free columns,
+// then sweeps over the rows not yet in the closure until nothing changes.
+struct KernelReduced {
+    struct spasm_csr *U2 = nullptr;
+    std::vector<int> qinv2;
+    ~KernelReduced() { if (U2) spasm_csr_free(U2); }
+};
+
+void kernel_closure(const struct spasm_csr *U, const int *qinv, int first, int step, KernelReduced &out)
+{
+    const int r = U->n, m = U->m;
+    std::vector<unsigned char> sel((size_t)std::max(m, 1), 0);
+    {
+        int f = 0;
+        for (int j = 0; j < m; j++)
+            if (qinv[j] < 0 && qinv[j] != -2) {
+                if (f >= first && (f - first) % step == 0) sel[(size_t)j] = 1;
+                f++;
+            }
+    }
+    std::vector<unsigned char> need((size_t)std::max(r, 1), 0);
+    unsigned char *nd = need.data();
+    int any = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(| : any)
+    for (int a = 0; a < r; a++)
+        for (i64 k = U->p[a]; k < U->p[a + 1]; k++)
+            if (sel[(size_t)U->j[k]] && U->x[k] != 0) { __atomic_store_n(&nd[a], 1, __ATOMIC_RELAXED); any = 1; break; }
+    int sweeps = 0;
+    for (int changed = any; changed; sweeps++) {
+        changed = 0;
+        // (descending: in a U whose rows come in elimination order a row refers to later rows, and a chain closes in one sweep)
+#pragma omp parallel for schedule(static, 4096) reduction(| : changed)
+        for (int i = 0; i < r; i++) {
+            const int a = r - 1 - i;
+            if (__atomic_load_n(&nd[a], __ATOMIC_RELAXED)) continue;
+            for (i64 k = U->p[a]; k < U->p[a + 1]; k++) {
+                const int b = qinv[U->j[k]];
+                if (b >= 0 && b != a && U->x[k] != 0 && __atomic_load_n(&nd[b], __ATOMIC_RELAXED)) {
+                    __atomic_store_n(&nd[a], 1, __ATOMIC_RELAXED);
+                    changed = 1;
+                    break;
+                }
+            }
+        }
+    }
+    std::vector<int> newidx((size_t)std::max(r, 1), -1);
+    int r2 = 0;
+    for (int a = 0; a < r; a++) if (need[(size_t)a]) newidx[(size_t)a] = r2++;
+    out.qinv2.assign((size_t)std::max(m, 1), -1);
+    for (int j = 0; j < m; j++) {
+        const int a = qinv[j];
+        out.qinv2[(size_t)j] = a < 0 ? a : (newidx[(size_t)a] >= 0 ? newidx[(size_t)a] : -2);
+    }
+    std::vector<i64> cnt((size_t)r2 + 1, 0);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int a = 0; a < r; a++) {
+        if (!need[(size_t)a]) continue;
+        i64 c = 0;
+        for (i64 k = U->p[a]; k < U->p[a + 1]; k++) c += out.qinv2[(size_t)U->j[k]] != -2;
+        cnt[(size_t)newidx[(size_t)a] + 1] = c;
+    }
+    for (int t = 0; t < r2; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
+    out.U2 = spasm_csr_alloc(r2, m, std::max<i64>(cnt[(size_t)r2], 1), U->field->p, true);
+    if (!out.U2) throw EngineError("out of host memory");
+    for (int t = 0; t <= r2; t++) out.U2->p[t] = cnt[(size_t)t];
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int a = 0; a < r; a++) {
+        if (!need[(size_t)a]) continue;
+        i64 w = cnt[(size_t)newidx[(size_t)a]];
+        for (i64 k = U->p[a]; k < U->p[a + 1]; k++)
+            if (out.qinv2[(size_t)U->j[k]] != -2) { out.U2->j[w] = U->j[k]; out.U2->x[w] = U->x[k]; w++; }
+    }
+    spasm_logf("[kernel] closure of the free columns: %d of %d rows of U, %lld of %lld entries (%d sweeps)\n", r2, r, (long long)cnt[(size_t)r2], (long long)spasm_nnz(U), sweeps);
+}
+
 struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step = 1)
 {
     require_device();
     if (!fact || !fact->U || !fact->qinv) throw EngineError("spasm_kernel: incomplete factorization (U / qinv missing)");
     const struct spasm_csr *U = fact->U;
     check_input(U, "spasm_kernel");
+    if (first < 0 || step < 1) throw EngineError("spasm_amd_kernel_strided: bad (first, step)");
+    // a U too large for the device as one round goes through its closure (SPASM_AMD_KERNEL_REDUCE_NNZ, tests: the size from which)
+    i64 reduce_at = (i64)1 << 31;
+    if (const char *e = getenv("SPASM_AMD_KERNEL_REDUCE_NNZ")) reduce_at = atoll(e);
+    if (spasm_nnz(U) >= reduce_at) {
+        const double t0 = spasm_wtime();
+        KernelReduced red;
+        kernel_closure(U, fact->qinv, first, step, red);
+        spasm_logf("[kernel] closure found in %.2fs\n", spasm_wtime() - t0);
+        return do_kernel_core(red.U2, red.qinv2.data(), first, step);
+    }
+    return do_kernel_core(U, fact->qinv, first, step);
+}
+
+// qinv[j] = row of U with its pivot on column j, -1: free column, -2: a pivot column of a row that is not part of U (kernel_closure)
+struct spasm_csr *do_kernel_core(const struct spasm_csr *U, const int *qinv, int first, int step)
+{
     const int r = U->n, m = U->m;
-    const int *qinv = fact->qinv;
     const i64 prime = U->field->p;
     const double t0 = spasm_wtime();
     spasm_logf("[kernel] start. U is %d x %d (%lld nnz). Transposing U\n", r, m, (long long)spasm_nnz(U));
@@ -4197,11 +4296,10 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
     std::vector<int> h_lab((size_t)std::max(r, 1)), h_rowsrc((size_t)std::max(r, 1)), h_free;
     for (int a = 0; a < r; a++) h_lab[(size_t)a] = r - 1 - idx_of[(size_t)a];
     for (int t = 0; t < r; t++) h_rowsrc[(size_t)(r - 1 - t)] = pc[(size_t)perm[(size_t)t]]; // column of pivot ridx
-    if (first < 0 || step < 1) throw EngineError("spasm_amd_kernel_strided: bad (first, step)");
     {
         int f = 0;
         for (int j = 0; j < m; j++)
-            if (qinv[j] < 0) {
+            if (qinv[j] < 0 && qinv[j] != -2) {
                 if (f >= first && (f - first) % step == 0) h_free.push_back(j);
                 f++;
             }
@@ -4253,9 +4351,17 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
         HIPCHK(hipGetLastError());
     }
     R->want_idx = true; // the kernel vectors are assembled from (pivot index, multiplier)
+    HIPCHK(hipStreamSynchronize(s));
+    const double t_rows = spasm_wtime();
     R->build_U(T, rowsrc.p);
+    HIPCHK(hipStreamSynchronize(s));
+    const double t_buildu = spasm_wtime();
     R->prepare_uinv(nfree);
-    R->solve_phase(T, freecol.p, nullptr, nfree, 4 * spasm_nnz(U));
+    // (the record pool: a guess that grows when a solve overflows it.  4 nnz(U) was the guess -- 160 GB of pool for the U of config 5
+    // at 1/5, 3.4 of the step's 4.5 s spent allocating it for kernel vectors of one or two entries)
+    R->solve_phase(T, freecol.p, nullptr, nfree, std::min<i64>(4 * spasm_nnz(U), std::max<i64>((i64)1 << 24, 1024 * (i64)nfree)));
+    HIPCHK(hipStreamSynchronize(s));
+    const double t_solve = spasm_wtime();
     // assemble K: row f = {(free column, -1)} U {(column of pivot ridx, y_ridx)}
     DevBuf<i64d> klen, kstart;
     klen.alloc((size_t)nfree + 1);
@@ -4282,8 +4388,8 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
         HIPCHK(hipStreamSynchronize(s));
         for (i64 q = 0; q < ktot; q++) { K->j[q] = ent[(size_t)q].x; K->x[q] = ent[(size_t)q].y; }
     }
-    spasm_logf("[kernel] pivot order %.2fs, U to the device %.2fs, transpose %.2fs, solves and K %.2fs\n", t_order - t0, t_upload - t_order,
-               t_transpose - t_upload, spasm_wtime() - t_transpose);
+    spasm_logf("[kernel] pivot order %.2fs, U to the device %.2fs, transpose %.2fs, rows of the transposed system %.2fs, its U %.2fs, solves %.2fs, K %.2fs\n", t_order - t0,
+               t_upload - t_order, t_transpose - t_upload, t_rows - t_transpose, t_buildu - t_rows, t_solve - t_buildu, spasm_wtime() - t_solve);
     spasm_logf("[kernel] done in %.1fs. NNZ(K) = %lld\n", spasm_wtime() - t0, (long long)spasm_nnz(K));
     return K;
 }

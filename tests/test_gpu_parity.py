@@ -350,6 +350,44 @@ def test_kernel_of_a_strided_subset_of_the_free_columns(S):
         assert S.CSR(ptr).rows() == K[first::step]
 
 
+@pytest.mark.parametrize("kind,n,m,kw,prime", [
+    (0, 900, 1100, dict(density=4e-3), 42013),          # a random matrix: the closure is most of U
+    (2, 3000, 1200, dict(row_nnz=30), 127),             # Macaulay-like: dense tail, sparse kernel
+    (1, 2000, 2600, dict(row_nnz=3), 65521),            # very sparse: many rows outside the closure
+    (0, 300, 500, dict(density=2e-3), 42013),           # empty columns: kernel vectors of one entry, closure nearly empty
+])
+def test_kernel_through_the_closure_of_the_free_columns(S, O, monkeypatch, kind, n, m, kw, prime):
+    """A U too large for the device as one round (32-bit offsets: 2^32 entries) is reduced on the host to the rows a kernel vector can
+    be non-zero on (kernel_closure, engine.hip) and the same solve runs on what is left.  SPASM_AMD_KERNEL_REDUCE_NNZ=0 sends
+    every U through that path: the basis must be the one the whole U gives, vector for vector, and the oracle's."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xC105, **kw)
+    fact = S.echelonize(A, **LM)
+    whole = S.kernel(fact).rows()
+    monkeypatch.setenv("SPASM_AMD_KERNEL_REDUCE_NNZ", "0")
+    try:
+        K = S.kernel(fact)
+        lib = S._abi.lib()
+        parts = []
+        for first in range(3):
+            ptr = lib.spasm_amd_kernel_strided(fact.data, first, 3)
+            assert ptr, S._abi.last_error()
+            parts.append(S.CSR(ptr).rows())
+    finally:
+        monkeypatch.delenv("SPASM_AMD_KERNEL_REDUCE_NNZ")
+    rows = K.rows()
+    assert len(rows) == A.m - fact.r
+    assert rows == whole
+    assert rows == O.kernel(O.echelonize(A, **LM)).rows()
+    for first in range(3):
+        assert parts[first] == whole[first::3]             # the closure of a SUBSET of the free columns
+    # A * k^T == 0, exact integers
+    Arows = A.rows()
+    for k in rows[:: max(1, len(rows) // 40)]:
+        kd = dict(k)
+        for row in Arows[:: max(1, len(Arows) // 200)]:
+            assert sum(v * kd.get(c, 0) for c, v in row) % prime == 0
+
+
 def test_rref_of_a_multi_round_factorization(S, O):
     """U of several sparse rounds plus a dense tail (config-2 style, scaled down): R must have no entry on a foreign pivot
     column, span the same space (verify), and reproduce the kernel through the textbook formula k[piv(a)] = R[a][j]."""
