@@ -38,7 +38,7 @@ SCATTER_KERNEL_PREFIX = ["k_scatter<8,", "k_scatter<9,", "k_scatter<10,", "k_sca
                          "k_scatter<14,", None]
 # streaming twin of class c (stats classes 8 .. 14): k_wstream<LOGT = 8 + c, ...>
 STREAM_KERNEL_PREFIX = [f"k_wstream<{8 + c}," for c in range(7)]
-TRAFFIC_FILES = ["r03_final_traffic.json", "r02_final_traffic.json", "r01_final_traffic.json"]  # newest first: PMC passes of tools/final_profile.sh
+TRAFFIC_FILES = ["r04_final_traffic.json", "r03_final_traffic.json", "r02_final_traffic.json", "r01_final_traffic.json"]  # newest first: PMC passes of tools/final_profile.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 

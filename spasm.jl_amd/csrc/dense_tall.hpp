@@ -62,6 +62,34 @@ template <typename DT> struct TallWork {
     }
 };
 
+// Z = the reduced form of r1 echelon rows on f columns without pivot: row t of the echelon form is row prow[t] of D (leading
+// dimension ldc), its pivot (a 1) on column pcol[t], and it holds nothing on the pivot columns of the rows BEFORE it (pcol[s], s < t);
+// Z_t = u_t[fcol] - sum_{s > t} u_t[pcol_s] Z_s.  A blocked back substitution: blocks of 1024 pivots against everything behind them on
+// the int8 GEMM, 64 at a time inside a block.  (Also the dense part of spasm_kernel's basis: engine.hip, kernel_dense_rhs.)
+template <typename DT>
+void tall_reduced_form(TallWork<DT> &W, const DT *D, i64 ldc, int r1, const int *prow, const int *pcol, const int *fcol, int f, DT *Z, i64 ldz, const ZpField &F, hipStream_t s)
+{
+    if (r1 <= 0 || f <= 0) return;
+    hipLaunchKernelGGL((k_tall_gather_cols<DT>), dim3(r1), dim3(256), 0, s, r1, prow, D, (i64d)ldc, fcol, f, Z, (i64d)ldz);
+    HIPCHK(hipGetLastError());
+    const int OB = W.KB, IB = 64;
+    for (int b1 = r1; b1 > 0;) {
+        const int b0 = std::max(0, (b1 - 1) / OB * OB), nb = b1 - b0;
+        // rows b0 .. b1 against everything behind the block
+        for (int s0 = b1; s0 < r1; s0 += OB)
+            W.gemm_sub(Z + (size_t)b0 * (size_t)ldz, ldz, nb, D, ldc, prow + b0, pcol + s0, std::min(OB, r1 - s0), Z + (size_t)s0 * (size_t)ldz, ldz, f);
+        // inside the block: 64 pivots at a time, the later ones of the block through the GEMM, then the back substitution
+        for (int i1 = b1; i1 > b0;) {
+            const int i0 = std::max(b0, (i1 - 1) / IB * IB), ni = i1 - i0;
+            if (i1 < b1) W.gemm_sub(Z + (size_t)i0 * (size_t)ldz, ldz, ni, D, ldc, prow + i0, pcol + i1, b1 - i1, Z + (size_t)i1 * (size_t)ldz, ldz, f);
+            hipLaunchKernelGGL((k_tall_backsub<DT>), dim3(cdiv(f, 16)), dim3(256), 0, s, i0, ni, f, F, D, (i64d)ldc, prow, pcol, Z, (i64d)ldz);
+            i1 = i0;
+        }
+        HIPCHK(hipGetLastError());
+        b1 = b0;
+    }
+}
+
 // rows per slab that is eliminated whole: enough to carry every pivot a remainder of C columns can have, with some slack for
 // dependent rows.  SPASM_AMD_TALL_SLAB (tests): rows of the first slab.
 inline int tall_first_slab(int R, int C)
@@ -136,26 +164,7 @@ int dense_finish_tall(RowSource &src, int R, int C, i64 ldc, const int *clist, c
     DevBuf<DT> Z;
     Z.alloc((size_t)std::max(r1, 1) * (size_t)ldz);
     TallWork<DT> W(F, s);
-    if (r1 > 0) {
-        hipLaunchKernelGGL((k_tall_gather_cols<DT>), dim3(r1), dim3(256), 0, s, r1, prow.p, D1.p, (i64d)ldc, fcol.p, f, Z.p, (i64d)ldz);
-        HIPCHK(hipGetLastError());
-        const int OB = W.KB, IB = 64;
-        for (int b1 = r1; b1 > 0;) {
-            const int b0 = std::max(0, (b1 - 1) / OB * OB), nb = b1 - b0;
-            // rows b0 .. b1 against everything behind the block
-            for (int s0 = b1; s0 < r1; s0 += OB)
-                W.gemm_sub(Z.p + (size_t)b0 * (size_t)ldz, ldz, nb, D1.p, ldc, prow.p + b0, pcol.p + s0, std::min(OB, r1 - s0), Z.p + (size_t)s0 * (size_t)ldz, ldz, f);
-            // inside the block: 64 pivots at a time, the later ones of the block through the GEMM, then the back substitution
-            for (int i1 = b1; i1 > b0;) {
-                const int i0 = std::max(b0, (i1 - 1) / IB * IB), ni = i1 - i0;
-                if (i1 < b1) W.gemm_sub(Z.p + (size_t)i0 * (size_t)ldz, ldz, ni, D1.p, ldc, prow.p + i0, pcol.p + i1, b1 - i1, Z.p + (size_t)i1 * (size_t)ldz, ldz, f);
-                hipLaunchKernelGGL((k_tall_backsub<DT>), dim3(cdiv(f, 16)), dim3(256), 0, s, i0, ni, f, F, D1.p, (i64d)ldc, prow.p, pcol.p, Z.p, (i64d)ldz);
-                i1 = i0;
-            }
-            HIPCHK(hipGetLastError());
-            b1 = b0;
-        }
-    }
+    if (r1 > 0) tall_reduced_form<DT>(W, D1.p, ldc, r1, prow.p, pcol.p, fcol.p, f, Z.p, ldz, F, s);
     HIPCHK(hipStreamSynchronize(s));
     D1.release();
     ts.t_z = spasm_wtime() - t1;

@@ -636,6 +636,11 @@ struct Round {
         S.len.ensure((size_t)nrows + 1);
         S.lead.ensure((size_t)nrows + 1);
         S.orig.ensure((size_t)nrows + 1);
+        // (what run_solve would otherwise allocate on its first use, between two launches of a round's timed step)
+        rstart.ensure((size_t)nrows + 1);
+        rlen.ensure((size_t)nrows + 1);
+        wreject_list.ensure((size_t)nrows + 1);
+        own_ctr.ensure((size_t)NPOOL * POOL_STRIDE);
     }
 
     void alloc_big()
@@ -1256,11 +1261,15 @@ struct Round {
     }
 
     // sum of the NCTR statistic copies (synchronises)
-    RoundCounters read_counters(const RoundCounters *from = nullptr)
+    // (total_bound_of: also fetch the total of the bounds of that many rows, s_total_bound, in the same round trip)
+    RoundCounters read_counters(const RoundCounters *from = nullptr, int total_bound_of = -1)
     {
         std::vector<RoundCounters> h(NCTR);
+        i64d tot = 0;
         HIPCHK(hipMemcpyAsync(h.data(), from ? from : ctr.p, NCTR * sizeof(RoundCounters), hipMemcpyDeviceToHost, stream));
+        if (total_bound_of >= 0) HIPCHK(hipMemcpyAsync(&tot, sstart.p + total_bound_of, sizeof(i64d), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        if (total_bound_of >= 0) s_total_bound = tot;
         RoundCounters c = h[0];
         for (int i = 1; i < NCTR; i++) {
             c.applications += h[i].applications;
@@ -1298,8 +1307,8 @@ struct Round {
             alloc_solve(nrows, pool);
             run_solve(M, rows, self_idx, nrows);
             run_bounds(nrows);
-            const RoundCounters c = read_counters();
-            const i64 tot = fetch_total_bound(nrows); // synchronises
+            const RoundCounters c = read_counters(nullptr, nrows); // the counters and the total of the bounds: one round trip
+            const i64 tot = s_total_bound;
             if (c.lpool_overflow) {
                 if (pool >= max_pool) return -1;
                 pool = std::min<i64>(std::max<i64>(pool * 2, (i64)(pool_used() * 5 / 4) + 1024), max_pool);
@@ -4254,6 +4263,238 @@ void kernel_closure(const struct spasm_csr *U, const int *qinv, int first, int s
     spasm_logf("[kernel] closure of the free columns: %d of %d rows of U, %lld of %lld entries (%d sweeps)\n", r2, r, (long long)cnt[(size_t)r2], (long long)spasm_nnz(U), sweeps);
 }
 
+#include "kernel_dense.hpp"
+
+// spasm_kernel through a dense right-hand side (kernel_dense.hpp): every free column at once, the dense tail of U on the int8 GEMM,
+// the sparse rows level by level.  For primes below 2^16 (the element types of the dense finish).  dense_tail_rows < 0: chosen by
+// density.  Returns NULL when Y (r x free columns) or the dense tail do not fit the device: the caller falls back.
+template <typename DT>
+struct spasm_csr *kernel_dense_rhs(const struct spasm_csr *U, const int *qinv, int first, int step, i64 dense_tail_rows)
+{
+    const int r = U->n, m = U->m;
+    const i64 prime = U->field->p;
+    const ZpField F = zp_field_make(prime);
+    const double t_start = spasm_wtime();
+    spasm_logf("[kernel] start. U is %d x %d (%lld nnz). All free columns at once: a dense right-hand side\n", r, m, (long long)spasm_nnz(U));
+    std::vector<int> pc;
+    const std::vector<int> perm = pivot_topological_order(U, qinv, "spasm_kernel", pc);
+    std::vector<int> pos_of_row((size_t)std::max(r, 1), 0), pivcol_of_pos((size_t)std::max(r, 1), 0);
+    for (int t = 0; t < r; t++) { pos_of_row[(size_t)perm[(size_t)t]] = t; pivcol_of_pos[(size_t)t] = pc[(size_t)perm[(size_t)t]]; }
+    std::vector<int> h_free, fidx((size_t)std::max(m, 1), -1);
+    {
+        int f = 0;
+        for (int j = 0; j < m; j++)
+            if (qinv[j] < 0 && qinv[j] != -2) {
+                if (f >= first && (f - first) % step == 0) { fidx[(size_t)j] = (int)h_free.size(); h_free.push_back(j); }
+                f++;
+            }
+    }
+    const int nf = (int)h_free.size();
+    if (nf == 0) {
+        struct spasm_csr *K = spasm_csr_alloc(0, m, 1, prime, true);
+        if (!K) throw EngineError("out of host memory");
+        K->p[0] = 0;
+        return K;
+    }
+    const i64 ldz = ((i64)nf + 63) / 64 * 64;
+    size_t fr = 0, tot_mem = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot_mem));
+    if ((double)std::max(r, 1) * (double)ldz * sizeof(DT) > 0.4 * (double)fr) return nullptr;
+    // ---- the dense tail: the longest run of last positions that is dense enough to be worth a dense block (any run is CORRECT: a
+    // row only refers to pivots behind it, so the rows of a tail refer to the tail and to free columns only)
+    int t0 = r;
+    {
+        const double budget = 0.35 * (double)fr;
+        if (dense_tail_rows >= 0) t0 = r - (int)std::min<i64>(dense_tail_rows, r);
+        else {
+            // The rows of a dense finish come last in U and hold nearly all of its entries: take the shortest tail that holds 99 %
+            // (then 90, 75, 50 %) of the entries of U, provided it IS dense (a twentieth of its triangle + free columns) and fits.
+            // (Per-row rules fail on the residual rows of a tall finish, which are short and still belong to the tail.)
+            std::vector<double> cum((size_t)r + 1, 0.0); // cum[t] = entries of the positions t .. r-1
+            for (int t = r - 1; t >= 0; t--) { const int a = perm[(size_t)t]; cum[(size_t)t] = cum[(size_t)t + 1] + (double)(U->p[a + 1] - U->p[a]); }
+            const double cover[4] = {0.99, 0.90, 0.75, 0.50};
+            for (int q = 0; q < 4 && t0 == r; q++) {
+                int lo = 0, hi = r; // the largest t with cum[t] >= cover * total (cum is non-increasing in t)
+                while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (cum[(size_t)mid] >= cover[q] * cum[0]) lo = mid; else hi = mid - 1; }
+                const double rows = (double)(r - lo);
+                if (rows >= 256 && cum[(size_t)lo] >= 0.05 * rows * (0.5 * rows + nf) && rows * (rows + nf + 64) * sizeof(DT) <= budget) t0 = lo;
+            }
+        }
+        const double rows = (double)(r - t0);
+        if (rows * (rows + nf + 64) * sizeof(DT) > budget) return nullptr;
+    }
+    const int rd = r - t0;
+    hipStream_t s = nullptr;
+    DevBuf<DT> Y;
+    Y.alloc((size_t)std::max(r, 1) * (size_t)ldz);
+    Y.zero(s);
+    DevBuf<int> d_qinv, d_pos, d_fidx;
+    d_qinv.alloc((size_t)m + 1); d_pos.alloc((size_t)r + 1); d_fidx.alloc((size_t)m + 1);
+    HIPCHK(hipMemcpyAsync(d_qinv.p, qinv, (size_t)m * sizeof(int), hipMemcpyHostToDevice, s));
+    if (r > 0) HIPCHK(hipMemcpyAsync(d_pos.p, pos_of_row.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_fidx.p, fidx.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, s));
+    const double t_prep = spasm_wtime();
+    double t_dense_rows = t_prep, t_z = t_prep;
+    if (rd > 0) {
+        // D1[k][0 .. rd) = the pivot columns of the tail in position order (the pivot of row k on column k), [rd, rd + nf) = the free columns
+        const i64 ldc = ((i64)rd + nf + 63) / 64 * 64;
+        DevBuf<DT> D1;
+        D1.alloc((size_t)rd * (size_t)ldc);
+        D1.zero(s);
+        const i64 CH = (i64)1 << 28; // entries per chunk of rows on their way to the device
+        std::vector<i64> hptr;
+        std::vector<int> hj, hx;
+        DevBuf<i64d> dptr;
+        DevBuf<int> dj, dx;
+        // (rows that lie one behind the other in U -- the usual case: U in elimination order -- go to the device from where they are)
+        bool contig = true;
+        for (int t = t0; t < r && contig; t++) contig = perm[(size_t)t] == perm[(size_t)t0] + (t - t0);
+        for (int ta = t0; ta < r;) {
+            int tb = ta;
+            i64 ne = 0;
+            while (tb < r) {
+                const int a = perm[(size_t)tb];
+                const i64 len = U->p[a + 1] - U->p[a];
+                if (tb > ta && ne + len > CH) break;
+                ne += len;
+                tb++;
+            }
+            const int nk = tb - ta;
+            hptr.assign((size_t)nk + 1, 0);
+            for (int k = 0; k < nk; k++) { const int a = perm[(size_t)(ta + k)]; hptr[(size_t)k + 1] = hptr[(size_t)k] + (U->p[a + 1] - U->p[a]); }
+            const int *src_j = nullptr, *src_x = nullptr;
+            if (contig) {
+                const i64 base = U->p[perm[(size_t)ta]];
+                src_j = U->j + base; src_x = U->x + base;
+            } else {
+                hj.resize((size_t)std::max<i64>(ne, 1)); hx.resize((size_t)std::max<i64>(ne, 1));
+#pragma omp parallel for schedule(dynamic, 64)
+                for (int k = 0; k < nk; k++) {
+                    const int a = perm[(size_t)(ta + k)];
+                    const i64 len = U->p[a + 1] - U->p[a];
+                    memcpy(hj.data() + hptr[(size_t)k], U->j + U->p[a], (size_t)len * sizeof(int));
+                    memcpy(hx.data() + hptr[(size_t)k], U->x + U->p[a], (size_t)len * sizeof(int));
+                }
+                src_j = hj.data(); src_x = hx.data();
+            }
+            dptr.ensure((size_t)nk + 1); dj.ensure((size_t)std::max<i64>(ne, CH) + 1); dx.ensure((size_t)std::max<i64>(ne, CH) + 1);
+            HIPCHK(hipMemcpyAsync(dptr.p, hptr.data(), ((size_t)nk + 1) * sizeof(i64), hipMemcpyHostToDevice, s));
+            if (ne > 0) {
+                HIPCHK(hipMemcpyAsync(dj.p, src_j, (size_t)ne * sizeof(int), hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemcpyAsync(dx.p, src_x, (size_t)ne * sizeof(int), hipMemcpyHostToDevice, s));
+            }
+            hipLaunchKernelGGL((k_kd_dense_rows<DT>), dim3(nk), dim3(256), 0, s, nk, ta - t0, dptr.p, dj.p, dx.p, d_qinv.p, d_pos.p, d_fidx.p, t0, rd, D1.p, (i64d)ldc);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s)); // (the staging vectors are reused)
+            ta = tb;
+        }
+        t_dense_rows = spasm_wtime();
+        DevBuf<int> prow, fcol; // (prow = pcol = 0 .. rd-1)
+        prow.alloc((size_t)rd + 1); fcol.alloc((size_t)nf + 1);
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(rd, 256)), dim3(256), 0, s, rd, prow.p);
+        hipLaunchKernelGGL(k_iota_from, dim3(cdiv(nf, 256)), dim3(256), 0, s, nf, rd, fcol.p);
+        HIPCHK(hipGetLastError());
+        TallWork<DT> W(F, s);
+        tall_reduced_form<DT>(W, D1.p, ldc, rd, prow.p, prow.p, fcol.p, nf, Y.p + (size_t)t0 * (size_t)ldz, ldz, F, s);
+        HIPCHK(hipStreamSynchronize(s));
+        t_z = spasm_wtime();
+    }
+    // ---- the sparse rows: positions [0, t0), level by level (level 0: rows that refer to no other sparse row)
+    int nlev = 0;
+    if (t0 > 0) {
+        std::vector<int> lev((size_t)t0, 0);
+        std::vector<i64> eptr((size_t)t0 + 1, 0);
+        for (int t = t0 - 1; t >= 0; t--) { // (descending: a row refers to positions behind it)
+            const int a = perm[(size_t)t];
+            int lv = 0;
+            i64 n = 0;
+            for (i64 k = U->p[a]; k < U->p[a + 1]; k++) {
+                const int c = U->j[k];
+                const int b = qinv[c];
+                if (b == a || U->x[k] == 0) continue;
+                if (b >= 0) { const int pos = pos_of_row[(size_t)b]; if (pos < t0) lv = std::max(lv, lev[(size_t)pos] + 1); n++; }
+                else if (fidx[(size_t)c] >= 0) n++;
+            }
+            lev[(size_t)t] = lv;
+            eptr[(size_t)t + 1] = n;
+            nlev = std::max(nlev, lv + 1);
+        }
+        for (int t = 0; t < t0; t++) eptr[(size_t)t + 1] += eptr[(size_t)t];
+        const i64 ne = eptr[(size_t)t0];
+        // (a U whose dense rows did not end up in the tail would be solved row after row here: hours.  Not this path's case.)
+        if ((double)ne * (double)nf > 4e14 || (nlev > (1 << 20) && (double)ne > 1e9)) return nullptr;
+        std::vector<int2> hent((size_t)std::max<i64>(ne, 1));
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (int t = 0; t < t0; t++) {
+            const int a = perm[(size_t)t];
+            i64 w = eptr[(size_t)t];
+            for (i64 k = U->p[a]; k < U->p[a + 1]; k++) {
+                const int c = U->j[k];
+                const int b = qinv[c];
+                if (b == a || U->x[k] == 0) continue;
+                if (b >= 0) hent[(size_t)w++] = make_int2(pos_of_row[(size_t)b], U->x[k]);
+                else if (fidx[(size_t)c] >= 0) hent[(size_t)w++] = make_int2(-1 - fidx[(size_t)c], U->x[k]);
+            }
+        }
+        std::vector<int> lstart((size_t)nlev + 1, 0), order((size_t)t0);
+        for (int t = 0; t < t0; t++) lstart[(size_t)lev[(size_t)t] + 1]++;
+        for (int l = 0; l < nlev; l++) lstart[(size_t)l + 1] += lstart[(size_t)l];
+        {
+            std::vector<int> at(lstart.begin(), lstart.end() - 1);
+            for (int t = 0; t < t0; t++) order[(size_t)at[(size_t)lev[(size_t)t]]++] = t;
+        }
+        DevBuf<i64d> dptr;
+        DevBuf<int2> dent;
+        DevBuf<int> dord;
+        dptr.alloc((size_t)t0 + 1); dent.alloc((size_t)ne + 1); dord.alloc((size_t)t0 + 1);
+        HIPCHK(hipMemcpyAsync(dptr.p, eptr.data(), ((size_t)t0 + 1) * sizeof(i64), hipMemcpyHostToDevice, s));
+        if (ne > 0) HIPCHK(hipMemcpyAsync(dent.p, hent.data(), (size_t)ne * sizeof(int2), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dord.p, order.data(), (size_t)t0 * sizeof(int), hipMemcpyHostToDevice, s));
+        const int ctiles = cdiv(nf, 1024);
+        for (int l = 0; l < nlev; l++) {
+            const int cnt = lstart[(size_t)l + 1] - lstart[(size_t)l];
+            if (cnt == 0) continue;
+            hipLaunchKernelGGL((k_kd_level<DT>), dim3(cnt, ctiles), dim3(256), 0, s, cnt, dord.p + lstart[(size_t)l], dptr.p, dent.p, F, Y.p, (i64d)ldz, nf);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    const double t_sparse = spasm_wtime();
+    // ---- K = Y transposed, compacted
+    const int nchunks = std::max(1, cdiv(r, KD_CHUNK));
+    DevBuf<i64d> cnt, off;
+    DevBuf<int> d_pcp, d_free;
+    const size_t ncnt = (size_t)nf * (size_t)nchunks;
+    cnt.alloc(ncnt + 1); off.alloc(ncnt + 1); d_pcp.alloc((size_t)r + 1); d_free.alloc((size_t)nf + 1);
+    HIPCHK(hipMemsetAsync(cnt.p + ncnt, 0, sizeof(i64d), s));
+    if (r > 0) HIPCHK(hipMemcpyAsync(d_pcp.p, pivcol_of_pos.data(), (size_t)r * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_free.p, h_free.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL((k_kd_count<DT>), dim3(cdiv(nf, 256), nchunks), dim3(256), 0, s, r, nf, Y.p, (i64d)ldz, cnt.p, nchunks);
+    HIPCHK(hipGetLastError());
+    Scanner scan;
+    scan.exclusive(cnt.p, off.p, ncnt + 1, s);
+    std::vector<i64d> h_off(ncnt + 1);
+    HIPCHK(hipMemcpyAsync(h_off.data(), off.p, (ncnt + 1) * sizeof(i64d), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const i64 ktot = h_off[ncnt];
+    DevBuf<int> Kj, Kx;
+    Kj.alloc((size_t)ktot + 1); Kx.alloc((size_t)ktot + 1);
+    hipLaunchKernelGGL((k_kd_fill<DT>), dim3(cdiv(nf, 256), nchunks), dim3(256), 0, s, r, nf, Y.p, (i64d)ldz, off.p, nchunks, d_pcp.p, d_free.p, Kj.p, Kx.p);
+    HIPCHK(hipGetLastError());
+    struct spasm_csr *K = spasm_csr_alloc(nf, m, std::max<i64>(ktot, 1), prime, true);
+    if (!K) throw EngineError("out of host memory");
+    for (int i = 0; i <= nf; i++) K->p[i] = i < nf ? h_off[(size_t)i * (size_t)nchunks] : ktot;
+    if (ktot > 0) {
+        HIPCHK(hipMemcpyAsync(K->j, Kj.p, (size_t)ktot * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(K->x, Kx.p, (size_t)ktot * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    spasm_logf("[kernel] pivot order and free columns %.2fs; dense tail of %d rows: to the device %.2fs, reduced form %.2fs; %d sparse rows in %d levels %.2fs; K %.2fs\n",
+               t_prep - t_start, rd, t_dense_rows - t_prep, t_z - t_dense_rows, t0, nlev, t_sparse - t_z, spasm_wtime() - t_sparse);
+    spasm_logf("[kernel] done in %.1fs. NNZ(K) = %lld\n", spasm_wtime() - t_start, (long long)spasm_nnz(K));
+    return K;
+}
+
 struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step = 1)
 {
     require_device();
@@ -4264,6 +4505,23 @@ struct spasm_csr *do_kernel(const struct spasm_lu *fact, int first = 0, int step
     // a U too large for the device as one round goes through its closure (SPASM_AMD_KERNEL_REDUCE_NNZ, tests: the size from which)
     i64 reduce_at = (i64)1 << 31;
     if (const char *e = getenv("SPASM_AMD_KERNEL_REDUCE_NNZ")) reduce_at = atoll(e);
+    // all free columns at once through a dense right-hand side (kernel_dense.hpp): primes below 2^16; SPASM_AMD_KERNEL_DENSE_RHS = 1
+    // always (tests), 0 never; SPASM_AMD_KERNEL_DENSE_TAIL (tests): rows of the dense tail instead of the choice by density
+    {
+        const ZpField F = zp_field_make(U->field->p);
+        const char *e = getenv("SPASM_AMD_KERNEL_DENSE_RHS");
+        // (by default from 2^26 entries of U on: config 5 at 1/5, 2e9 entries, takes 1.3 s this way and 2.3 s with one sparse solve
+        // per free column; below that the difference is noise and the sparse solves also serve the large primes)
+        const bool want = e ? atoi(e) != 0 : spasm_nnz(U) >= std::min<i64>(reduce_at, (i64)1 << 26);
+        if (want && F.small && dense_elem_bytes(F, 1) <= 2) {
+            i64 tail = -1;
+            if (const char *t = getenv("SPASM_AMD_KERNEL_DENSE_TAIL")) tail = atoll(t);
+            struct spasm_csr *K = dense_elem_bytes(F, 1) == 1 ? kernel_dense_rhs<signed char>(U, fact->qinv, first, step, tail)
+                                                              : kernel_dense_rhs<short>(U, fact->qinv, first, step, tail);
+            if (K) return K;
+            spasm_logf("[kernel] the dense right-hand side does not fit the device: one sparse solve per free column\n");
+        }
+    }
     if (spasm_nnz(U) >= reduce_at) {
         const double t0 = spasm_wtime();
         KernelReduced red;

@@ -388,6 +388,45 @@ def test_kernel_through_the_closure_of_the_free_columns(S, O, monkeypatch, kind,
             assert sum(v * kd.get(c, 0) for c, v in row) % prime == 0
 
 
+@pytest.mark.parametrize("tail", ["0", "100", "1000000000", None], ids=["no_dense_tail", "tail_of_100_rows", "everything_dense", "tail_by_density"])
+@pytest.mark.parametrize("kind,n,m,kw,prime,opts", [
+    (0, 900, 1100, dict(density=4e-3), 42013, LM),           # several sparse rounds + a dense finish
+    (2, 3000, 1200, dict(row_nnz=30), 127, LM),              # Macaulay-like, bytes: dense tail from the tall finish
+    (1, 2000, 2600, dict(row_nnz=3), 65521, LM),             # very sparse, deep pivot graph, many free columns (shorts)
+    (0, 300, 500, dict(density=2e-3), 42013, LM),            # empty columns
+    (2, 3000, 1200, dict(row_nnz=30), 127, {}),              # default options: pivots that are not leftmost entries
+    (0, 700, 900, dict(density=6e-3), 251, {}),              # p = 251: residues fill the byte
+])
+def test_kernel_through_a_dense_right_hand_side(S, O, monkeypatch, kind, n, m, kw, prime, opts, tail):
+    """spasm_kernel with all free columns at once (csrc/kernel_dense.hpp: the dense tail of U through the reduced form on the int8
+    GEMM, the sparse rows level by level, K = the transpose) -- the path of a U too large for the device as one round, forced here
+    at small sizes with every split between dense tail and sparse rows.  Must give the basis of the sparse solves, vector for vector."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0xD3A5E, **kw)
+    fact = S.echelonize(A, **opts)
+    whole = S.kernel(fact).rows()
+    monkeypatch.setenv("SPASM_AMD_KERNEL_DENSE_RHS", "1")
+    if tail is not None:
+        monkeypatch.setenv("SPASM_AMD_KERNEL_DENSE_TAIL", tail)
+    try:
+        rows = S.kernel(fact).rows()
+        lib = S._abi.lib()
+        parts = []
+        for first in range(2):
+            ptr = lib.spasm_amd_kernel_strided(fact.data, first, 2)
+            assert ptr, S._abi.last_error()
+            parts.append(S.CSR(ptr).rows())
+    finally:
+        monkeypatch.delenv("SPASM_AMD_KERNEL_DENSE_RHS")
+        if tail is not None:
+            monkeypatch.delenv("SPASM_AMD_KERNEL_DENSE_TAIL")
+    assert len(rows) == A.m - fact.r
+    assert rows == whole
+    assert parts[0] == whole[0::2] and parts[1] == whole[1::2]
+    if not opts:
+        return
+    assert rows == O.kernel(O.echelonize(A, **LM)).rows()
+
+
 def test_rref_of_a_multi_round_factorization(S, O):
     """U of several sparse rounds plus a dense tail (config-2 style, scaled down): R must have no entry on a foreign pivot
     column, span the same space (verify), and reproduce the kernel through the textbook formula k[piv(a)] = R[a][j]."""

@@ -95,7 +95,7 @@ def test_planted_rank_one_third(S):
 
 
 @pytest.mark.gpu
-def test_planted_rank_with_the_factorization(S):
+def test_planted_rank_with_the_factorization(S, monkeypatch):
     """not rank-only: U is collected and verified against A"""
     n, m = 100_000, 40_000
     n0 = int(0.99 * m)
@@ -104,3 +104,23 @@ def test_planted_rank_with_the_factorization(S):
     fact = S.echelonize(M)
     assert fact.r == n0
     assert S.factorization_verify(M, fact, 9)
+    # the kernel: m - n0 vectors, A * k^T == 0 with exact integers -- through the dense right-hand side (csrc/kernel_dense.hpp: the
+    # dense tail of this U on the GEMM, the sparse rows level by level) and through one sparse solve per free column
+    import scipy.sparse as sp
+
+    As = sp.csr_matrix((A.data.astype(np.int64), A.indices, A.indptr), shape=A.shape)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SPASM_AMD_KERNEL_DENSE_RHS", mode)
+        try:
+            K = S.kernel(fact)
+        finally:
+            monkeypatch.delenv("SPASM_AMD_KERNEL_DENSE_RHS")
+        assert K.n == m - n0
+        Kp, Kj, Kx = np.asarray(K.p), np.asarray(K.j), np.asarray(K.x)
+        for f in range(0, K.n, max(1, K.n // 25)):
+            k = np.zeros(m, dtype=np.int64)
+            k[Kj[Kp[f]:Kp[f + 1]]] = Kx[Kp[f]:Kp[f + 1]]
+            assert not np.any((As @ k) % 127)
+        got[mode] = K.rows()
+    assert got["1"] == got["0"]

@@ -151,6 +151,16 @@ def test_echelonize_sharded_matches_single_device(S, O, world, kind, n, m, kw, p
     assert shard_rounds == [rr["npiv"] for rr in ref_rounds[: len(shard_rounds)]]
     k = sum(shard_rounds)
     assert results[0][4][:k] == ref.U.rows()[:k]
+    # ... and against what a user of ONE device gets, the reference's default options (FL on columns + the greedy search, which the
+    # sharded rounds do not run): other pivots, the same rank, and the same kernel as a SUBSPACE -- the reduced row echelon form of a
+    # basis is unique for the subspace
+    from test_gpu_default_options import rows_to_dense
+
+    dflt = S.echelonize(A)
+    assert dflt.r == ref.r
+    Kd = O.dense_rref(rows_to_dense(S.kernel(dflt).rows(), m, p), p)[0]
+    Ks = O.dense_rref(rows_to_dense(results[0][5], m, p), p)[0]
+    assert Kd.shape == Ks.shape and (np.asarray(Kd) == np.asarray(Ks)).all()
 
 
 @pytest.mark.gpu
@@ -171,10 +181,20 @@ def test_echelonize_multi_in_one_process_matches_the_single_device_result(S, O, 
     assert got.r == ref.r
     assert np.asarray(got.qinv >= 0).tolist() == np.asarray(ref.qinv >= 0).tolist()
     assert S.factorization_verify(A, got, 5)
-    assert S.kernel(got).rows() == S.kernel(ref).rows()
+    Krows = S.kernel(got).rows()
+    assert Krows == S.kernel(ref).rows()
     # pivotal rows first in p, each once
     p = np.asarray(got.p)[: got.r]
     assert len(set(p.tolist())) == got.r and (p >= 0).all() and (p < n).all()
+    # the default-options single-device run (other pivot searches, other pivots): same rank, same kernel as a subspace
+    if m <= 2600:
+        from test_gpu_default_options import rows_to_dense
+
+        dflt = S.echelonize(A)
+        assert dflt.r == got.r
+        Kd = O.dense_rref(rows_to_dense(S.kernel(dflt).rows(), m, prime), prime)[0]
+        Ks = O.dense_rref(rows_to_dense(Krows, m, prime), prime)[0]
+        assert Kd.shape == Ks.shape and (np.asarray(Kd) == np.asarray(Ks)).all()
 
 
 @pytest.mark.gpu

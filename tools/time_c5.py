@@ -18,4 +18,16 @@ for r in S.last_rounds():
 if "--verify" in sys.argv:
     t0 = time.time(); ok = S.factorization_verify(A, fact, 1); print(f"factorization_verify {ok} in {time.time()-t0:.2f}s", flush=True)
 t0 = time.time(); K = S.kernel(fact, verbose=("-v" in sys.argv)); t1 = time.time()
-print(f"kernel {t1-t0:.3f}s dim {K.n} nnz(K) {S.nnz(K)}")
+print(f"kernel {t1-t0:.3f}s dim {K.n} nnz(K) {S.nnz(K)}", flush=True)
+if "--check-kernel" in sys.argv:   # A * k^T == 0 for a sample of the basis, exact integers; rows(K) == m - rank
+    import numpy as np, scipy.sparse as sp
+    t0 = time.time()
+    nzA = int(A.p[A.n]); As = sp.csr_matrix((np.asarray(A.x[:nzA], dtype=np.int64), np.asarray(A.j[:nzA], dtype=np.int64), np.asarray(A.p[:A.n + 1], dtype=np.int64)), shape=(A.n, A.m))
+    Kp, Kj, Kx = np.asarray(K.p), np.asarray(K.j), np.asarray(K.x)
+    pick = sorted(set(np.linspace(0, K.n - 1, num=min(K.n, 48), dtype=np.int64).tolist())) if K.n else []
+    bad = 0
+    for f in pick:
+        k = np.zeros(A.m, dtype=np.int64); lo, hi = int(Kp[f]), int(Kp[f + 1]); k[Kj[lo:hi]] = Kx[lo:hi]
+        bad += int(np.any((As @ k) % 127 != 0))
+    print(f"kernel check: rows(K) {K.n} == m - r {A.m - fact.r}: {K.n == A.m - fact.r}; A * k^T == 0 for {len(pick) - bad} of {len(pick)} sampled vectors [{time.time()-t0:.1f}s]", flush=True)
+    sys.exit(0 if (bad == 0 and K.n == A.m - fact.r) else 1)
