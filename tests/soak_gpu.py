@@ -1,5 +1,5 @@
-"""Randomised soak of the round-3 paths against the single-device leftmost-pivot run and the oracle (small matrices, many shapes):
-the dense finish over row shards (random shard counts and block sizes), the tall-and-skinny finish (random slabs and batches), the
+"""Randomised soak of the round-3 and round-4 paths against the single-device leftmost-pivot run and the oracle (small matrices, many shapes):
+the dense finish over row shards (random shard counts and block sizes), the tall-and-skinny finish (random slabs and batches), the tall finish with column slabs and row chunks, the kernel paths of round 4, the
 greedy search (random limits; engine vs oracle pair for pair through max_round = 1 runs).   python tests/soak_gpu.py [seconds=120] [seed=1] [scale=1]   (test infrastructure: it uses the oracle; not collected by pytest)"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,8 +13,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 SC = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # matrix sizes times SC
 LM = dict(enable_greedy_pivot_search=False)
 t_end = time.time() + budget
-done = {"multi": 0, "tall": 0, "greedy": 0}
-KEYS = ["SPASM_AMD_MULTI_DENSE_MIN_BYTES", "SPASM_AMD_MULTI_FINISH_NNZ", "SPASM_AMD_DENSE_KB", "SPASM_AMD_TALL", "SPASM_AMD_TALL_SLAB", "SPASM_AMD_TALL_BATCH", "SPASM_AMD_GREEDY_REACH_MAX",
+done = {"multi": 0, "tall": 0, "greedy": 0, "kernel": 0}
+KEYS = ["SPASM_AMD_TALL_CHUNK", "SPASM_AMD_MEM_BUDGET_MB", "SPASM_AMD_KERNEL_DENSE_RHS", "SPASM_AMD_KERNEL_DENSE_TAIL", "SPASM_AMD_KERNEL_REDUCE_NNZ", "SPASM_AMD_MULTI_DENSE_MIN_BYTES", "SPASM_AMD_MULTI_FINISH_NNZ", "SPASM_AMD_DENSE_KB", "SPASM_AMD_TALL", "SPASM_AMD_TALL_SLAB", "SPASM_AMD_TALL_BATCH", "SPASM_AMD_GREEDY_REACH_MAX",
         "SPASM_AMD_GREEDY_OCC_MAX", "SPASM_AMD_PANEL_GLOBAL"]
 
 
@@ -57,7 +57,7 @@ while time.time() < t_end:
     olu = O.echelonize(A, **LM)
     assert ref.r == olu.r and pattern(ref) == pattern(olu), ("single device vs oracle", case)
     K = S.kernel(ref).rows()
-    which = case % 3
+    which = case % 4
     if which == 0:
         nsh = int(rng.integers(1, 9))
         env = dict(SPASM_AMD_MULTI_DENSE_MIN_BYTES=0, SPASM_AMD_MULTI_FINISH_NNZ=int(rng.choice([1, 1000, 1 << 22])), SPASM_AMD_DENSE_KB=int(rng.choice([64, 128, 256, 1024])))
@@ -70,10 +70,32 @@ while time.time() < t_end:
     elif which == 1:
         env = dict(SPASM_AMD_TALL=1, SPASM_AMD_TALL_SLAB=int(rng.choice([64, 128, 320, 1024])), SPASM_AMD_TALL_BATCH=int(rng.choice([128, 512, 100000])),
                    SPASM_AMD_DENSE_KB=int(rng.choice([64, 256, 1024])))
+        if rng.random() < 0.5:   # r04: the residuals in chunks of rows
+            env["SPASM_AMD_TALL_CHUNK"] = int(rng.choice([64, 256, 1024]))
+        if rng.random() < 0.5:   # r04: the dense W in column slabs (the free columns of a slab are ADDED to the residuals)
+            env["SPASM_AMD_MEM_BUDGET_MB"] = int(rng.choice([1, 2, 8]))
         setenv(**env)
         got = S.echelonize(A, sparsity_threshold=float(rng.choice([0.001, 0.05, 0.3])), **LM)
         tag = ("tall", env)
         done["tall"] += 1
+    elif which == 3:
+        # r04: the kernel through a dense right-hand side (any split between dense tail and sparse rows) and through the closure
+        # of the free columns, from the leftmost-pivot factorization and from the default one
+        f2 = S.echelonize(A) if rng.random() < 0.5 else ref
+        want = K if f2 is ref else None
+        setenv()
+        if want is None:
+            want = S.kernel(f2).rows()
+        if p < 65536 and rng.random() < 0.7:
+            env = dict(SPASM_AMD_KERNEL_DENSE_RHS=1)
+            if rng.random() < 0.8:
+                env["SPASM_AMD_KERNEL_DENSE_TAIL"] = int(rng.choice([0, 1, 63, 64, 65, 300, 1 << 30]))
+        else:
+            env = dict(SPASM_AMD_KERNEL_DENSE_RHS=0, SPASM_AMD_KERNEL_REDUCE_NNZ=0)
+        setenv(**env)
+        assert S.kernel(f2).rows() == want, ("kernel paths", case, A.n, A.m, p, env)
+        done["kernel"] += 1
+        continue
     else:
         env = dict(SPASM_AMD_GREEDY_REACH_MAX=int(rng.choice([0, 1, 2, 8, 64, 1024])), SPASM_AMD_GREEDY_OCC_MAX=int(rng.choice([1, 2, 5, 1 << 30])))
         setenv(**env)
