@@ -338,6 +338,18 @@ spasm_amd_shard *spasm_amd_shard_create(const struct spasm_csr *A, int row_lo, i
 spasm_amd_shard *spasm_amd_shard_create_strided(const struct spasm_csr *A, int row_lo, int row_hi, int stride);
 int spasm_amd_shard_elect(spasm_amd_shard *sh, int64_t *keys_dev);
 int spasm_amd_shard_set_keys(spasm_amd_shard *sh, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned);
+/* r04: shard_set_keys in two halves with "Faugere-Lachartre on columns" (enable_greedy_pivot_search, src/SpaSM.jl:326; README.md:23)
+ * between them -- the search of the single-device round over ROW SHARDS: shard_assign numbers the leftmost pivots (returns how many);
+ * shard_open_step runs one step of the search on this shard's rows: `in_dev` is the array the step before left, REDUCED over the
+ * shards by the caller, `out_dev` receives the array this step leaves (m elements) for the caller to reduce --
+ *   step 0 BEGIN -> closed (int32, MAX) | 1 HIST (in: closed) -> colcnt (int32, SUM) | 2 PROPOSE (in: colcnt) -> best2 (int64, MIN)
+ *   3 ACCEPT (in: best2) -> newflag (int32, MAX) | 4 RECORD (in: newflag; pass = 1..4) -> closed (int32, MAX), returns the pivots the
+ *   pass accepted (0: the search is over) | 5 FINISH: renumbers, returns the pivots the search added
+ * (steps 1-4 once per pass, at most four passes: four m-word reductions per pass); shard_finish_keys then does the rest of
+ * shard_set_keys (the shard's non-pivot rows, the pivot rows it owns).  < 0 on error. */
+int spasm_amd_shard_assign(spasm_amd_shard *sh, const int64_t *keys_dev);
+int spasm_amd_shard_open_step(spasm_amd_shard *sh, int step, int pass, const void *in_dev, void *out_dev);
+int spasm_amd_shard_finish_keys(spasm_amd_shard *sh, int *n_owned, i64 *nnz_owned);
 int spasm_amd_shard_export(spasm_amd_shard *sh, int *hdr_dev, int *ent_dev);
 spasm_amd_schur_plan *spasm_amd_shard_import(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev);
 /* X * U = B for every row of B in one device pass: what SpaSM.jl's sparse_triangular_solve(U, B, qinv) / `B / LU`

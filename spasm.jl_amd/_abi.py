@@ -205,6 +205,9 @@ SIGNATURES = {
     "spasm_amd_shard_create_strided": (C.c_void_p, [_P(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),
     "spasm_amd_shard_elect": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "spasm_amd_shard_set_keys": (C.c_int32, [C.c_void_p, C.c_void_p, _P(C.c_int32), _P(C.c_int64)]),
+    "spasm_amd_shard_assign": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "spasm_amd_shard_open_step": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "spasm_amd_shard_finish_keys": (C.c_int32, [C.c_void_p, _P(C.c_int32), _P(C.c_int64)]),
     "spasm_amd_shard_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "spasm_amd_shard_import": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "spasm_amd_triangular_solve": (_P(CsrStruct), [_P(CsrStruct), _P(C.c_int32), _P(CsrStruct), _P(C.c_ubyte)]),

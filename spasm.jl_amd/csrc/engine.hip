@@ -404,11 +404,17 @@ struct Round {
     DevBuf<u64d> best2;
     int n_leftmost = 0, n_open = 0;
     DevBuf<int> newpass, newidx, newrow_of_col, newrows;
-    int extend_pivots_on_open_columns(const DevMat &A)
+    // The search in steps, cut where an array that describes ALL rows must be reduced over the row shards (one device: no cut).
+    // (row_base, row_stride): local row i is global row row_base + i * row_stride; pivrow / newrows hold global rows.
+    int open_count[OPEN_PASSES + 1] = {0};
+    int open_nnew = 0, open_npass = 0;
+    // -> closed[] (reduce: MAX): the columns the pivot rows THIS shard holds touch
+    void open_begin(const DevMat &A, int row_base, int row_stride)
     {
         n_leftmost = npiv;
         n_open = 0;
-        if (npiv == 0 || A.n == 0) return 0;
+        open_nnew = open_npass = 0;
+        for (int &c : open_count) c = 0;
         closed.ensure((size_t)m + 1); colcnt.ensure((size_t)m + 1); newflag.ensure((size_t)m + 1); newscan.ensure((size_t)m + 1);
         newpass.ensure((size_t)m + 1); newidx.ensure((size_t)m + 1); newrow_of_col.ensure((size_t)m + 1); newrows.ensure((size_t)m + 1);
         best2.ensure((size_t)m + 1);
@@ -417,42 +423,68 @@ struct Round {
         HIPCHK(hipMemsetAsync(closed.p, 0, ((size_t)m + 1) * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(newpass.p, 0, ((size_t)m + 1) * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(is_piv.p, 0, ((size_t)A.n + 1) * sizeof(int), stream));
-        hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, 0, 1, A.n, pivrow.p, is_piv.p);
-        HIPCHK(hipGetLastError());
-        constexpr int TEAM = 8;
-        hipLaunchKernelGGL((k_close_cols<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, stream, npiv, pivrow.p, A.start.p, A.len.p, A.ent.p, closed.p);
-        HIPCHK(hipGetLastError());
-        int count[OPEN_PASSES + 1] = {0};
-        int nnew = 0, npass = 0;
-        for (int pass = 1; pass <= OPEN_PASSES; pass++) {
-            HIPCHK(hipMemsetAsync(colcnt.p, 0, ((size_t)m + 1) * sizeof(int), stream));
-            HIPCHK(hipMemsetAsync(newflag.p, 0, ((size_t)m + 1) * sizeof(int), stream));
-            hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best2.p);
-            hipLaunchKernelGGL(k_col_histogram, dim3(cdiv((i64)A.n * 8, 256)), dim3(256), 0, stream, A.n, is_piv.p, A.start.p, A.len.p, A.ent.p, colcnt.p);
-            hipLaunchKernelGGL((k_propose_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, 0, 1, is_piv.p, A.start.p, A.len.p,
-                               A.ent.p, closed.p, colcnt.p, prop.p, best2.p);
-            hipLaunchKernelGGL((k_accept_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, 0, 1, A.start.p, A.len.p, A.ent.p,
-                               prop.p, best2.p, newflag.p);
+        if (npiv > 0) {
+            hipLaunchKernelGGL(k_mark_rows, dim3(cdiv(npiv, 256)), dim3(256), 0, stream, npiv, row_base, row_stride, A.n, pivrow.p, is_piv.p);
+            constexpr int TEAM = 8;
+            hipLaunchKernelGGL((k_close_cols<TEAM>), dim3(cdiv((i64)npiv * TEAM, 256)), dim3(256), 0, stream, npiv, pivrow.p, row_base, row_stride, A.n, A.start.p, A.len.p,
+                               A.ent.p, closed.p);
             HIPCHK(hipGetLastError());
-            scan.exclusive(newflag.p, newscan.p, (size_t)m + 1, stream);
-            int nacc = 0;
-            HIPCHK(hipMemcpyAsync(&nacc, newscan.p + m, sizeof(int), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            if (nacc == 0) break;
-            hipLaunchKernelGGL(k_record_open, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, pass, newflag.p, newscan.p, best2.p, newpass.p, newidx.p,
-                               newrow_of_col.p, newrows.p, is_piv.p);
-            hipLaunchKernelGGL((k_close_cols<TEAM>), dim3(cdiv((i64)nacc * TEAM, 256)), dim3(256), 0, stream, nacc, newrows.p, A.start.p, A.len.p, A.ent.p,
-                               closed.p);
-            HIPCHK(hipGetLastError());
-            count[pass] = nacc;
-            nnew += nacc;
-            npass = pass;
         }
+    }
+    // -> colcnt[] (reduce: SUM): rows that are no pivots per column
+    void open_hist(const DevMat &A)
+    {
+        HIPCHK(hipMemsetAsync(colcnt.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(newflag.p, 0, ((size_t)m + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_fill_u64, dim3(cdiv((i64)m + 1, 256)), dim3(256), 0, stream, (i64d)m + 1, (u64d)NO_BEST, best2.p);
+        if (A.n > 0) hipLaunchKernelGGL(k_col_histogram, dim3(cdiv((i64)A.n * 8, 256)), dim3(256), 0, stream, A.n, is_piv.p, A.start.p, A.len.p, A.ent.p, colcnt.p);
+        HIPCHK(hipGetLastError());
+    }
+    // -> best2[] (reduce: MIN): the best proposal per column
+    void open_propose(const DevMat &A, int row_base, int row_stride)
+    {
+        constexpr int TEAM = 8;
+        if (A.n > 0)
+            hipLaunchKernelGGL((k_propose_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, row_base, row_stride, is_piv.p, A.start.p, A.len.p,
+                               A.ent.p, closed.p, colcnt.p, prop.p, best2.p);
+        HIPCHK(hipGetLastError());
+    }
+    // -> newflag[] (reduce: MAX): the columns whose winner holds no other proposed column
+    void open_accept(const DevMat &A, int row_base, int row_stride)
+    {
+        constexpr int TEAM = 8;
+        if (A.n > 0)
+            hipLaunchKernelGGL((k_accept_open<TEAM>), dim3(cdiv((i64)A.n * TEAM, 256)), dim3(256), 0, stream, A.n, row_base, row_stride, A.start.p, A.len.p, A.ent.p,
+                               prop.p, best2.p, newflag.p);
+        HIPCHK(hipGetLastError());
+    }
+    // the accepted pivots of the pass (the same on every shard) -> closed[] (reduce: MAX); returns how many
+    int open_record(const DevMat &A, int pass, int row_base, int row_stride)
+    {
+        scan.exclusive(newflag.p, newscan.p, (size_t)m + 1, stream);
+        int nacc = 0;
+        HIPCHK(hipMemcpyAsync(&nacc, newscan.p + m, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (nacc == 0) return 0;
+        constexpr int TEAM = 8;
+        hipLaunchKernelGGL(k_record_open, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, pass, newflag.p, newscan.p, best2.p, newpass.p, newidx.p,
+                           newrow_of_col.p, newrows.p, is_piv.p, row_base, row_stride, A.n);
+        hipLaunchKernelGGL((k_close_cols<TEAM>), dim3(cdiv((i64)nacc * TEAM, 256)), dim3(256), 0, stream, nacc, newrows.p, row_base, row_stride, A.n, A.start.p, A.len.p,
+                           A.ent.p, closed.p);
+        HIPCHK(hipGetLastError());
+        open_count[pass] = nacc;
+        open_nnew += nacc;
+        open_npass = pass;
+        return nacc;
+    }
+    // renumber: the open-column pivots first (last pass first), the leftmost pivots behind them (colscan still holds their ascending
+    // numbering).  Returns how many pivots the search added.
+    int open_finish()
+    {
+        const int nnew = open_nnew;
         if (nnew == 0) return 0;
-        // renumber: the open-column pivots first (last pass first), the leftmost pivots behind them (colscan still holds their ascending
-        // numbering)
         int base[OPEN_PASSES + 2] = {0};
-        for (int pass = npass, at = 0; pass >= 1; pass--) { base[pass] = at; at += count[pass]; }
+        for (int pass = open_npass, at = 0; pass >= 1; pass--) { base[pass] = at; at += open_count[pass]; }
         static_assert(OPEN_PASSES == 4, "k_col_assign2 takes the bases of four passes");
         pivrow.ensure((size_t)npiv + nnew + 1);
         pivcol.ensure((size_t)npiv + nnew + 1);
@@ -462,6 +494,20 @@ struct Round {
         npiv += nnew;
         n_open = nnew;
         return nnew;
+    }
+    int extend_pivots_on_open_columns(const DevMat &A)
+    {
+        n_leftmost = npiv;
+        n_open = 0;
+        if (npiv == 0 || A.n == 0) return 0;
+        open_begin(A, 0, 1);
+        for (int pass = 1; pass <= OPEN_PASSES; pass++) {
+            open_hist(A);
+            open_propose(A, 0, 1);
+            open_accept(A, 0, 1);
+            if (open_record(A, pass, 0, 1) == 0) break;
+        }
+        return open_finish();
     }
 
     // ---- (1b'') the greedy cycle-free search (greedy.hpp; reference README.md:23): after the leftmost election and "FL on columns",
@@ -4779,16 +4825,85 @@ void shard_elect(spasm_amd_shard *S, int64_t *keys_dev)
     HIPCHK(hipStreamSynchronize(R.stream));
 }
 
-int shard_set_keys(spasm_amd_shard *S, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned)
+// the reduced election keys -> the leftmost pivots, numbered (the same on every shard); returns how many
+int shard_assign(spasm_amd_shard *S, const int64_t *keys_dev)
+{
+    spasm_amd_schur_plan *P = S->plan;
+    Round &R = P->R;
+    const int m = P->A.m;
+    R.m = m;
+    R.best.ensure((size_t)m + 1);
+    HIPCHK(hipMemcpyAsync(R.best.p, keys_dev, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice, R.stream));
+    R.assign_pivots();
+    R.n_leftmost = R.npiv;
+    R.n_open = 0;
+    return R.npiv;
+}
+
+// "FL on columns" over row shards (Round::open_*): one step of the search on this shard's rows.  `in_dev`: the array the step before
+// left, REDUCED over the shards by the caller (copied in first); `out_dev` receives the array this step leaves, m elements, for the
+// caller to reduce: BEGIN -> closed (int32, MAX); HIST (in: closed) -> colcnt (int32, SUM); PROPOSE (in: colcnt) -> best2 (int64,
+// MIN); ACCEPT (in: best2) -> newflag (int32, MAX); RECORD (in: newflag) -> closed (int32, MAX), returns the pivots the pass
+// accepted (0: the search is over, nothing written); FINISH renumbers and returns the pivots the search added.
+enum { OPEN_BEGIN = 0, OPEN_HIST = 1, OPEN_PROPOSE = 2, OPEN_ACCEPT = 3, OPEN_RECORD = 4, OPEN_FINISH = 5 };
+int shard_open_step(spasm_amd_shard *S, int step, int pass, const void *in_dev, void *out_dev)
 {
     spasm_amd_schur_plan *P = S->plan;
     Round &R = P->R;
     hipStream_t s = R.stream;
-    const int m = P->A.m;
-    R.m = m;
-    R.best.ensure((size_t)m + 1);
-    HIPCHK(hipMemcpyAsync(R.best.p, keys_dev, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice, s));
-    R.assign_pivots();
+    const size_t m = (size_t)P->A.m;
+    int ret = 0;
+    auto take = [&](void *dst, size_t elem) { if (in_dev) HIPCHK(hipMemcpyAsync(dst, in_dev, m * elem, hipMemcpyDeviceToDevice, s)); };
+    auto give = [&](const void *src, size_t elem) { if (out_dev) HIPCHK(hipMemcpyAsync(out_dev, src, m * elem, hipMemcpyDeviceToDevice, s)); };
+    switch (step) {
+    case OPEN_BEGIN:
+        R.open_begin(P->A, P->lo, P->stride);
+        give(R.closed.p, sizeof(int));
+        break;
+    case OPEN_HIST:
+        take(R.closed.p, sizeof(int));
+        R.open_hist(P->A);
+        give(R.colcnt.p, sizeof(int));
+        break;
+    case OPEN_PROPOSE:
+        take(R.colcnt.p, sizeof(int));
+        R.open_propose(P->A, P->lo, P->stride);
+        give(R.best2.p, sizeof(u64d));
+        break;
+    case OPEN_ACCEPT:
+        take(R.best2.p, sizeof(u64d));
+        R.open_accept(P->A, P->lo, P->stride);
+        give(R.newflag.p, sizeof(int));
+        break;
+    case OPEN_RECORD:
+        take(R.newflag.p, sizeof(int));
+        ret = R.open_record(P->A, pass, P->lo, P->stride);
+        if (ret > 0) give(R.closed.p, sizeof(int));
+        break;
+    case OPEN_FINISH:
+        ret = R.open_finish();
+        break;
+    default:
+        throw EngineError("spasm_amd_shard_open_step: unknown step");
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return ret;
+}
+
+// the pivots are final: this shard's non-pivot rows, the pivot rows it owns (what shard_export sends); returns npiv
+int shard_finish_keys(spasm_amd_shard *S, int *n_owned, i64 *nnz_owned);
+
+int shard_set_keys(spasm_amd_shard *S, const int64_t *keys_dev, int *n_owned, i64 *nnz_owned)
+{
+    shard_assign(S, keys_dev);
+    return shard_finish_keys(S, n_owned, nnz_owned);
+}
+
+int shard_finish_keys(spasm_amd_shard *S, int *n_owned, i64 *nnz_owned)
+{
+    spasm_amd_schur_plan *P = S->plan;
+    Round &R = P->R;
+    hipStream_t s = R.stream;
     R.mark_local(P->A, P->lo, 0, INT_MAX, P->stride, 1); // local non-pivot rows; pivrow holds global ids
     S->npiv = R.npiv;
     // owned pivot rows, in ascending pivot index
@@ -5133,6 +5248,8 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
         i64 nnz_own = 0;
         DevBuf<u64d> keys;
         DevBuf<int> hdr, ent, hdr_all, ent_all;
+        DevBuf<int> oc_i;   // "FL on columns": the int32 array of the current step
+        DevBuf<u64d> oc_q;  // .. and the proposals
     };
     std::vector<std::unique_ptr<ShardState>> st((size_t)nshards);
     auto cleanup = [&]() {
@@ -5353,13 +5470,80 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipDeviceSynchronize());
             }
-            int npiv = 0;
+            int npiv = 0, n_open = 0;
             i64 tot_rows = 0, tot_ent = 0;
             for (int k = 0; k < nshards; k++) {
                 HIPCHK(hipSetDevice(dev_of(k)));
                 if (k > 0) HIPCHK(hipMemcpy(st[(size_t)k]->keys.p, st[0]->keys.p, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice));
+                npiv = shard_assign(st[(size_t)k]->sh, (const int64_t *)st[(size_t)k]->keys.p);
+            }
+            // "Faugere-Lachartre on columns" over the shards (enable_greedy_pivot_search, in the max_round sparse rounds like the
+            // single-device loop): the steps of shard_open_step, the array each leaves merged on device 0 and handed back -- what the
+            // four all-reduces per pass do between processes (sharded.py: set_keys_open).  The third, cycle-free search is not sharded.
+            if (opts->enable_greedy_pivot_search && round < opts->max_round && npiv > 0 && !getenv("SPASM_AMD_MULTI_NO_OPEN_COLUMNS")) {
+                for (int k = 0; k < nshards; k++) {
+                    HIPCHK(hipSetDevice(dev_of(k)));
+                    st[(size_t)k]->oc_i.ensure((size_t)m + 1);
+                    st[(size_t)k]->oc_q.ensure((size_t)m + 1);
+                }
+                HIPCHK(hipSetDevice(dev_of(0)));
+                DevBuf<int> stage_i;
+                stage_i.alloc((size_t)m + 1);
+                stage.ensure((size_t)m + 1);
+                // kind 0: int32 MAX, 1: int32 SUM, 2: u64 MIN; the merged array ends up in every shard's buffer
+                auto merge = [&](int kind) {
+                    HIPCHK(hipSetDevice(dev_of(0)));
+                    for (int k = 1; k < nshards; k++) {
+                        if (kind == 2) {
+                            HIPCHK(hipMemcpy(stage.p, st[(size_t)k]->oc_q.p, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice));
+                            hipLaunchKernelGGL(k_min_u64, dim3(cdiv(m, 256)), dim3(256), 0, nullptr, (i64d)m, st[0]->oc_q.p, stage.p);
+                        } else {
+                            HIPCHK(hipMemcpy(stage_i.p, st[(size_t)k]->oc_i.p, (size_t)m * sizeof(int), hipMemcpyDeviceToDevice));
+                            if (kind == 0) hipLaunchKernelGGL(k_max_i32, dim3(cdiv(m, 256)), dim3(256), 0, nullptr, (i64d)m, st[0]->oc_i.p, stage_i.p);
+                            else hipLaunchKernelGGL(k_add_i32, dim3(cdiv(m, 256)), dim3(256), 0, nullptr, (i64d)m, st[0]->oc_i.p, stage_i.p);
+                        }
+                        HIPCHK(hipGetLastError());
+                        HIPCHK(hipDeviceSynchronize());
+                    }
+                    for (int k = 1; k < nshards; k++) {
+                        HIPCHK(hipSetDevice(dev_of(k)));
+                        if (kind == 2) HIPCHK(hipMemcpy(st[(size_t)k]->oc_q.p, st[0]->oc_q.p, (size_t)m * sizeof(u64d), hipMemcpyDeviceToDevice));
+                        else HIPCHK(hipMemcpy(st[(size_t)k]->oc_i.p, st[0]->oc_i.p, (size_t)m * sizeof(int), hipMemcpyDeviceToDevice));
+                    }
+                };
+                // one step on every shard: in / out = the shard's own buffer of the kind (0: none, 1: oc_i, 2: oc_q); returns shard 0's count
+                auto step_all = [&](int step, int pass, int in_kind, int out_kind) {
+                    int ret = 0;
+                    for (int k = 0; k < nshards; k++) {
+                        HIPCHK(hipSetDevice(dev_of(k)));
+                        ShardState &q = *st[(size_t)k];
+                        const void *in = in_kind == 1 ? (const void *)q.oc_i.p : in_kind == 2 ? (const void *)q.oc_q.p : nullptr;
+                        void *out = out_kind == 1 ? (void *)q.oc_i.p : out_kind == 2 ? (void *)q.oc_q.p : nullptr;
+                        const int rc = shard_open_step(q.sh, step, pass, in, out);
+                        if (k == 0) ret = rc;
+                        else if (rc != ret) throw EngineError("spasm_amd_echelonize_multi: the shards disagree on the pivots of a pass");
+                    }
+                    return ret;
+                };
+                step_all(OPEN_BEGIN, 0, 0, 1);
+                merge(0);
+                for (int pass = 1; pass <= OPEN_PASSES; pass++) {
+                    step_all(OPEN_HIST, pass, 1, 1);
+                    merge(1);
+                    step_all(OPEN_PROPOSE, pass, 1, 2);
+                    merge(2);
+                    step_all(OPEN_ACCEPT, pass, 2, 1);
+                    merge(0);
+                    if (step_all(OPEN_RECORD, pass, 1, 1) == 0) break;
+                    merge(0);
+                }
+                n_open = step_all(OPEN_FINISH, 0, 0, 0);
+                if (n_open) spasm_logf("[pivots] ``Faugère-Lachartre on columns'' over %d shards: %d pivots found\n", nshards, n_open);
+            }
+            for (int k = 0; k < nshards; k++) {
+                HIPCHK(hipSetDevice(dev_of(k)));
                 ShardState &q = *st[(size_t)k];
-                npiv = shard_set_keys(q.sh, (const int64_t *)q.keys.p, &q.n_own, &q.nnz_own);
+                npiv = shard_finish_keys(q.sh, &q.n_own, &q.nnz_own);
                 tot_rows += q.n_own;
                 tot_ent += q.nnz_own;
             }
@@ -5963,6 +6147,36 @@ SPASM_API int spasm_amd_shard_set_keys(spasm_amd_shard *sh, const int64_t *keys_
         return shard_set_keys(sh, keys_dev, n_owned, nnz_owned);
     } catch (const std::exception &e) {
         spasm_set_error("spasm_amd_shard_set_keys: %s", e.what());
+        return -1;
+    }
+}
+
+SPASM_API int spasm_amd_shard_assign(spasm_amd_shard *sh, const int64_t *keys_dev)
+{
+    try {
+        return shard_assign(sh, keys_dev);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_assign: %s", e.what());
+        return -1;
+    }
+}
+
+SPASM_API int spasm_amd_shard_open_step(spasm_amd_shard *sh, int step, int pass, const void *in_dev, void *out_dev)
+{
+    try {
+        return shard_open_step(sh, step, pass, in_dev, out_dev);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_open_step: %s", e.what());
+        return -1;
+    }
+}
+
+SPASM_API int spasm_amd_shard_finish_keys(spasm_amd_shard *sh, int *n_owned, i64 *nnz_owned)
+{
+    try {
+        return shard_finish_keys(sh, n_owned, nnz_owned);
+    } catch (const std::exception &e) {
+        spasm_set_error("spasm_amd_shard_finish_keys: %s", e.what());
         return -1;
     }
 }

@@ -226,6 +226,18 @@ __global__ void k_min_u64(i64d n, u64d *__restrict__ dst, const u64d *__restrict
     if (i < n) { const u64d a = dst[i], b = src[i]; dst[i] = b < a ? b : a; }
 }
 
+// "FL on columns" over the shards of one process: the m-word arrays of a step merged pairwise (what all-reduce MAX / SUM does between processes)
+__global__ void k_max_i32(i64d n, int *__restrict__ dst, const int *__restrict__ src)
+{
+    const i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int a = dst[i], b = src[i]; dst[i] = b > a ? b : a; }
+}
+__global__ void k_add_i32(i64d n, int *__restrict__ dst, const int *__restrict__ src)
+{
+    const i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 __global__ void k_fill_u64(i64d n, u64d v, u64d *__restrict__ out)
 {
     i64d i = (i64d)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,14 +289,18 @@ __global__ void k_col_assign(int m, const u64d *__restrict__ best, const int *__
 // Deterministic and order-free, so the CPU oracle can take the same pivots (oracle/spasm_oracle.c: fl_on_columns).
 // ------------------------------------------------------------------------------------------------
 #define OPEN_PASSES 4
+__device__ __forceinline__ int shard_local(int g, int row_lo, int row_stride, int n);
+// (rowsrc holds GLOBAL rows; a shard (row_lo, row_stride, n local rows) closes the columns of the pivot rows it holds, the
+// reduction over the shards -- a maximum -- gives everybody all of them; one device: (0, 1, n))
 template <int TEAM>
-__global__ void k_close_cols(int npiv, const int *__restrict__ rowsrc, const i64d *__restrict__ start, const int *__restrict__ len,
+__global__ void k_close_cols(int npiv, const int *__restrict__ rowsrc, int row_lo, int row_stride, int n, const i64d *__restrict__ start, const int *__restrict__ len,
                              const int2 *__restrict__ ent, int *__restrict__ closed)
 {
     const int tl = threadIdx.x % TEAM;
     const int idx = (int)(((i64d)blockIdx.x * blockDim.x + threadIdx.x) / TEAM);
     if (idx >= npiv) return;
-    const int row = rowsrc[idx];
+    const int row = shard_local(rowsrc[idx], row_lo, row_stride, n);
+    if (row < 0) return;
     const i64d st = start[row];
     const int ln = len[row];
     for (int k = tl; k < ln; k += TEAM) closed[ent[st + k].x] = 1;
@@ -377,16 +393,17 @@ __global__ void k_col_flags2(int m, const u64d *__restrict__ best, const int *__
 // rows for the next pass (is_piv) and are listed (newrows) so that their columns can be closed
 __global__ void k_record_open(int m, int pass, const int *__restrict__ newflag, const int *__restrict__ newscan, const u64d *__restrict__ best2,
                               int *__restrict__ newpass, int *__restrict__ newidx, int *__restrict__ newrow_of_col, int *__restrict__ newrows,
-                              int *__restrict__ is_piv)
+                              int *__restrict__ is_piv, int row_lo, int row_stride, int n)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m || !newflag[j]) return;
-    const int row = (int)(unsigned)(best2[j] & 0xffffffffull);
+    const int row = (int)(unsigned)(best2[j] & 0xffffffffull); // (a GLOBAL row)
     newpass[j] = pass;
     newidx[j] = newscan[j];
     newrow_of_col[j] = row;
     newrows[newscan[j]] = row;
-    is_piv[row] = 1;
+    const int loc = shard_local(row, row_lo, row_stride, n);
+    if (loc >= 0) is_piv[loc] = 1;
 }
 
 // numbering: the open-column pivots of the LAST pass first, then the earlier passes, each by ascending column, then the leftmost

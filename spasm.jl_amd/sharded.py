@@ -52,6 +52,59 @@ class GpuShardEngine:
         self.npiv = int(npiv)
         return int(npiv), self.n_own, self.nnz_own
 
+    def set_keys_open(self, keys, group=None):
+        """set_keys with "Faugere-Lachartre on columns" between its halves (the single-device round's second pivot search,
+        enable_greedy_pivot_search; reference src/SpaSM.jl:326, README.md:23) over the row shards: the steps of
+        spasm_amd_shard_open_step, each followed by the reduction of the array it leaves (closed: MAX, colcnt: SUM, best2: MIN,
+        newflag: MAX -- four m-word all-reduces per pass, at most four passes).  Returns (npiv, owned rows, owned entries, pivots the
+        search added)."""
+        lib = self.lib
+        keys = keys.to(self.device).contiguous()
+        npiv0 = lib.spasm_amd_shard_assign(self.shard, C.c_void_p(keys.data_ptr()))
+        if npiv0 < 0:
+            raise RuntimeError("spasm_amd_shard_assign failed: " + _abi.last_error())
+        added = 0
+        if npiv0 > 0:
+            def step(k, pass_, tin, tout):
+                rc = lib.spasm_amd_shard_open_step(self.shard, k, pass_, C.c_void_p(tin.data_ptr()) if tin is not None else None,
+                                                   C.c_void_p(tout.data_ptr()) if tout is not None else None)
+                if rc < 0:
+                    raise RuntimeError("spasm_amd_shard_open_step failed: " + _abi.last_error())
+                return rc
+
+            def reduce(t, op):
+                if not dist.is_initialized() or dist.get_world_size(group) == 1:
+                    return t
+                x = _collective_device(t, group).contiguous()
+                dist.all_reduce(x, op=op, group=group)
+                return x.to(self.device)
+
+            i32 = lambda: torch.empty(self.m, dtype=torch.int32, device=self.device)  # noqa: E731
+            closed, colcnt, newflag = i32(), i32(), i32()
+            best2 = torch.empty(self.m, dtype=torch.int64, device=self.device)
+            step(0, 0, None, closed)
+            closed = reduce(closed, dist.ReduceOp.MAX)
+            for pass_ in range(1, 5):
+                step(1, pass_, closed, colcnt)
+                colcnt = reduce(colcnt, dist.ReduceOp.SUM)
+                step(2, pass_, colcnt, best2)
+                best2 = reduce(best2, dist.ReduceOp.MIN)
+                step(3, pass_, best2, newflag)
+                newflag = reduce(newflag, dist.ReduceOp.MAX)
+                closed = i32()
+                if step(4, pass_, newflag, closed) == 0:
+                    break
+                closed = reduce(closed, dist.ReduceOp.MAX)
+            added = step(5, 0, None, None)
+        n = C.c_int32(0)
+        nnz = C.c_int64(0)
+        npiv = lib.spasm_amd_shard_finish_keys(self.shard, C.byref(n), C.byref(nnz))
+        if npiv < 0:
+            raise RuntimeError("spasm_amd_shard_finish_keys failed: " + _abi.last_error())
+        self.n_own, self.nnz_own = int(n.value), int(nnz.value)
+        self.npiv = int(npiv)
+        return int(npiv), self.n_own, self.nnz_own, int(added)
+
     def export(self):
         hdr = torch.empty((max(self.n_own, 1), 2), dtype=torch.int32, device=self.device)
         ent = torch.empty((max(self.nnz_own, 1), 2), dtype=torch.int32, device=self.device)
@@ -383,12 +436,16 @@ def _gather_U_blocks(blk, group):
             g_rows[:, 2].astype(np.int64))
 
 
-def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, engine_cls=None, finish=None, dense_over_shards=None):
+def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, engine_cls=None, finish=None, dense_over_shards=None,
+                       open_columns=False):
     """Row-sharded echelonize of A (every rank passes the same matrix; rank r keeps rows r, r + G, ...).
     Per round: all-reduce(MIN) of the election keys, all-gather of the elected pivot rows, local Schur complement of the
     rank's rows.  When at most `finish_nnz` entries are left in total, or the remainder is dense enough for the dense tail
     (the single-device rule), or after `max_rounds` rounds, the remaining rows are all-gathered and every rank finishes
     them with the single-device engine, so all ranks return the same LU.
+    open_columns=True: the rounds also run "Faugere-Lachartre on columns" over the shards (GpuShardEngine.set_keys_open: what the
+    single-device round does under enable_greedy_pivot_search, without its third, cycle-free search) -- the pivots of the sharded
+    rounds are then those of the single-device rounds with SPASM_AMD_NO_CYCLE_FREE_SEARCH=1, whatever the number of ranks.
     Returns (LU, info)."""
     import numpy as np
 
@@ -476,7 +533,11 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
                                            "collect_U": _time.time() - t_finish}})
                 break
             keys = all_reduce_min(eng.elect(), group)
-            npiv, n_own, nnz_own = eng.set_keys(keys)
+            n_open = 0
+            if open_columns and hasattr(eng, "set_keys_open"):
+                npiv, n_own, nnz_own, n_open = eng.set_keys_open(keys, group)
+            else:
+                npiv, n_own, nnz_own = eng.set_keys(keys)
             t_elect = _time.time()
             if npiv == 0:
                 break
@@ -505,13 +566,13 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
                     if len(dblk[0]):
                         blocks.append(dblk)
                         n_u += len(dblk[0])
-                    rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv), "seconds": {}})
+                    rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv), "npiv_open": int(n_open), "seconds": {}})
                     rounds.append({"round": len(rounds), "finish": True, "dense_over_shards": True, "rows": rows_left, "nnz": -1, "npiv": int(dpiv),
                                    "seconds": {"dense_finish": _time.time() - t_u}})
                     break
                 eng.prepare()
             eng.advance()  # the round runs; its Schur rows are the shard's matrix of the next round, still on the device
-            rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv),
+            rounds.append({"round": len(rounds), "finish": False, "rows": rows_left, "nnz": nnz_left, "npiv": int(npiv), "npiv_open": int(n_open),
                            "gathered_bytes": int(hdr_all.numel() * 4 + ent_all.numel() * 4),
                            "seconds": {"elect": t_elect - t_round, "exchange_import": t_exchange - t_elect, "fetch_U": t_u - t_exchange,
                                        "schur_advance": _time.time() - t_u}})

@@ -64,7 +64,7 @@ while time.time() < t_end:
         if rng.random() < 0.2:
             env["SPASM_AMD_PANEL_GLOBAL"] = 1
         setenv(**env)
-        got = S.echelonize_multi(A, nsh)
+        got = S.echelonize_multi(A, nsh, **LM)
         tag = ("multi", nsh, env, S._abi.lib().spasm_amd_multi_last_finish())
         done["multi"] += 1
     elif which == 1:

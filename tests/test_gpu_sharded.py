@@ -163,6 +163,81 @@ def test_echelonize_sharded_matches_single_device(S, O, world, kind, n, m, kw, p
     assert Kd.shape == Ks.shape and (np.asarray(Kd) == np.asarray(Ks)).all()
 
 
+def _open_columns_worker(rank, world, port, kind, n, m, kw, p, seed, finish_nnz, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import torch
+    import torch.distributed as dist
+
+    import spasm_jl_amd as S
+    from spasm_jl_amd import sharded
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        A = S.synth_csr(kind, n, m, prime=p, seed=seed, **kw)
+        fact, info = sharded.echelonize_sharded(A, finish_nnz=finish_nnz, open_columns=True, dense_over_shards=False)
+        assert S.factorization_verify(A, fact, 9)
+        q.put((rank, fact.r, np.asarray(fact.qinv).tolist(), fact.U.rows(), S.kernel(fact).rows(),
+               [(r["finish"], r["npiv"], r.get("npiv_open", 0)) for r in info["rounds"]]))
+    except Exception as exc:
+        import traceback
+
+        q.put((rank, -1, repr(exc) + traceback.format_exc(), [], [], []))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind,n,m,kw,p,finish_nnz", [(2, 1, 3000, 3000, dict(row_nnz=6), 65521, 6000),
+                                                           (3, 1, 2500, 3200, dict(row_nnz=4), 42013, 4000),
+                                                           (4, 2, 3000, 1200, dict(row_nnz=30), 127, 40000),
+                                                           (2, 0, 1500, 2000, dict(density=0.004), 2147483647, 3000)])
+def test_sharded_rounds_with_fl_on_columns_match_the_single_device_rounds(S, O, monkeypatch, world, kind, n, m, kw, p, finish_nnz):
+    """VERDICT r3 #5, first half: "Faugere-Lachartre on columns" in the SHARDED rounds (four m-word reductions per pass over the
+    ranks: spasm_amd_shard_open_step, GpuShardEngine.set_keys_open).  The pivots of the sharded rounds are then those of the
+    single-device rounds under enable_greedy_pivot_search without its third search (SPASM_AMD_NO_CYCLE_FREE_SEARCH=1), round for round:
+    the same counts, the same rows of U.  (The cycle-free greedy search is not sharded: it walks the pivot rows of other ranks.)"""
+    seed = 1234
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_open_columns_worker, args=(r, world, port, kind, n, m, kw, p, seed, finish_nnz, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] >= 0 for r in results), [r[2] for r in results]
+    assert all(pr.exitcode == 0 for pr in procs)
+    results.sort()
+    A = S.synth_csr(kind, n, m, prime=p, seed=seed, **kw)
+    monkeypatch.setenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH", "1")
+    try:
+        ref = S.echelonize(A, enable_dense=False, max_round=1 << 20)   # sparse rounds with both searches, as far as they go
+        ref_rounds = S.last_rounds()
+    finally:
+        monkeypatch.delenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH")
+    assert ref.r == O.echelonize(A, **LM).r
+    refU = ref.U.rows()
+    from test_gpu_default_options import rows_to_dense
+
+    for rank, r, qinv, Urows, Krows, rounds in results:
+        assert r == ref.r
+        assert rounds == results[0][5] and Urows == results[0][3]                       # every rank returns the same LU
+    rounds = [(np_, no) for fin, np_, no in results[0][5] if not fin]
+    assert len(rounds) >= 1 and sum(no for _, no in rounds) > 0, rounds                 # the search found something
+    got = [(int(rr["npiv"]), int(rr["npiv_open"])) for rr in ref_rounds[: len(rounds)]]
+    assert rounds == got, (rounds, got)
+    k = sum(np_ for np_, _ in rounds)
+    assert results[0][3][:k] == refU[:k]                                                # the rows of U of those rounds
+    Kd = O.dense_rref(rows_to_dense(S.kernel(ref).rows(), m, p), p)[0]
+    Ks = O.dense_rref(rows_to_dense(results[0][4], m, p), p)[0]
+    assert Kd.shape == Ks.shape and (np.asarray(Kd) == np.asarray(Ks)).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,m,kw,prime,nshards", [
     (1, 6000, 6000, dict(row_nnz=5), 65521, 2),
@@ -177,7 +252,7 @@ def test_echelonize_multi_in_one_process_matches_the_single_device_result(S, O, 
     the same.  Leftmost pivots throughout, so rank, pivot columns and kernel equal the single-device leftmost-pivot run's."""
     A = S.synth_csr(kind, n, m, prime=prime, seed=0x3417, **kw)
     ref = S.echelonize(A, **LM)
-    got = S.echelonize_multi(A, nshards)
+    got = S.echelonize_multi(A, nshards, **LM)
     assert got.r == ref.r
     assert np.asarray(got.qinv >= 0).tolist() == np.asarray(ref.qinv >= 0).tolist()
     assert S.factorization_verify(A, got, 5)
@@ -194,6 +269,45 @@ def test_echelonize_multi_in_one_process_matches_the_single_device_result(S, O, 
         assert dflt.r == got.r
         Kd = O.dense_rref(rows_to_dense(S.kernel(dflt).rows(), m, prime), prime)[0]
         Ks = O.dense_rref(rows_to_dense(Krows, m, prime), prime)[0]
+        assert Kd.shape == Ks.shape and (np.asarray(Kd) == np.asarray(Ks)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,m,kw,prime,nshards", [
+    (1, 6000, 6000, dict(row_nnz=5), 65521, 2),
+    (1, 4000, 5000, dict(row_nnz=4), 42013, 3),
+    (2, 5000, 2000, dict(row_nnz=30), 127, 4),
+    (0, 1500, 2000, dict(density=0.004), 0xFFFFFFFB, 8),
+])
+def test_echelonize_multi_default_options_runs_fl_on_columns_over_the_shards(S, O, monkeypatch, kind, n, m, kw, prime, nshards):
+    """spasm_amd_echelonize_multi under the reference's default options (enable_greedy_pivot_search = 1): its sharded rounds run
+    "FL on columns" over the shards; round for round the pivots are those of the single-device rounds without the third search."""
+    A = S.synth_csr(kind, n, m, prime=prime, seed=0x0C01, **kw)
+    monkeypatch.setenv("SPASM_AMD_MULTI_FINISH_NNZ", "1")          # sparse rounds as far as they go
+    monkeypatch.setenv("SPASM_AMD_MULTI_DENSE_MIN_BYTES", str(1 << 60))
+    try:
+        got = S.echelonize_multi(A, nshards, enable_dense=False, max_round=1 << 20)
+    finally:
+        monkeypatch.delenv("SPASM_AMD_MULTI_FINISH_NNZ")
+        monkeypatch.delenv("SPASM_AMD_MULTI_DENSE_MIN_BYTES")
+    monkeypatch.setenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH", "1")
+    try:
+        ref = S.echelonize(A, enable_dense=False, max_round=1 << 20)
+        ref_rounds = S.last_rounds()
+    finally:
+        monkeypatch.delenv("SPASM_AMD_NO_CYCLE_FREE_SEARCH")
+    assert got.r == ref.r == O.echelonize(A, **LM).r
+    assert S.factorization_verify(A, got, 5)
+    assert int(ref_rounds[0]["npiv_open"]) > 0
+    # round 0: the same pivots, leftmost and on open columns, hence the same rows of U (later rounds too as long as both loops go on
+    # the same way; where they stop is a rule of each loop)
+    k = int(ref_rounds[0]["npiv"])
+    assert got.U.rows()[:k] == ref.U.rows()[:k]
+    from test_gpu_default_options import rows_to_dense
+
+    if m <= 2600:
+        Kd = O.dense_rref(rows_to_dense(S.kernel(ref).rows(), m, prime), prime)[0]
+        Ks = O.dense_rref(rows_to_dense(S.kernel(got).rows(), m, prime), prime)[0]
         assert Kd.shape == Ks.shape and (np.asarray(Kd) == np.asarray(Ks)).all()
 
 
@@ -219,10 +333,10 @@ def test_dense_finish_over_row_shards(S, O, monkeypatch, kind, n, m, kw, prime, 
     monkeypatch.setenv("SPASM_AMD_MULTI_DENSE_MIN_BYTES", "0")  # (by default remainders below 16 GiB are finished on one device)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    got = S.echelonize_multi(A, nshards)
+    got = S.echelonize_multi(A, nshards, **LM)
     how = S._abi.lib().spasm_amd_multi_last_finish()
     monkeypatch.setenv("SPASM_AMD_MULTI_GATHER", "1")
-    old = S.echelonize_multi(A, nshards)            # the hand-off to device 0, as before
+    old = S.echelonize_multi(A, nshards, **LM)      # the hand-off to device 0, as before
     assert S._abi.lib().spasm_amd_multi_last_finish() == 0
     monkeypatch.delenv("SPASM_AMD_MULTI_GATHER")
     for k in env:
@@ -250,7 +364,7 @@ def test_dense_finish_over_row_shards_rank_deficient(S, O, monkeypatch):
     monkeypatch.setenv("SPASM_AMD_MULTI_FINISH_NNZ", "1000")
     monkeypatch.setenv("SPASM_AMD_MULTI_DENSE_MIN_BYTES", "0")
     monkeypatch.setenv("SPASM_AMD_DENSE_KB", "128")
-    got = S.echelonize_multi(A, 3)
+    got = S.echelonize_multi(A, 3, **LM)
     assert S._abi.lib().spasm_amd_multi_last_finish() == 2
     assert got.r == ref.r <= 150
     assert np.asarray(got.qinv >= 0).tolist() == np.asarray(ref.qinv >= 0).tolist()
