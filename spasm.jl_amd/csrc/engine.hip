@@ -160,21 +160,32 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
 
 // grid = min(rows, resident workgroups): the kernels walk their row list with a grid stride, and a workgroup that is not resident
 // from the start would do its share after everybody else (the LDS bound alone can be above what the registers admit)
-template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1> void launch_wstream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
+template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1, int EPL = 1> void launch_wstream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
     static int per_cu_dev[kMaxDev] = {0};
     int &per_cu = per_cu_dev[current_device()];
     if (!per_cu) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>, WPB * 64, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL>, WPB * 64, lds));
         per_cu = std::max(nb, 1);
     }
     if (nrows <= 0) return; // (warm-up call: attributes and occupancy only)
     const int rows_per_block = TPR == 64 ? WPB : 1;
     const int grid = std::max(1, std::min((nrows + rows_per_block - 1) / rows_per_block, num_cu * per_cu));
-    hipLaunchKernelGGL((k_wstream<LOGT, TPR, WPB, B, SMALL, MINW>), dim3(grid), dim3(WPB * 64), lds, s, a);
+    hipLaunchKernelGGL((k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL>), dim3(grid), dim3(WPB * 64), lds, s, a);
     HIPCHK(hipGetLastError());
+}
+
+// chunks of the plan along W: 2^6 entries (a lane of the streaming kernel takes one entry per chunk) or 2^7 (two: one 16-byte load and,
+// where the chunk is full, one 16-byte store per lane; half the per-chunk work).  SPASM_AMD_CHUNK = 64 | 128.
+// Measured on config 3 (the rows of W average 170 entries): chunks of 128 are SLOWER, 3.75 ms per step against 3.33 -- a run of 170
+// entries is three chunks of 64 (89 % of the lanes busy) or two of 128 (66 %), and a chunk of the two-entry kernel costs 1.7 x the
+// instructions of a one-entry chunk: nothing is saved below runs of ~500 entries.  Default 64; the other stays for such matrices.
+inline int stream_chunk_log()
+{
+    const char *e = getenv("SPASM_AMD_CHUNK"); // (read per launch: a test sets it for one case)
+    return e && atoi(e) == 128 ? 7 : 6;
 }
 
 // the streaming twins of the hash-table classes (row bounds up to 160 << c): first table of 256 << c words (at most 5/8 full); a
@@ -183,8 +194,21 @@ const int kNumStreamClasses = 7;
 inline int stream_logt(int c) { return 8 + c; }
 inline int stream_tpr(int c) { return c <= 2 ? 64 : (c == 3 ? 128 : 256); }
 inline int stream_wpb(int c) { return c == 3 ? 2 : 4; }
-template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
+template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s, int chunk_log = 6)
 {
+    if (chunk_log == 7) {
+        switch (cls) { // (ring slots D: chunks of 128 in flight per wave)
+        case 0: launch_wstream<8, 64, 4, 2, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
+        case 1: launch_wstream<9, 64, 4, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
+        case 2: launch_wstream<10, 64, 4, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
+        case 3: launch_wstream<11, 128, 2, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
+        case 4: launch_wstream<12, 256, 4, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
+        case 5: launch_wstream<13, 256, 4, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
+        case 6: launch_wstream<14, 256, 4, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
+        default: break;
+        }
+        return;
+    }
     switch (cls) {
     case 0: launch_wstream<8, 64, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;
     case 1: launch_wstream<9, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
@@ -235,6 +259,7 @@ struct Round {
     DevBuf<int2> fixbuf;            // per row slot: SFIX duplicates found by the streaming kernels, merged by k_stream_fix
     DevBuf<int> fixcnt;
     bool use_stream = true;         // SPASM_AMD_STREAM=0 turns W and the streaming scatter off
+    int chunk_log = 6;              // entries per chunk record of the last plan along W (2^6 or 2^7: stream_chunk_log)
     // W = -(I + U_PP)^-1 U_PN (stream.hpp), built level by level of the pivot graph (wlevel.hpp).  One buffer, addressed by 32-bit
     // offsets: [U_PN | the own non-pivot entries of the rows the plan kernel takes | the rows of W]
     bool use_w = false;
@@ -1240,6 +1265,8 @@ struct Round {
             wp.overflow_count = &ctr.p->wplan_reject;
             wp.ctr = ctr.p;
             wp.F = F;
+            chunk_log = stream_chunk_log(); // (the streaming kernels of this solve's scatter take what the plan cut)
+            wp.chunk_log = chunk_log;
             constexpr int TEAM = 16, TPB = 256;
             hipLaunchKernelGGL((k_wplan<TEAM, TPB>), dim3(std::min(cdiv((i64)nrows * TEAM, TPB), num_cu * 16)), dim3(TPB), 0, stream, wp);
             HIPCHK(hipGetLastError());
@@ -1433,8 +1460,8 @@ struct Round {
         }
         for (int c = 0; c < std::min(nhash, kNumStreamClasses); c++) {
             const size_t lds = stream_lds_bytes(stream_logt(c), stream_tpr(c), stream_wpb(c));
-            if (F.small) launch_stream_class<true>(c, sa, 0, num_cu, lds, stream);
-            else launch_stream_class<false>(c, sa, 0, num_cu, lds, stream);
+            if (F.small) launch_stream_class<true>(c, sa, 0, num_cu, lds, stream, stream_chunk_log());
+            else launch_stream_class<false>(c, sa, 0, num_cu, lds, stream, stream_chunk_log());
         }
     }
 
@@ -1548,8 +1575,8 @@ struct Round {
             sa.redo_count = class_count.p + c;
             sa.redo_desc = class_desc.p + (size_t)c * nrows;
             const size_t lds = stream_lds_bytes(stream_logt(c), stream_tpr(c), stream_wpb(c));
-            if (F.small) launch_stream_class<true>(c, sa, nrows, num_cu, lds, s);
-            else launch_stream_class<false>(c, sa, nrows, num_cu, lds, s);
+            if (F.small) launch_stream_class<true>(c, sa, nrows, num_cu, lds, s, chunk_log);
+            else launch_stream_class<false>(c, sa, nrows, num_cu, lds, s, chunk_log);
         };
         // the duplicates the streaming kernels found are merged afterwards, a wave per row that has any
         auto launch_stream_fix = [&](hipStream_t s) {

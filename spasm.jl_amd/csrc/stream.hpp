@@ -319,6 +319,7 @@ struct WPlanArgs {
     int *overflow_count;
     RoundCounters *ctr;
     ZpField F;
+    int chunk_log;             // 6: chunks of 64 entries (a lane of the streaming kernel takes one), 7: of 128 (a lane takes two)
 };
 
 // The plan of a row's Schur row under W: its stream = the row's own entries on non-pivot columns (copied, compacted, behind W: they
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
     const int tl = threadIdx.x % TEAM;
     const int team = threadIdx.x / TEAM;
     const ZpField F = a.F;
+    const int CL = a.chunk_log, CH = 1 << CL;
     u64d rpos = 0, rend = 0, opos = 0, oend = 0; // the team's current blocks (uniform in the team)
     auto take = [&](u64d &pos, u64d &end, u64d need, u64d blk, u64d *ctr, u64d cap) -> u64d {
         if (pos + need > end) {
@@ -395,12 +397,12 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
             const u64d mP = team_ballot<TEAM>(isP);
             if (k0 < 64) pm |= mP << (k0 & 63);
             int tot;
-            (void)team_incl_scan<TEAM>(isP ? (ci.y + 63) >> 6 : 0, tot);
+            (void)team_incl_scan<TEAM>(isP ? (ci.y + CH - 1) >> CL : 0, tot);
             C += tot;
             nN += __popcll(team_ballot<TEAM>(valid && !isP));
         }
         const bool anyzero = team_ballot<TEAM>(zero_own) != 0;
-        const int own_chunks = (nN + 63) >> 6;
+        const int own_chunks = (nN + CH - 1) >> CL;
         const int R = C + own_chunks;
         const u64d base = take(rpos, rend, (u64d)R, RBLK, a.pool_ctr, a.lpool_cap);
         const u64d obase = base == ~0ull ? ~0ull : take(opos, oend, (u64d)nN, OBLK, a.own_ctr, a.own_cap);
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
             no += __popcll(mN);
             // its run, when it sits on a pivot column
             const int len = isP ? ci.y : 0;
-            const int nch = (len + 63) >> 6;
+            const int nch = (len + CH - 1) >> CL;
             int tot, ctot;
             const int incl = team_incl_scan<TEAM>(len, tot);
             const int cincl = team_incl_scan<TEAM>(nch, ctot);
@@ -433,9 +435,9 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
             i64d pre = run + incl - len;
             int4 *out = a.Lpool + base + w + (cincl - nch);
             for (int q = 0; q < nch; q++) { // (the lanes of a team have runs of different lengths)
-                const int clen = min(64, len - 64 * q);
+                const int clen = min(CH, len - CH * q);
                 const unsigned px = (pre < 0x8000 ? (unsigned)pre : 0x7fffu) << 16 | (unsigned)clen;
-                out[q] = make_int4((int)px, nm, (int)((unsigned)ci.z + 64u * (unsigned)q), clen);
+                out[q] = make_int4((int)px, nm, (int)((unsigned)ci.z + (unsigned)CH * (unsigned)q), clen);
                 pre += clen;
             }
             w += ctot;
@@ -443,8 +445,8 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
         }
         if (room) // the own entries as chunks with multiplier 1 (the scatter kernels subtract record.y times the entry)
             for (int q = tl; q < own_chunks; q += TEAM) {
-                const int clen = min(64, nN - 64 * q);
-                a.Lpool[base + q] = make_int4((int)(((unsigned)(64 * q) << 16) | (unsigned)clen), -1, (int)(a.own_base + (unsigned)obase + 64u * (unsigned)q), clen);
+                const int clen = min(CH, nN - CH * q);
+                a.Lpool[base + q] = make_int4((int)(((unsigned)(CH * q) << 16) | (unsigned)clen), -1, (int)(a.own_base + (unsigned)obase + (unsigned)CH * (unsigned)q), clen);
             }
         if (tl == 0) {
             if (base == ~0ull) { // the record pool is full: the host grows it and runs the plan again
@@ -479,9 +481,14 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
 // row before it is being finished.
 // TPR = threads per row (64: a wave per row, WPB rows per workgroup; else the workgroup).
 // ------------------------------------------------------------------------------------------------
-template <int LOGT, int TPR, int WPB, int D, bool SMALL, int MINW>
+// EPL = entries per lane and chunk: 1 (chunks of up to 64 entries, an 8-byte load and store per lane) or 2 (chunks of up to 128: a lane
+// takes the entries 2 l and 2 l + 1 with ONE 16-byte load, and one 16-byte store where the chunk is full; the per-chunk work --
+// the record's fields by v_readlane, the ring slot, the group bookkeeping -- is paid once per 128 entries).
+typedef int v4i32s __attribute__((ext_vector_type(4)));
+template <int LOGT, int TPR, int WPB, int D, bool SMALL, int MINW, int EPL = 1>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
 {
+    static_assert(EPL == 1 || EPL == 2, "one or two entries per lane");
     constexpr bool WAVE_ROW = (TPR == 64);
     static_assert(WAVE_ROW || TPR == WPB * 64, "a row is owned by one wave or by the whole workgroup");
     constexpr int NW = WAVE_ROW ? 1 : WPB; // waves sharing a row
@@ -527,7 +534,18 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
     // the ring of chunk loads.  Always D requests per row (slots past the wave's last chunk repeat it, a wave without chunks reads
     // entry 0): with a number of loads that depends on the row the compiler can only wait for ALL loads in flight when an older
     // one is needed.
-    int2 ring[D];
+    // (EPL = 2: a slot holds the entries 2 l and 2 l + 1 of its chunk -- the load is clamped to the chunk's last entry, the entry
+    // behind that one belongs to somebody else and is replaced by a copy of the first where it is used)
+    typedef typename std::conditional<EPL == 2, int4, int2>::type ring_t;
+    ring_t ring[D];
+    auto ring_load = [&](unsigned off, int clen) -> ring_t {
+        if constexpr (EPL == 2) {
+            const v4i32s v = *(const v4i32s *)(a.UPN + (size_t)off + (unsigned)min(2 * lane, clen - 1));
+            return make_int4(v.x, v.y, v.z, v.w);
+        } else {
+            return a.UPN[(size_t)off + (unsigned)min(lane, clen - 1)];
+        }
+    };
     auto request = [&](const int4 &rc, int nmine, bool live) {
 #pragma unroll
         for (int j = 0; j < D; j++) {
@@ -535,8 +553,10 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
             const bool have = live && nmine > 0;
             const unsigned off = have ? (unsigned)__builtin_amdgcn_readlane(rc.z, g) : 0u;
             const int clen = have ? __builtin_amdgcn_readlane(rc.w, g) : 1;
-            if (SCATTER_DBG(a, 8)) ring[j] = make_int2(lane + 4096 * j, 1);
-            else ring[j] = a.UPN[(size_t)off + (unsigned)min(lane, clen - 1)];
+            if constexpr (EPL == 1) {
+                if (SCATTER_DBG(a, 8)) { ring[j] = make_int2(lane + 4096 * j, 1); continue; }
+            }
+            ring[j] = ring_load(off, clen);
         }
     };
     auto chunks_of = [&](int ll) { return ll > rw ? (ll - rw + NW - 1) / NW : 0; };
@@ -558,55 +578,90 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
         // ---- the chunks, Q at a time: the first-table CAS of all Q are in flight together, then the second- and third-table ones.
         // The first D come from the ring, in straight-line code (a loop header would cost a vmcnt(0)); what a wave has beyond them
         // (few rows) is loaded and used group by group in a loop.
-        constexpr int Q = D >= 4 ? 4 : D;
+        // Q chunks = NE entries of a lane per group
+        constexpr int Q = EPL == 2 ? (D >= 2 ? 2 : 1) : (D >= 4 ? 4 : D);
+        constexpr int NE = Q * EPL;
         static_assert(D % Q == 0, "whole groups of slots");
-        auto do_group = [&](const int2 (&e)[Q], int g0, int nthere) {
-            int cc[Q], vv[Q], pp[Q], cl[Q];
-            unsigned oo[Q], left[Q];
+        auto do_group = [&](const ring_t (&e)[Q], int g0, int nthere) {
+            int cc[NE], vv[NE], pp[NE], cl[Q];
+            bool there[NE]; // the entry is the lane's own (not a clamped copy)
+            unsigned oo[NE], left[NE];
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const int g = min(g0 + q, max(my_chunks - 1, 0));
                 const int rx = __builtin_amdgcn_readlane(rec.x, g);
+                const int nmul = -__builtin_amdgcn_readlane(rec.y, g);
                 cl[q] = rx & 0xffff;
-                cc[q] = e[q].x;
-                vv[q] = stream_mul<SMALL>(F, -__builtin_amdgcn_readlane(rec.y, g), e[q].y);
-                pp[q] = (int)((unsigned)rx >> 16) + min(lane, cl[q] - 1) + 1;
-                oo[q] = 0;
-                left[q] = 0;
+                if constexpr (EPL == 2) {
+                    const int i0 = min(2 * lane, cl[q] - 1);
+                    const bool second = 2 * lane + 1 < cl[q]; // (else: a copy of the first, same position: storing and inserting it again changes nothing)
+                    cc[2 * q] = e[q].x;
+                    vv[2 * q] = stream_mul<SMALL>(F, nmul, e[q].y);
+                    pp[2 * q] = (int)((unsigned)rx >> 16) + i0 + 1;
+                    cc[2 * q + 1] = second ? e[q].z : e[q].x;
+                    vv[2 * q + 1] = second ? stream_mul<SMALL>(F, nmul, e[q].w) : vv[2 * q];
+                    pp[2 * q + 1] = pp[2 * q] + (second ? 1 : 0);
+                    there[2 * q] = 2 * lane < cl[q];
+                    there[2 * q + 1] = second;
+                } else {
+                    cc[q] = e[q].x;
+                    vv[q] = stream_mul<SMALL>(F, nmul, e[q].y);
+                    pp[q] = (int)((unsigned)rx >> 16) + min(lane, cl[q] - 1) + 1;
+                    there[q] = lane < cl[q];
+                }
             }
-            if (nthere >= Q) { // a full group (wave-uniform)
 #pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    if (!SCATTER_DBG(a, 1)) __builtin_nontemporal_store(((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q], (long long *)(rowp + ((unsigned)(pp[q] - 1) << 3)));
+            for (int k = 0; k < NE; k++) { oo[k] = 0; left[k] = 0; }
+            auto store_chunk = [&](int q) {
+                if constexpr (EPL == 2) {
+                    if (cl[q] == 128) { // (wave-uniform) a full chunk: both entries of every lane in one 16-byte store
+                        v4i32s v;
+                        v.x = cc[2 * q]; v.y = vv[2 * q]; v.z = cc[2 * q + 1]; v.w = vv[2 * q + 1];
+                        __builtin_nontemporal_store(v, (v4i32s *)(rowp + ((unsigned)(pp[2 * q] - 1) << 3)));
+                    } else {
+                        __builtin_nontemporal_store(((long long)(unsigned)vv[2 * q] << 32) | (unsigned)cc[2 * q], (long long *)(rowp + ((unsigned)(pp[2 * q] - 1) << 3)));
+                        __builtin_nontemporal_store(((long long)(unsigned)vv[2 * q + 1] << 32) | (unsigned)cc[2 * q + 1], (long long *)(rowp + ((unsigned)(pp[2 * q + 1] - 1) << 3)));
+                    }
+                    mylead = min(mylead, min(cc[2 * q], cc[2 * q + 1]));
+                } else {
+                    __builtin_nontemporal_store(((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q], (long long *)(rowp + ((unsigned)(pp[q] - 1) << 3)));
                     mylead = min(mylead, cc[q]);
                 }
-                if (!SCATTER_DBG(a, 2)) stream_insert_n<LOGT, Q>(tb, cc, pp, oo, left);
+            };
+            if (nthere >= Q) { // a full group (wave-uniform)
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+                    if (!SCATTER_DBG(a, 1)) store_chunk(q);
+                    else if constexpr (EPL == 2) mylead = min(mylead, min(cc[2 * q], cc[2 * q + 1]));
+                    else mylead = min(mylead, cc[q]);
+                if (!SCATTER_DBG(a, 2)) stream_insert_n<LOGT, NE>(tb, cc, pp, oo, left);
             } else {
 #pragma unroll
                 for (int q = 0; q < Q; q++)
                     if (q < nthere) {
-                        __builtin_nontemporal_store(((long long)(unsigned)vv[q] << 32) | (unsigned)cc[q], (long long *)(rowp + ((unsigned)(pp[q] - 1) << 3)));
-                        mylead = min(mylead, cc[q]);
-                        const int c1[1] = {cc[q]}, p1[1] = {pp[q]};
-                        unsigned o1[1], l1[1];
-                        stream_insert_n<LOGT, 1>(tb, c1, p1, o1, l1);
-                        oo[q] = o1[0];
-                        left[q] = l1[0];
+                        store_chunk(q);
+                        int c1[EPL], p1[EPL];
+                        unsigned o1[EPL], l1[EPL];
+#pragma unroll
+                        for (int u = 0; u < EPL; u++) { c1[u] = cc[EPL * q + u]; p1[u] = pp[EPL * q + u]; }
+                        stream_insert_n<LOGT, EPL>(tb, c1, p1, o1, l1);
+#pragma unroll
+                        for (int u = 0; u < EPL; u++) { oo[EPL * q + u] = o1[u]; left[EPL * q + u] = l1[u]; }
                     }
             }
             unsigned any = 0;
 #pragma unroll
-            for (int q = 0; q < Q; q++) any |= left[q];
+            for (int k = 0; k < NE; k++) any |= left[k];
             if (__ballot(any != 0) != 0) { // rare: duplicates, triple losers; a lane past the end of its chunk holds a copy
 #pragma unroll
-                for (int q = 0; q < Q; q++)
-                    stream_report(stream_outcome(left[q]), oo[q], q < nthere && lane < cl[q], cc[q], vv[q], pp[q], mrow, fix, FCAP, lst);
+                for (int k = 0; k < NE; k++)
+                    stream_report(stream_outcome(left[k]), oo[k], k / EPL < nthere && there[k], cc[k], vv[k], pp[k], mrow, fix, FCAP, lst);
             }
         };
 #pragma unroll
         for (int j0 = 0; j0 < D; j0 += Q) {
             if (j0 < my_chunks) { // (wave-uniform)
-                int2 e[Q];
+                ring_t e[Q];
 #pragma unroll
                 for (int q = 0; q < Q; q++) e[q] = ring[j0 + q];
                 do_group(e, j0, my_chunks - j0);
@@ -615,11 +670,11 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
         if (my_chunks > D) {
             for (int g0 = D; g0 < my_chunks; g0 += Q) {
                 // (more than 64 chunks per wave do not occur: the plan kernel leaves such rows to the lists)
-                int2 e[Q];
+                ring_t e[Q];
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
                     const int g = min(g0 + q, my_chunks - 1);
-                    e[q] = a.UPN[(size_t)(unsigned)__builtin_amdgcn_readlane(rec.z, g) + (unsigned)min(lane, __builtin_amdgcn_readlane(rec.w, g) - 1)];
+                    e[q] = ring_load((unsigned)__builtin_amdgcn_readlane(rec.z, g), __builtin_amdgcn_readlane(rec.w, g));
                 }
                 do_group(e, g0, my_chunks - g0);
             }
