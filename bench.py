@@ -235,6 +235,9 @@ def main():
             "w_buffer_sizing_and_allocation_ms": round(d.get("ms_w_sizing", 0.0), 4),
             "per_class_ms": {"hash": [round(x, 4) for x in d["ms_class"][:8]], "stream": [round(x, 4) for x in d["ms_class"][8:15]]},
             "per_class_rows": {"hash": d["rows_class"][:8], "stream": d["rows_class"][8:15]},
+            # streamed entries and (rows + chunk records) of the streaming classes: entries / (64 * chunks) = share of busy lanes
+            "per_class_entries": {"stream": d["ent_class"][8:15]},
+            "per_class_chunks": {"stream": [int(sg) - int(rw) for sg, rw in zip(d["seg_class"][8:15], d["rows_class"][8:15])]},
             "stream_fix": d["stream_fix"], "stream_redo": d["stream_redo"], "stream_fix_ms": round(d["ms_class"][15], 4),
             "fused": {"ms": round(d.get("ms_fused", 0.0), 4), "fix_ms": round(d.get("ms_fused_fix", 0.0), 4), "rows": d.get("rows_fused", 0),
                       "entries": d.get("ent_fused", 0), "segments": d.get("seg_fused", 0), "rows_left_to_general_path": d.get("rows_rejected", 0),
