@@ -400,6 +400,9 @@ typedef struct spasm_amd_dshard spasm_amd_dshard;
 spasm_amd_schur_plan *spasm_amd_shard_import_U(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev);
 int spasm_amd_schur_plan_prepare(spasm_amd_schur_plan *plan);
 spasm_amd_dshard *spasm_amd_dshard_open(spasm_amd_schur_plan *plan, int me, int nshards);
+/* r04: the same finish over the shard's CURRENT rows (a remainder that is dense already; no round, no U): _flags / _density (returns 1.0)
+ * / _build and the panel steps as after spasm_amd_dshard_open.  The shard stays the caller's. */
+spasm_amd_dshard *spasm_amd_dshard_open_rows(spasm_amd_shard *sh, int me, int nshards);
 int spasm_amd_dshard_flags(spasm_amd_dshard *ds, int *flags_dev);
 double spasm_amd_dshard_density(spasm_amd_dshard *ds, const int *flags_dev, int free_cols, int *C_out);
 int spasm_amd_dshard_build(spasm_amd_dshard *ds);

@@ -228,6 +228,7 @@ SIGNATURES = {
     "spasm_amd_shard_import_U": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "spasm_amd_schur_plan_prepare": (C.c_int32, [C.c_void_p]),
     "spasm_amd_dshard_open": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32]),
+    "spasm_amd_dshard_open_rows": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "spasm_amd_dshard_flags": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "spasm_amd_dshard_density": (C.c_double, [C.c_void_p, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "spasm_amd_dshard_build": (C.c_int32, [C.c_void_p]),

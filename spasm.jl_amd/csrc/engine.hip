@@ -5667,6 +5667,7 @@ struct spasm_lu *do_echelonize_multi(const struct spasm_csr *A, struct echeloniz
 struct DShardBase {
     virtual ~DShardBase() {}
     virtual void build(spasm_amd_schur_plan *P, DenseW &W, int me, int nshards, int C) = 0;
+    virtual void build_rows(spasm_amd_schur_plan *P, DenseFill &fl, int me, int nshards, int C) = 0; // the live rows of P->A instead of a round's Schur rows
     virtual void block_begin() = 0;
     virtual void candidates(int c0, int w, void *cand_dev) = 0;
     virtual void elect(const void *stack_dev, int w) = 0;
@@ -5695,6 +5696,20 @@ template <typename DT> struct DShardT : DShardBase {
         sh.R = P->R.nnp;
         sh.s = P->R.stream;
         schur_dense_build(P->R, P->A, sh.R, W, sh.KB, sh.D, sh.row_orig, P->R.stream);
+        sh.setup(nsh, true);
+    }
+    void build_rows(spasm_amd_schur_plan *P, DenseFill &fl, int me, int nsh, int C) override
+    {
+        nshards = nsh;
+        memset(&hglob, 0, sizeof hglob);
+        sh.me = me;
+        sh.C = C;
+        sh.ldc = ((i64)C + 63) / 64 * 64;
+        sh.F = P->R.F;
+        sh.KB = dense_kb();
+        sh.R = fl.R;
+        sh.s = P->R.stream;
+        fl.build(sh.KB, sh.D, sh.row_orig); // (KB guest rows behind the shard's own, as schur_dense_build leaves them)
         sh.setup(nsh, true);
     }
     void block_begin() override { sh.block_begin(); }
@@ -5728,7 +5743,10 @@ template <typename DT> struct DShardT : DShardBase {
 
 struct spasm_amd_dshard {
     spasm_amd_schur_plan *plan = nullptr; // not owned
-    std::unique_ptr<DenseW> dw;
+    std::unique_ptr<DenseW> dw;           // the Schur rows of the plan's round through the dense W ..
+    std::unique_ptr<DenseFill> fl;        // .. or (spasm_amd_dshard_open_rows) the live rows of the shard's matrix as they are
+    const int *cflag() const { return fl ? fl->cflag.p : dw->cflag.p; }
+    const int *clist() const { return fl ? fl->clist.p : dw->clist.p; }
     std::unique_ptr<DShardBase> impl;
     int me = 0, nshards = 1, C = 0;
 };
@@ -5752,12 +5770,31 @@ spasm_amd_dshard *dshard_open(spasm_amd_schur_plan *P, int me, int nshards)
     return ds.release();
 }
 
+// the same over the shard's CURRENT rows (no round, no U): a remainder that is dense already is eliminated by all ranks together
+// where it is (the one-process path's dense_now)
+spasm_amd_dshard *dshard_open_rows(spasm_amd_shard *S, int me, int nshards)
+{
+    if (!S || !S->plan) throw EngineError("spasm_amd_dshard_open_rows: null shard");
+    spasm_amd_schur_plan *P = S->plan;
+    if (!P->R.F.small) throw EngineError("spasm_amd_dshard_open_rows: the dense finish over shards takes primes below 2^16");
+    const int elem = P->R.F.p <= 255 ? 1 : 2;
+    if (nshards < 1 || nshards > DM_MAXSHARDS || nshards * DP_W > 147456 / (DP_W * elem)) throw EngineError("spasm_amd_dshard_open_rows: too many shards for the election workgroup");
+    if (me < 0 || me >= nshards) throw EngineError("spasm_amd_dshard_open_rows: shard number out of range");
+    std::unique_ptr<spasm_amd_dshard> ds(new spasm_amd_dshard());
+    ds->plan = P;
+    ds->me = me;
+    ds->nshards = nshards;
+    ds->fl.reset(new DenseFill(P->A, P->R.stream));
+    ds->fl->flag_columns();
+    return ds.release();
+}
+
 // the rows of U this shard owns after the finish, as a host CSR; pivcol_out / row_out: their pivot columns and originating rows
 struct spasm_csr *dshard_fetch_U(spasm_amd_dshard *ds, int *pivcol_out, int *row_out, int *n_out)
 {
     HostU U;
     U.p.push_back(0);
-    const int got = ds->impl->extract(ds->dw->clist.p, U);
+    const int got = ds->impl->extract(ds->clist(), U);
     const i64 nz = U.p.back();
     struct spasm_csr *Uc = spasm_csr_alloc(got, ds->plan->A.m, nz, ds->plan->prime, true);
     if (!Uc) throw EngineError("out of host memory for the shard's rows of U");
@@ -6296,7 +6333,7 @@ SPASM_API int spasm_amd_multi_last_finish(void) { return g_multi_finish; }
     catch (const std::exception &e) { spasm_set_error(name ": %s", e.what()); return fail; }
 // (a step called out of order -- no handle, or before dshard_build -- is an error, not a crash)
 #define DSHARD_BUILT(ds) do { if (!(ds) || !(ds)->impl) throw EngineError("no dense shard (spasm_amd_dshard_open / _density / _build come first)"); } while (0)
-#define DSHARD_OPEN(ds) do { if (!(ds) || !(ds)->dw) throw EngineError("no dense shard (spasm_amd_dshard_open comes first)"); } while (0)
+#define DSHARD_OPEN(ds) do { if (!(ds) || (!(ds)->dw && !(ds)->fl)) throw EngineError("no dense shard (spasm_amd_dshard_open comes first)"); } while (0)
 
 SPASM_API spasm_amd_schur_plan *spasm_amd_shard_import_U(spasm_amd_shard *sh, int n_rows, i64 n_entries, const int *hdr_dev, const int *ent_dev)
 {
@@ -6310,14 +6347,24 @@ SPASM_API spasm_amd_dshard *spasm_amd_dshard_open(spasm_amd_schur_plan *plan, in
 {
     DSHARD_TRY("spasm_amd_dshard_open", return dshard_open(plan, me, nshards);, nullptr)
 }
+SPASM_API spasm_amd_dshard *spasm_amd_dshard_open_rows(spasm_amd_shard *sh, int me, int nshards)
+{
+    DSHARD_TRY("spasm_amd_dshard_open_rows", return dshard_open_rows(sh, me, nshards);, nullptr)
+}
 SPASM_API int spasm_amd_dshard_flags(spasm_amd_dshard *ds, int *flags_dev)
 {
     DSHARD_TRY("spasm_amd_dshard_flags", DSHARD_OPEN(ds);
-               HIPCHK(hipMemcpy(flags_dev, ds->dw->cflag.p, ((size_t)ds->plan->A.m + 1) * sizeof(int), hipMemcpyDeviceToDevice)); return 0;, -1)
+               HIPCHK(hipMemcpy(flags_dev, ds->cflag(), ((size_t)ds->plan->A.m + 1) * sizeof(int), hipMemcpyDeviceToDevice)); return 0;, -1)
 }
 SPASM_API double spasm_amd_dshard_density(spasm_amd_dshard *ds, const int *flags_dev, int free_cols, int *C_out)
 {
     DSHARD_TRY("spasm_amd_dshard_density", DSHARD_OPEN(ds);
+               if (ds->fl) { // the rows as they are: the density is the matrix's own, which the caller knows; 1.0 = "dense, as you said"
+                   HIPCHK(hipMemcpy(ds->fl->cflag.p, flags_dev, ((size_t)ds->plan->A.m + 1) * sizeof(int), hipMemcpyDeviceToDevice));
+                   ds->C = ds->fl->finish_columns();
+                   if (C_out) *C_out = ds->C;
+                   return 1.0;
+               }
                HIPCHK(hipMemcpy(ds->dw->cflag.p, flags_dev, ((size_t)ds->plan->A.m + 1) * sizeof(int), hipMemcpyDeviceToDevice));
                ds->C = ds->dw->finish_columns();
                if (C_out) *C_out = ds->C;
@@ -6330,7 +6377,8 @@ SPASM_API int spasm_amd_dshard_build(spasm_amd_dshard *ds)
                if (ds->C <= 0) throw EngineError("no column left (call spasm_amd_dshard_density first)");
                if (ds->plan->R.F.p <= 255) ds->impl.reset(new DShardT<signed char>());
                else ds->impl.reset(new DShardT<short>());
-               ds->impl->build(ds->plan, *ds->dw, ds->me, ds->nshards, ds->C);
+               if (ds->fl) ds->impl->build_rows(ds->plan, *ds->fl, ds->me, ds->nshards, ds->C);
+               else ds->impl->build(ds->plan, *ds->dw, ds->me, ds->nshards, ds->C);
                return 0;, -1)
 }
 SPASM_API int spasm_amd_dshard_info(spasm_amd_dshard *ds, int *C_out, int *KB, i64 *ldc, int *elem, int *nd, int *cand_bytes)

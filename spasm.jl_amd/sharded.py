@@ -311,13 +311,15 @@ def _chk(rc, what):
     return rc
 
 
-def dense_round_sharded(eng, free_cols, sparsity_threshold, group=None, force=False):
+def dense_round_sharded(eng, free_cols, sparsity_threshold, group=None, force=False, rows=False):
     """The round whose pivots have just been exchanged (eng.plan holds U, unprepared), when its Schur complement is dense: every
     rank's Schur rows go straight into its dense matrix and the ranks eliminate them TOGETHER (csrc/dense_multi.hpp: rows stay where
     they are; per panel of 64 columns an all-gather of the candidates' panel entries, the election on every rank, one broadcast of
     the winners' rows per owner).  Returns None when the round stays sparse (estimated density at or below the threshold), else this
     rank's share of the rows of U as (row lengths, columns, values, pivot columns, original rows) and the number of pivots found by
-    all ranks."""
+    all ranks.
+    rows=True: no round at all -- the ranks' CURRENT rows (a remainder that is dense already) are eliminated together where they
+    are (spasm_amd_dshard_open_rows; the one-process path's dense_now)."""
     import numpy as np
 
     from .api import CSR
@@ -325,7 +327,7 @@ def dense_round_sharded(eng, free_cols, sparsity_threshold, group=None, force=Fa
     lib = eng.lib
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    ds = lib.spasm_amd_dshard_open(eng.plan, rank, world)
+    ds = lib.spasm_amd_dshard_open_rows(eng.shard, rank, world) if rows else lib.spasm_amd_dshard_open(eng.plan, rank, world)
     if not ds:
         raise RuntimeError("spasm_amd_dshard_open failed: " + _abi.last_error())
     try:
@@ -493,6 +495,20 @@ def echelonize_sharded(A, group=None, finish_nnz=1 << 22, max_rounds=1 << 30, en
             if not dense_ok and rounds and not rounds[-1]["finish"] and rounds[-1]["nnz"] > 0 and nnz_left > rounds[-1]["nnz"]:
                 predicted = nnz_left * (nnz_left / rounds[-1]["nnz"])
                 dense_enough = dense_enough or predicted > sparsity_threshold * rows_left * max(free_cols, 1)
+            if dense_ok and dense_enough and nnz_left > finish_nnz and len(rounds) < max_rounds:
+                # the remainder is dense ALREADY and worth sharing (these are the remainders that do not fit one device):
+                # no hand-off, no further round -- all ranks eliminate their rows together where they are
+                t_d = _time.time()
+                got = dense_round_sharded(eng, free_cols, sparsity_threshold, group, force=True, rows=True)
+                if got is not None:
+                    dblk, dpiv = got
+                    dblk = _gather_U_blocks(dblk, group)
+                    if len(dblk[0]):
+                        blocks.append(dblk)
+                        n_u += len(dblk[0])
+                    rounds.append({"round": len(rounds), "finish": True, "dense_over_shards": True, "dense_rows_as_they_are": True, "rows": rows_left,
+                                   "nnz": nnz_left, "npiv": int(dpiv), "seconds": {"dense_finish": _time.time() - t_d}})
+                    break
             if nnz_left <= finish_nnz or len(rounds) >= max_rounds or dense_enough:
                 # hand-off: every rank gets all remaining rows and finishes them (deterministic, so the results agree)
                 ids, p, j, x = eng.fetch_rows()

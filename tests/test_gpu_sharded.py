@@ -409,7 +409,10 @@ def _dense_over_ranks_worker(rank, world, port, kind, n, m, kw, p, seed, env, q)
     (2, 2, 4000, 1600, dict(row_nnz=30), 127, dict()),
     (4, 2, 5000, 2000, dict(row_nnz=30), 127, dict(SPASM_AMD_DENSE_KB="128")),
     (3, 1, 1500, 1200, dict(row_nnz=30), 65521, dict(SPASM_AMD_DENSE_KB="256")),
-], ids=["macaulay_2_ranks", "macaulay_4_ranks_several_blocks", "two_digits_3_ranks"])
+    # dense from the start: no round, the ranks' rows as they are (spasm_amd_dshard_open_rows; ADVICE r3, the one-process path's dense_now)
+    (2, 0, 900, 700, dict(density=0.3), 127, dict(SPASM_AMD_DENSE_KB="128")),
+    (3, 0, 500, 800, dict(density=0.2), 42013, dict()),
+], ids=["macaulay_2_ranks", "macaulay_4_ranks_several_blocks", "two_digits_3_ranks", "dense_already_2_ranks", "dense_already_3_ranks_wide"])
 def test_dense_finish_over_ranks(S, O, world, kind, n, m, kw, p, env):
     """The dense finish with ONE PROCESS PER SHARD (sharded.dense_round_sharded over the spasm_amd_dshard_* steps):
     2, 3 and 4 ranks share the test box's one GPU, the exchanges -- an all-gather of the candidate records, one broadcast of the
@@ -440,3 +443,5 @@ def test_dense_finish_over_ranks(S, O, world, kind, n, m, kw, p, env):
         assert rounds == results[0][5]
         assert any(d for _, _, d in rounds), rounds                        # the finish went over the ranks
         assert sum(np_ for _, np_, _ in rounds) == ref.r
+        if kind == 0:
+            assert len(rounds) == 1 and rounds[0][0] and rounds[0][2], rounds  # dense already: no sparse round, no hand-off
