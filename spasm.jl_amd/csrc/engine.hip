@@ -160,20 +160,20 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
 
 // grid = min(rows, resident workgroups): the kernels walk their row list with a grid stride, and a workgroup that is not resident
 // from the start would do its share after everybody else (the LDS bound alone can be above what the registers admit)
-template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1, int EPL = 1> void launch_wstream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
+template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1, int EPL = 1, int QX = 0> void launch_wstream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
     static int per_cu_dev[kMaxDev] = {0};
     int &per_cu = per_cu_dev[current_device()];
     if (!per_cu) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL>, WPB * 64, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX>, WPB * 64, lds));
         per_cu = std::max(nb, 1);
     }
     if (nrows <= 0) return; // (warm-up call: attributes and occupancy only)
     const int rows_per_block = TPR == 64 ? WPB : 1;
     const int grid = std::max(1, std::min((nrows + rows_per_block - 1) / rows_per_block, num_cu * per_cu));
-    hipLaunchKernelGGL((k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL>), dim3(grid), dim3(WPB * 64), lds, s, a);
+    hipLaunchKernelGGL((k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX>), dim3(grid), dim3(WPB * 64), lds, s, a);
     HIPCHK(hipGetLastError());
 }
 
@@ -208,6 +208,10 @@ template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int
         default: break;
         }
         return;
+    }
+    if (const char *e = getenv("SPASM_AMD_Q01")) { // A/B: two chunks per group for the rows of a few chunks (classes 0 and 1)
+        if (atoi(e) == 2 && cls == 0) { launch_wstream<8, 64, 4, 4, SMALL, 1, 1, 2>(a, nrows, num_cu, lds, s); return; }
+        if (atoi(e) == 2 && cls == 1) { launch_wstream<9, 64, 4, 8, SMALL, 1, 1, 2>(a, nrows, num_cu, lds, s); return; }
     }
     switch (cls) {
     case 0: launch_wstream<8, 64, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
 // takes the entries 2 l and 2 l + 1 with ONE 16-byte load, and one 16-byte store where the chunk is full; the per-chunk work --
 // the record's fields by v_readlane, the ring slot, the group bookkeeping -- is paid once per 128 entries).
 typedef int v4i32s __attribute__((ext_vector_type(4)));
-template <int LOGT, int TPR, int WPB, int D, bool SMALL, int MINW, int EPL = 1>
+template <int LOGT, int TPR, int WPB, int D, bool SMALL, int MINW, int EPL = 1, int QX = 0>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
 {
     static_assert(EPL == 1 || EPL == 2, "one or two entries per lane");
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
         // The first D come from the ring, in straight-line code (a loop header would cost a vmcnt(0)); what a wave has beyond them
         // (few rows) is loaded and used group by group in a loop.
         // Q chunks = NE entries of a lane per group
-        constexpr int Q = EPL == 2 ? (D >= 2 ? 2 : 1) : (D >= 4 ? 4 : D);
+        constexpr int Q = QX ? QX : (EPL == 2 ? (D >= 2 ? 2 : 1) : (D >= 4 ? 4 : D)); // (QX: chunks per group chosen by the caller)
         constexpr int NE = Q * EPL;
         static_assert(D % Q == 0, "whole groups of slots");
         auto do_group = [&](const ring_t (&e)[Q], int g0, int nthere) {

@@ -262,7 +262,7 @@ def test_echelonize_multi_in_one_process_matches_the_single_device_result(S, O, 
     p = np.asarray(got.p)[: got.r]
     assert len(set(p.tolist())) == got.r and (p >= 0).all() and (p < n).all()
     # the default-options single-device run (other pivot searches, other pivots): same rank, same kernel as a subspace
-    if m <= 2600:
+    if m <= 2600 and prime < (1 << 31):   # (beyond 2^31 the dense checker works on python integers: minutes)
         from test_gpu_default_options import rows_to_dense
 
         dflt = S.echelonize(A)
@@ -305,7 +305,7 @@ def test_echelonize_multi_default_options_runs_fl_on_columns_over_the_shards(S, 
     assert got.U.rows()[:k] == ref.U.rows()[:k]
     from test_gpu_default_options import rows_to_dense
 
-    if m <= 2600:
+    if m <= 2600 and prime < (1 << 31):
         Kd = O.dense_rref(rows_to_dense(S.kernel(ref).rows(), m, prime), prime)[0]
         Ks = O.dense_rref(rows_to_dense(S.kernel(got).rows(), m, prime), prime)[0]
         assert Kd.shape == Ks.shape and (np.asarray(Kd) == np.asarray(Ks)).all()
