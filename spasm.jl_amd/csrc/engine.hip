@@ -209,10 +209,8 @@ template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int
         }
         return;
     }
-    if (const char *e = getenv("SPASM_AMD_Q01")) { // A/B: two chunks per group for the rows of a few chunks (classes 0 and 1)
-        if (atoi(e) == 2 && cls == 0) { launch_wstream<8, 64, 4, 4, SMALL, 1, 1, 2>(a, nrows, num_cu, lds, s); return; }
-        if (atoi(e) == 2 && cls == 1) { launch_wstream<9, 64, 4, 8, SMALL, 1, 1, 2>(a, nrows, num_cu, lds, s); return; }
-    }
+    // (groups of two chunks instead of four for the classes whose rows have three to six chunks, so that fewer of them take the
+    // one-at-a-time path of a group that is not full: no difference, 0.1085 / 0.208 ms against 0.1083 / 0.2043; template parameter QX)
     switch (cls) {
     case 0: launch_wstream<8, 64, 4, 4, SMALL>(a, nrows, num_cu, lds, s); break;
     case 1: launch_wstream<9, 64, 4, 8, SMALL>(a, nrows, num_cu, lds, s); break;
