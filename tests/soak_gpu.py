@@ -49,8 +49,12 @@ def random_matrix():
 
 
 case = 0
+t_say = time.time()
 while time.time() < t_end:
     case += 1
+    if time.time() - t_say > 60:   # (a run that says nothing for minutes is taken to be hung)
+        print("soak:", case, "cases so far", done, flush=True)
+        t_say = time.time()
     A, p = random_matrix()
     setenv()
     ref = S.echelonize(A, **LM)
@@ -64,6 +68,22 @@ while time.time() < t_end:
         if rng.random() < 0.2:
             env["SPASM_AMD_PANEL_GLOBAL"] = 1
         setenv(**env)
+        if rng.random() < 0.4:
+            # r04: the reference's default options over the shards ("FL on columns" over the shards): other pivots than `ref`, the same
+            # rank, a U that verifies, a kernel of the same dimension with A k^T = 0; round 0's pivots are the single-device round's
+            # without the third search
+            got = S.echelonize_multi(A, nsh)
+            tag = ("multi default options", nsh, env, S._abi.lib().spasm_amd_multi_last_finish())
+            assert got.r == ref.r, ("rank", case, A.n, A.m, p, tag, got.r, ref.r)
+            assert S.factorization_verify(A, got, 3), ("verify", case, A.n, A.m, p, tag)
+            Kg = S.kernel(got)
+            assert Kg.n == A.m - ref.r, ("kernel dimension", case, tag)
+            Ar = A.rows()
+            for kv in Kg.rows()[:: max(1, Kg.n // 5)]:
+                kd = dict(kv)
+                assert all(sum(v * kd.get(c, 0) for c, v in row) % p == 0 for row in Ar[:: max(1, len(Ar) // 100)]), ("A k^T", case, tag)
+            done["multi"] += 1
+            continue
         got = S.echelonize_multi(A, nsh, **LM)
         tag = ("multi", nsh, env, S._abi.lib().spasm_amd_multi_last_finish())
         done["multi"] += 1
