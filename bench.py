@@ -19,7 +19,8 @@ region has no data-path collective.  A failing exchange ends the run with a non-
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the scatter launch of
 the busiest hash-table class): algorithmic bytes per launch over its HIP-event duration on the
-launch stream.  `cpu_baseline` times the CPU oracle (oracle/liboracle.so, OpenMP) on a bounded
+launch stream; `roofline.valu` holds the same launch against the ceiling it actually runs into (wave64 VALU issue: DESIGN.md section 8).
+`cpu_baseline` times the CPU oracle (oracle/liboracle.so, OpenMP) on a bounded
 sample of the same round, on rank 0 at N = 1 only.
 """
 import argparse
@@ -214,6 +215,26 @@ def main():
                         break
             except (OSError, KeyError, ValueError):
                 pass
+        # the same kernel against the OTHER ceiling it runs into: a CU retires one wave64 VALU instruction per clock (four 16-lane
+        # SIMDs, four clocks each).  SQ_INSTS_VALU per launch from the committed PMC pass (profiles/*_instruction_mix.txt, a separate
+        # run as the guide prescribes), over the live duration of this run; only for the workload it was measured on.
+        valu = None
+        if world == 1 and n == 1_000_000 and args.row_nnz == 20 and args.prime == 65521 and prefix and not fused and k_ms > 0:
+            try:
+                lines = open(os.path.join(ROOT, "profiles", "r04_final_instruction_mix.txt")).read().splitlines()
+                at = [i for i, ln in enumerate(lines) if ln.startswith("== " + prefix.rstrip(","))]
+                if len(at) == 1:
+                    for ln in lines[at[0] + 1: at[0] + 30]:
+                        if ln.startswith("=="):
+                            break
+                        f = ln.split()
+                        if len(f) == 2 and f[0] == "SQ_INSTS_VALU":
+                            insts = float(f[1])
+                            valu = {"wave_instructions_per_launch": int(insts), "peak_per_s": 256 * 2.4e9,
+                                    "frac_of_valu_peak": round(insts / (256 * 2.4e9 * k_ms * 1e-3), 4), "source": "r04_final_instruction_mix.txt",
+                                    "note": "one wave64 VALU instruction per CU and clock at 2.4 GHz; quarter-rate instructions count as one"}
+            except (OSError, ValueError):
+                pass
         roofline = {
             "bound": "hbm",
             "kernel": k_name,
@@ -222,6 +243,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "valu": valu,
             "bytes_per_launch": k_bytes,
             "ms_per_launch": round(k_ms, 4),
             "round_algorithmic_read_GBs": round(read_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1), 1) if ms_per_step > 0 else None,
