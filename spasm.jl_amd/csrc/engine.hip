@@ -160,20 +160,20 @@ template <bool SMALL> void launch_scatter_class(int cls, const ScatterArgs &a, i
 
 // grid = min(rows, resident workgroups): the kernels walk their row list with a grid stride, and a workgroup that is not resident
 // from the start would do its share after everybody else (the LDS bound alone can be above what the registers admit)
-template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1, int EPL = 1, int QX = 0> void launch_wstream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
+template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1, int EPL = 1, int QX = 0, bool BLOOM = false> void launch_wstream(const StreamArgs &a, int nrows, int num_cu, size_t lds, hipStream_t s)
 {
     static int per_cu_dev[kMaxDev] = {0};
     int &per_cu = per_cu_dev[current_device()];
     if (!per_cu) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX, BLOOM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX>, WPB * 64, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX, BLOOM>, WPB * 64, lds));
         per_cu = std::max(nb, 1);
     }
     if (nrows <= 0) return; // (warm-up call: attributes and occupancy only)
     const int rows_per_block = TPR == 64 ? WPB : 1;
     const int grid = std::max(1, std::min((nrows + rows_per_block - 1) / rows_per_block, num_cu * per_cu));
-    hipLaunchKernelGGL((k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX>), dim3(grid), dim3(WPB * 64), lds, s, a);
+    hipLaunchKernelGGL((k_wstream<LOGT, TPR, WPB, B, SMALL, MINW, EPL, QX, BLOOM>), dim3(grid), dim3(WPB * 64), lds, s, a);
     HIPCHK(hipGetLastError());
 }
 
@@ -182,6 +182,11 @@ template <int LOGT, int TPR, int WPB, int B, bool SMALL, int MINW = 1, int EPL =
 // Measured on config 3 (the rows of W average 170 entries): chunks of 128 are SLOWER, 3.75 ms per step against 3.33 -- a run of 170
 // entries is three chunks of 64 (89 % of the lanes busy) or two of 128 (66 %), and a chunk of the two-entry kernel costs 1.7 x the
 // instructions of a one-entry chunk: nothing is saved below runs of ~500 entries.  Default 64; the other stays for such matrices.
+inline bool stream_bloom()
+{
+    const char *e = getenv("SPASM_AMD_BLOOM");
+    return e && atoi(e) != 0;
+}
 inline int stream_chunk_log()
 {
     const char *e = getenv("SPASM_AMD_CHUNK"); // (read per launch: a test sets it for one case)
@@ -205,6 +210,19 @@ template <bool SMALL> void launch_stream_class(int cls, const StreamArgs &a, int
         case 4: launch_wstream<12, 256, 4, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
         case 5: launch_wstream<13, 256, 4, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
         case 6: launch_wstream<14, 256, 4, 4, SMALL, 1, 2>(a, nrows, num_cu, lds, s); break;
+        default: break;
+        }
+        return;
+    }
+    if (stream_bloom()) { // the duplicate check as a filter (stream.hpp: BLOOM)
+        switch (cls) {
+        case 0: launch_wstream<8, 64, 4, 4, SMALL, 1, 1, 0, true>(a, nrows, num_cu, lds, s); break;
+        case 1: launch_wstream<9, 64, 4, 8, SMALL, 1, 1, 0, true>(a, nrows, num_cu, lds, s); break;
+        case 2: launch_wstream<10, 64, 4, 8, SMALL, 1, 1, 0, true>(a, nrows, num_cu, lds, s); break;
+        case 3: launch_wstream<11, 128, 2, 8, SMALL, 1, 1, 0, true>(a, nrows, num_cu, lds, s); break;
+        case 4: launch_wstream<12, 256, 4, 8, SMALL, 1, 1, 0, true>(a, nrows, num_cu, lds, s); break;
+        case 5: launch_wstream<13, 256, 4, 8, SMALL, 1, 1, 0, true>(a, nrows, num_cu, lds, s); break;
+        case 6: launch_wstream<14, 256, 4, 8, SMALL, 1, 1, 0, true>(a, nrows, num_cu, lds, s); break;
         default: break;
         }
         return;

@@ -485,10 +485,17 @@ __global__ __launch_bounds__(TPB) void k_wplan(WPlanArgs a)
 // takes the entries 2 l and 2 l + 1 with ONE 16-byte load, and one 16-byte store where the chunk is full; the per-chunk work --
 // the record's fields by v_readlane, the ring slot, the group bookkeeping -- is paid once per 128 entries).
 typedef int v4i32s __attribute__((ext_vector_type(4)));
-template <int LOGT, int TPR, int WPB, int D, bool SMALL, int MINW, int EPL = 1, int QX = 0>
+// BLOOM: the duplicate check as a FILTER instead of the three exact tag tables.  A row's duplicates are rare (config 3: 0.35 per row of
+// 630 entries) but the tables make every entry pay for them -- hash, CAS, compare, and, because SOME lane of 64 always meets another
+// column, the second- and third-table code of every chunk: 33 of a chunk's 59 VALU.  Here an entry sets two bits of ONE word of a
+// 2^LOGT-word bitmap with one returning ds_or (one word: the later of two equal columns sees both bits set whatever the interleaving
+// of lanes and waves); an entry whose bits were set already is a SUSPECT (a duplicate, or ~0.1 % of the entries by chance), goes on
+// the row's list, and is resolved at the end of the row against the row itself, read back from where it was just stored.
+template <int LOGT, int TPR, int WPB, int D, bool SMALL, int MINW, int EPL = 1, int QX = 0, bool BLOOM = false>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
 {
     static_assert(EPL == 1 || EPL == 2, "one or two entries per lane");
+    static_assert(!(BLOOM && EPL == 2), "the filter is built for one entry per lane");
     constexpr bool WAVE_ROW = (TPR == 64);
     static_assert(WAVE_ROW || TPR == WPB * 64, "a row is owned by one wave or by the whole workgroup");
     constexpr int NW = WAVE_ROW ? 1 : WPB; // waves sharing a row
@@ -628,6 +635,35 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
                     mylead = min(mylead, cc[q]);
                 }
             };
+            if constexpr (BLOOM) {
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+                    if (q < nthere) store_chunk(q); // (wave-uniform)
+                unsigned msk[NE], wd[NE], ow[NE];
+#pragma unroll
+                for (int k = 0; k < NE; k++) {
+                    const unsigned h = stream_mul24(cc[k], STREAM_K1), h2 = stream_mul24(cc[k], STREAM_K2);
+                    // (all 1.75 * 2^LOGT words of the row's table area; three bits: a chance hit needs another entry in the word
+                    // AND its bits to cover these three -- about 0.005 % of the entries)
+                    wd[k] = (__builtin_amdgcn_ubfe(h, 8, 16) * (unsigned)StreamTabs<LOGT>::WORDS) >> 16;
+                    const unsigned m2 = (1u << __builtin_amdgcn_ubfe(h2, 19, 5)) | (1u << __builtin_amdgcn_ubfe(h2, 14, 5)) | (1u << __builtin_amdgcn_ubfe(h2, 9, 5));
+                    msk[k] = (k / EPL < nthere && there[k]) ? m2 : 0u; // (a clamped copy sets nothing and is never a suspect)
+                }
+#pragma unroll
+                for (int k = 0; k < NE; k++) ow[k] = atomicOr(&tb.t1[wd[k]], msk[k]);
+                bool sus = false;
+#pragma unroll
+                for (int k = 0; k < NE; k++) sus |= msk[k] != 0u && (ow[k] & msk[k]) == msk[k];
+                if (__ballot(sus) != 0) { // rare
+#pragma unroll
+                    for (int k = 0; k < NE; k++)
+                        if (msk[k] != 0u && (ow[k] & msk[k]) == msk[k]) {
+                            const int i = atomicAdd(mrow + 1, 1);
+                            if (i < SLCAP) lst[i] = make_int4(cc[k], vv[k], pp[k] - 1, INT_MAX); // (.w: the smallest OTHER position on the column, found below)
+                        }
+                }
+                return;
+            }
             if (nthere >= Q) { // a full group (wave-uniform)
 #pragma unroll
                 for (int q = 0; q < Q; q++)
@@ -692,12 +728,67 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_wstream(StreamArgs a)
 #pragma unroll
             for (int w2 = 0; w2 < WPB; w2++) lead_out = min(lead_out, mrow[4 + w2]);
         }
+        if constexpr (BLOOM) {
+            // Suspects are resolved against the row's INPUT, read again (the runs of W are read-only and L2-resident; reading the
+            // stored row back would wait for its stores to be acknowledged -- tens of microseconds while the chip streams writes).
+            // Every wave of the row scans its own chunks.  Every column has at most one entry that is no suspect (the first to reach
+            // its word).  A suspect s with other entries on its column: o = the smallest position of the others; o < s: s merges
+            // into o (said once, by the row's first wave); else s owns the column and the others that are no suspects themselves
+            // merge into s (a second scan, rare; the suspects among them say so on their own turn).  Nobody else: chance.
+            const int nsus = __builtin_amdgcn_readfirstlane(((lds_vint *)mrow)[1]);
+            if (nsus != 0 && nsus <= SLCAP) {
+                auto scan = [&](bool owners) {
+                    for (int g0 = 0; g0 < my_chunks; g0 += 8) {
+                        int2 e[8];
+                        int ps[8], nm[8];
+                        bool ok[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int g = min(g0 + u, my_chunks - 1);
+                            const int clen = __builtin_amdgcn_readlane(rec.w, g);
+                            e[u] = a.UPN[(size_t)(unsigned)__builtin_amdgcn_readlane(rec.z, g) + (unsigned)min(lane, clen - 1)];
+                            ps[u] = (int)((unsigned)__builtin_amdgcn_readlane(rec.x, g) >> 16) + lane;
+                            nm[u] = -__builtin_amdgcn_readlane(rec.y, g);
+                            ok[u] = g0 + u < my_chunks && lane < clen;
+                        }
+                        for (int i = 0; i < nsus; i++) {
+                            const int4 sp = lst[i];
+                            if (owners && !(sp.w != INT_MAX && sp.w > sp.z)) continue; // (uniform)
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                if (ok[u] && e[u].x == sp.x && ps[u] != sp.z) {
+                                    if (!owners) atomicMin(&lst[i].w, ps[u]);
+                                    else {
+                                        bool plain = true; // (not a suspect itself)
+                                        for (int j = 0; j < nsus; j++) plain = plain && lst[j].z != ps[u];
+                                        if (plain) stream_fix_push(mrow, fix, FCAP, sp.z, ps[u], stream_mul<SMALL>(F, nm[u], e[u].y));
+                                    }
+                                }
+                            }
+                        }
+                    }
+                };
+                scan(false);
+                if (!WAVE_ROW) lds_barrier();
+                bool any_owner = false;
+                for (int i = 0; i < nsus; i++) {
+                    const int4 sp = lst[i];
+                    if (sp.w == INT_MAX) continue;
+                    if (sp.w < sp.z) { if ((WAVE_ROW || wave == 0) && lane == 0) stream_fix_push(mrow, fix, FCAP, sp.w, sp.z, sp.y); }
+                    else any_owner = true;
+                }
+                if (any_owner) { // (the same on every wave of the row: they read the same words)
+                    scan(true);
+                    if (!WAVE_ROW) lds_barrier();
+                }
+            }
+        }
         // the lists are wave 0's business from here on (the other waves go on to reset the tables: nothing below touches those)
         if (WAVE_ROW || wave == 0) {
             bool redo = false;
             const int nlist = __builtin_amdgcn_readfirstlane(((lds_vint *)mrow)[1]); // (an LDS-qualified read: a generic one drains vmcnt too)
             redo = nlist > SLCAP;
-            if (nlist != 0 && !redo) {
+            if (!BLOOM && nlist != 0 && !redo) {
                 // entries that lost in all tables are in none: compare them among themselves (a handful)
                 for (int b = 0; b < nlist; b += 64) {
                     const int i = b + lane;

@@ -506,6 +506,23 @@ def test_schur_round_with_chunks_of_128_entries(S, O, monkeypatch, n, k, p, seed
     assert Sc.rows() == So.rows()
 
 
+@pytest.mark.parametrize("n,k,p,seed", [(20000, 20, 65521, 0x5A5A0003), (6000, 40, 127, 29), (3000, 60, 7, 31)])
+def test_schur_round_with_the_duplicate_check_as_a_filter(S, O, monkeypatch, n, k, p, seed):
+    """SPASM_AMD_BLOOM=1: the streaming kernels check for duplicate columns with a bitmap filter (three bits of one word per entry, one
+    returning ds_or) instead of the three exact tag tables, and resolve the suspects against the row's input at the end of the row.
+    Exact -- the Schur complement must be the oracle's, with many duplicates (p = 7, 60 per row) and few -- and slower on config 3
+    (DESIGN.md section 8): kept as a measured alternative."""
+    A = S.synth_csr(1, n, n, row_nnz=k, prime=p, seed=seed)
+    monkeypatch.setenv("SPASM_AMD_BLOOM", "1")
+    try:
+        Sc, st, p_out = run_plan(S, A)
+    finally:
+        monkeypatch.delenv("SPASM_AMD_BLOOM")
+    So, info = O.schur_round(A)
+    assert st["npiv"] == info["npiv"] and st["nnz_out"] == info["nnz_out"] and st["rows_out"] == info["rows_out"]
+    assert Sc.rows() == So.rows()
+
+
 def test_config3_full_size_counters_and_sampled_rows(S, O):
     """BASELINE config 3 at FULL size (1M x 1M, 20 nnz/row, p = 65521), the workload bench.py times.
     (a) The counters of the whole round equal the oracle's, committed as tests/golden/config3_oracle_counts.json by
